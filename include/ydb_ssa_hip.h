@@ -1,0 +1,159 @@
+/*
+ * C ABI of the MI355X executor for YDB column-shard SSA programs (libydb_ssa_hip.so).
+ *
+ * Every entry point replaces one interface of the reference's CPU path; the cited file:line
+ * is the reference code a host shim would stop calling.  Plain pointers and sizes only: batches
+ * cross the boundary through the Arrow C Data Interface (struct ArrowArray / ArrowSchema as in
+ * contrib/libs/apache/arrow/cpp/src/arrow/c/abi.h), programs as the serialized protobuf a
+ * ColumnShard receives.  All functions are thread-safe unless stated otherwise; none aborts.
+ */
+#ifndef YDB_SSA_HIP_H
+#define YDB_SSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct ArrowArray;
+struct ArrowSchema;
+
+typedef struct ssa_program ssa_program_t; /* parsed program + executor (one HIP stream) */
+typedef struct ssa_batch ssa_batch_t;     /* record batch resident in HBM */
+
+/* Return codes.  SSA_UNSUPPORTED means "valid program, not executable on the GPU path": the shim
+ * falls back to the CPU NSsa::TProgram::ApplyTo.  SSA_INVALID corresponds to a non-OK arrow::Status
+ * from the reference path (program.h:435-447), SSA_PARSE_ERROR to TProgramContainer::Init == false. */
+enum ssa_status {
+    SSA_OK = 0,
+    SSA_INVALID = 1,
+    SSA_PARSE_ERROR = 2,
+    SSA_UNSUPPORTED = 3,
+    SSA_HIP_ERROR = 4
+};
+
+/* Arrow type ids used by ssa_device_column (the column types a ColumnShard produces:
+ * ydb/core/formats/arrow/switch/switch_type.h:125-172). */
+enum ssa_type {
+    SSA_T_BOOL = 1, SSA_T_INT8 = 2, SSA_T_INT16 = 3, SSA_T_INT32 = 4, SSA_T_INT64 = 5,
+    SSA_T_UINT8 = 6, SSA_T_UINT16 = 7, SSA_T_UINT32 = 8, SSA_T_UINT64 = 9,
+    SSA_T_FLOAT = 10, SSA_T_DOUBLE = 11, SSA_T_TIMESTAMP_US = 12, SSA_T_DURATION_US = 13,
+    SSA_T_STRING = 14, SSA_T_BINARY = 15, SSA_T_DECIMAL128 = 16
+};
+
+/* Library / device set-up.  Returns the number of visible HIP devices or a negative ssa_status. */
+int ssa_device_count(void);
+const char* ssa_version(void);
+/* Frees a message returned through an `err` out-parameter. */
+void ssa_free_string(char* s);
+
+/*
+ * Parse a program.  Replaces NOlap::TProgramContainer::Init (ydb/core/tx/program/program.cpp:481-551):
+ *  - `program` / `program_size`: serialized NKikimrSSA::TOlapProgram when `olap_wrapper` != 0
+ *    (EOlapProgramType::OLAP_PROGRAM_SSA_PROGRAM_WITH_PARAMETERS), else a bare NKikimrSSA::TProgram.
+ *  - `col_ids` / `col_names` / `ncols`: the IColumnResolver (ydb/core/tx/program/program.h:17-25); the
+ *    first entry doubles as GetDefaultColumn() for `SELECT count(*)`.
+ *  - `params` / `params_schema` (may be NULL): the deserialized TOlapProgram.Parameters batch (one row).
+ *  - `device`: HIP device the program's executor is bound to.
+ * On failure returns SSA_PARSE_ERROR and a malloc'd message in *err (may be NULL).
+ */
+int ssa_program_create(const uint8_t* program, size_t program_size, int olap_wrapper,
+                       const uint32_t* col_ids, const char* const* col_names, size_t ncols,
+                       const struct ArrowArray* params, const struct ArrowSchema* params_schema,
+                       int device, ssa_program_t** out, char** err);
+void ssa_program_destroy(ssa_program_t* program);
+
+/* TProgram::DebugString (ydb/core/formats/arrow/program.h:451-459); malloc'd, free with ssa_free_string. */
+char* ssa_program_debug_string(const ssa_program_t* program);
+/* TProgramContainer::GetSourceColumns / GetEarlyFilterColumns (tx/program/program.cpp:463-479):
+ * newline-separated column names; malloc'd. */
+char* ssa_program_source_columns(const ssa_program_t* program);
+char* ssa_program_early_filter_columns(const ssa_program_t* program);
+size_t ssa_program_step_count(const ssa_program_t* program);
+/* Host-only: lowers every step against `schema` (a struct ArrowSchema; ARROW_FLAG_NULLABLE marks columns
+ * that carry nulls) and returns the scan plans plus the output schema as text, or NULL and *err.  This is the
+ * type-inference half of TProgramStep::Apply (which Arrow kernel DispatchBest would pick, program.cpp:51-78)
+ * without touching a GPU. */
+char* ssa_program_explain(const ssa_program_t* program, const struct ArrowSchema* schema, char** err);
+
+/*
+ * Whole-program seam.  Replaces NSsa::TProgram::ApplyTo(std::shared_ptr<arrow::RecordBatch>&, ExecContext*)
+ * (ydb/core/formats/arrow/program.h:435-447; callers: engines/reader/plain_reader/iterator/merge.cpp:36):
+ * imports the batch (honouring ArrowArray.offset of sliced columns), runs every step on the GPU and exports
+ * the result.  `in` is not released; `out` / `out_schema` are filled with arrays owned by the library until
+ * their release callbacks run.
+ */
+int ssa_program_apply(ssa_program_t* program, const struct ArrowArray* in, const struct ArrowSchema* in_schema,
+                      struct ArrowArray* out, struct ArrowSchema* out_schema, char** err);
+
+/*
+ * Early-filter seam.  Replaces NSsa::TProgramStep::BuildFilter (ydb/core/formats/arrow/program.cpp:921-946,
+ * caller engines/reader/plain_reader/iterator/fetching.cpp:74-86): evaluates the Assigns and Filters of step
+ * `step_index` only and returns the combined filter as an Arrow-order bitmap (bit i of byte i/8, LSB first,
+ * ceil(rows/8) bytes, caller-allocated) plus the number of selected rows.
+ */
+int ssa_program_build_filter(ssa_program_t* program, size_t step_index, const struct ArrowArray* in,
+                             const struct ArrowSchema* in_schema, uint8_t* out_bits, int64_t* out_selected, char** err);
+
+/* ---- HBM-resident batches: the same seam without the PCIe crossing ------------------------------------ */
+
+/* Upload a RecordBatch (H2D copy of every buffer, offsets re-based). */
+int ssa_batch_import(ssa_program_t* program, const struct ArrowArray* in, const struct ArrowSchema* in_schema,
+                     ssa_batch_t** out, char** err);
+
+/* Column already in device memory (not copied, not owned; must outlive the batch). */
+struct ssa_device_column {
+    const char* name;
+    int32_t type;          /* enum ssa_type */
+    int32_t reserved;
+    const void* values;    /* fixed width: values; BOOL: bitmap; STRING/BINARY: int32 offsets (rows + 1) */
+    const uint8_t* validity; /* bitmap, NULL = no nulls */
+    const uint8_t* chars;  /* STRING/BINARY bytes */
+    int64_t chars_size;
+    int64_t null_count;    /* -1 = unknown */
+};
+int ssa_batch_from_device(const struct ssa_device_column* cols, size_t ncols, int64_t rows, ssa_batch_t** out, char** err);
+
+/* TProgram::ApplyTo on an HBM-resident batch; the result stays in HBM. */
+int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_batch_t** out, char** err);
+/* Download a batch into Arrow C Data structures. */
+int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, struct ArrowArray* out,
+                     struct ArrowSchema* out_schema, char** err);
+int64_t ssa_batch_rows(const ssa_batch_t* batch);
+size_t ssa_batch_columns(const ssa_batch_t* batch);
+void ssa_batch_destroy(ssa_batch_t* batch);
+
+/* ---- measurement ------------------------------------------------------------------------------------------ */
+
+/* When enabled, every fused scan kernel launch of this program is bracketed by HIP events on the program's
+ * stream.  ssa_profile_read returns and clears: accumulated kernel milliseconds, launches, and algorithmic
+ * bytes (each referenced source column counted once per launch). */
+void ssa_profile_enable(ssa_program_t* program, int enabled);
+void ssa_profile_read(ssa_program_t* program, double* scan_ms, int64_t* launches, int64_t* algorithmic_bytes);
+
+/* ---- synthetic TPC-H lineitem generated in HBM (benchmark / parity input) ----------------------------------- */
+
+/* Fills caller-provided device arrays with rows [row0, row0 + nrows) of the deterministic synthetic lineitem
+ * (counter-based splitmix64 of `seed`, column id and row number).  Any pointer may be NULL to skip that column. */
+struct ssa_lineitem_columns {
+    int32_t* l_shipdate;      /* days since epoch */
+    double* l_quantity;
+    double* l_extendedprice;
+    double* l_discount;
+    double* l_tax;
+    int32_t* rf_offsets;      /* l_returnflag utf8: nrows + 1 offsets */
+    uint8_t* rf_chars;
+    int32_t* ls_offsets;      /* l_linestatus utf8 */
+    uint8_t* ls_chars;
+    int8_t* rf_code;          /* dictionary codes: 0 = "A", 1 = "N", 2 = "R" */
+    int8_t* ls_code;          /* 0 = "F", 1 = "O" */
+};
+int ssa_gen_lineitem(const struct ssa_lineitem_columns* cols, int64_t row0, int64_t nrows, uint64_t seed, int device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* YDB_SSA_HIP_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libydb_ssa_hip.so (see include/ydb_ssa_hip.h).
+
+The library is loaded from the in-tree build directory only; importing this module fails loudly
+if it has not been built -- there is no CPU fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .arrow_c import ArrowArray, ArrowSchema
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libydb_ssa_hip.so")
+
+SSA_OK, SSA_INVALID, SSA_PARSE_ERROR, SSA_UNSUPPORTED, SSA_HIP_ERROR = range(5)
+STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "PARSE_ERROR", 3: "UNSUPPORTED", 4: "HIP_ERROR"}
+
+
+class DeviceColumn(ctypes.Structure):
+    _fields_ = [
+        ("name", ctypes.c_char_p),
+        ("type", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("values", ctypes.c_void_p),
+        ("validity", ctypes.c_void_p),
+        ("chars", ctypes.c_void_p),
+        ("chars_size", ctypes.c_int64),
+        ("null_count", ctypes.c_int64),
+    ]
+
+
+class LineitemColumns(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "l_shipdate", "l_quantity", "l_extendedprice", "l_discount", "l_tax",
+        "rf_offsets", "rf_chars", "ls_offsets", "ls_chars", "rf_code", "ls_code")]
+
+
+# Every symbol include/ydb_ssa_hip.h declares.
+EXPORTED_SYMBOLS = [
+    "ssa_device_count", "ssa_version", "ssa_free_string", "ssa_program_create", "ssa_program_destroy",
+    "ssa_program_debug_string", "ssa_program_source_columns", "ssa_program_early_filter_columns",
+    "ssa_program_step_count", "ssa_program_explain", "ssa_program_apply", "ssa_program_build_filter", "ssa_batch_import",
+    "ssa_batch_from_device", "ssa_program_apply_device", "ssa_batch_export", "ssa_batch_rows",
+    "ssa_batch_columns", "ssa_batch_destroy", "ssa_profile_enable", "ssa_profile_read", "ssa_gen_lineitem",
+]
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The executor has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    P = ctypes.POINTER
+    vp, cp, i64, i32, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+    lib.ssa_device_count.restype = i32
+    lib.ssa_version.restype = cp
+    lib.ssa_free_string.argtypes = [vp]
+    lib.ssa_program_create.argtypes = [vp, sz, i32, P(ctypes.c_uint32), P(cp), sz, P(ArrowArray), P(ArrowSchema), i32,
+                                       P(vp), P(vp)]
+    lib.ssa_program_create.restype = i32
+    lib.ssa_program_destroy.argtypes = [vp]
+    for f in (lib.ssa_program_debug_string, lib.ssa_program_source_columns, lib.ssa_program_early_filter_columns):
+        f.argtypes = [vp]
+        f.restype = vp
+    lib.ssa_program_step_count.argtypes = [vp]
+    lib.ssa_program_step_count.restype = sz
+    lib.ssa_program_explain.argtypes = [vp, P(ArrowSchema), P(vp)]
+    lib.ssa_program_explain.restype = vp
+    lib.ssa_program_apply.argtypes = [vp, P(ArrowArray), P(ArrowSchema), P(ArrowArray), P(ArrowSchema), P(vp)]
+    lib.ssa_program_apply.restype = i32
+    lib.ssa_program_build_filter.argtypes = [vp, sz, P(ArrowArray), P(ArrowSchema), vp, P(i64), P(vp)]
+    lib.ssa_program_build_filter.restype = i32
+    lib.ssa_batch_import.argtypes = [vp, P(ArrowArray), P(ArrowSchema), P(vp), P(vp)]
+    lib.ssa_batch_import.restype = i32
+    lib.ssa_batch_from_device.argtypes = [P(DeviceColumn), sz, i64, P(vp), P(vp)]
+    lib.ssa_batch_from_device.restype = i32
+    lib.ssa_program_apply_device.argtypes = [vp, vp, P(vp), P(vp)]
+    lib.ssa_program_apply_device.restype = i32
+    lib.ssa_batch_export.argtypes = [vp, vp, P(ArrowArray), P(ArrowSchema), P(vp)]
+    lib.ssa_batch_export.restype = i32
+    lib.ssa_batch_rows.argtypes = [vp]
+    lib.ssa_batch_rows.restype = i64
+    lib.ssa_batch_columns.argtypes = [vp]
+    lib.ssa_batch_columns.restype = sz
+    lib.ssa_batch_destroy.argtypes = [vp]
+    lib.ssa_profile_enable.argtypes = [vp, i32]
+    lib.ssa_profile_read.argtypes = [vp, P(ctypes.c_double), P(i64), P(i64)]
+    lib.ssa_gen_lineitem.argtypes = [P(LineitemColumns), i64, i64, ctypes.c_uint64, i32]
+    lib.ssa_gen_lineitem.restype = i32
+    _lib = lib
+    return lib
+
+
+def take_string(lib, ptr) -> str:
+    if not ptr:
+        return ""
+    s = ctypes.string_at(ptr).decode(errors="replace")
+    lib.ssa_free_string(ptr)
+    return s

@@ -1,0 +1,350 @@
+// extern "C" boundary: see include/ydb_ssa_hip.h for the contract of every entry point.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+
+#include "../../include/ydb_ssa_hip.h"
+#include "exec.h"
+#include "program.h"
+#include "vm_ops.h"
+
+using namespace ssa;
+
+struct ssa_program {
+    TProgramContainer Container;
+    std::unique_ptr<Executor> Exec;
+    std::mutex Lock;  // one HIP stream per program: concurrent applies on one handle are serialised
+    int Device = 0;
+};
+
+struct ssa_batch {
+    BatchPtr Batch;
+};
+
+namespace {
+
+char* DupString(const std::string& s) {
+    char* p = static_cast<char*>(std::malloc(s.size() + 1));
+    if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+int Fail(const Status& st, char** err) {
+    if (err) *err = DupString(st.Msg);
+    switch (st.Code) {
+        case ST_OK: return SSA_OK;
+        case ST_INVALID: return SSA_INVALID;
+        case ST_PARSE_ERROR: return SSA_PARSE_ERROR;
+        case ST_UNSUPPORTED: return SSA_UNSUPPORTED;
+        default: return SSA_HIP_ERROR;
+    }
+}
+
+// First row of a one-row parameters batch -> named scalars (tx/program/program.cpp:338-356).
+Status ReadParameters(const ArrowArray* arr, const ArrowSchema* schema, TParameters& out) {
+    if (!arr || !schema) return Status::OK();
+    if (!schema->format || std::string(schema->format) != "+s") return Status::Invalid("parameters: expected a struct array");
+    for (int64_t i = 0; i < arr->n_children; ++i) {
+        const ArrowArray* a = arr->children[i];
+        const ArrowSchema* s = schema->children[i];
+        if (a->length != 1) continue;  // "Incorrect values count in parameter array" -> parameter unusable
+        const std::string fmt = s->format ? s->format : "";
+        TScalar sc;
+        const int64_t off = a->offset;
+        const uint8_t* validity = a->n_buffers > 0 ? static_cast<const uint8_t*>(a->buffers[0]) : nullptr;
+        sc.Valid = !(validity && a->null_count != 0 && !((validity[off >> 3] >> (off & 7)) & 1));
+        const void* v = a->n_buffers > 1 ? a->buffers[1] : nullptr;
+        auto num = [&](int type, uint64_t bits) {
+            sc.Type = type;
+            sc.Bits = bits;
+        };
+        if (fmt == "b") num(T_BOOL, (static_cast<const uint8_t*>(v)[off >> 3] >> (off & 7)) & 1);
+        else if (fmt == "c") num(T_I8, uint64_t(int64_t(static_cast<const int8_t*>(v)[off])));
+        else if (fmt == "C") num(T_U8, static_cast<const uint8_t*>(v)[off]);
+        else if (fmt == "s") num(T_I16, uint64_t(int64_t(static_cast<const int16_t*>(v)[off])));
+        else if (fmt == "S") num(T_U16, static_cast<const uint16_t*>(v)[off]);
+        else if (fmt == "i") num(T_I32, uint64_t(int64_t(static_cast<const int32_t*>(v)[off])));
+        else if (fmt == "I") num(T_U32, static_cast<const uint32_t*>(v)[off]);
+        else if (fmt == "l") num(T_I64, uint64_t(static_cast<const int64_t*>(v)[off]));
+        else if (fmt == "L") num(T_U64, static_cast<const uint64_t*>(v)[off]);
+        else if (fmt == "f") num(T_F32, F64ToBits(double(static_cast<const float*>(v)[off])));
+        else if (fmt == "g") num(T_F64, F64ToBits(static_cast<const double*>(v)[off]));
+        else if (fmt.rfind("tsu:", 0) == 0) num(T_TS, uint64_t(static_cast<const int64_t*>(v)[off]));
+        else if (fmt == "u" || fmt == "z") {
+            sc.Type = fmt == "u" ? T_STRING : T_BINARY;
+            const int32_t* offs = static_cast<const int32_t*>(a->buffers[1]);
+            const char* chars = static_cast<const char*>(a->buffers[2]);
+            sc.Bytes.assign(chars + offs[off], size_t(offs[off + 1] - offs[off]));
+        } else {
+            continue;
+        }
+        out[s->name ? s->name : ""] = sc;
+    }
+    return Status::OK();
+}
+
+// Parsing needs no GPU; executing does.  There is deliberately no CPU fallback behind this boundary.
+Status EnsureExecutor(ssa_program* p) {
+    if (p->Exec) return Status::OK();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        return Status::Hip("no HIP device: the GPU executor cannot run here (this library has no CPU fallback)");
+    }
+    if (p->Device < 0 || p->Device >= ndev) return Status::Invalid("bad device index");
+    p->Exec = std::make_unique<Executor>(p->Device);
+    return Status::OK();
+}
+
+char* JoinNames(const std::set<std::string>& names) {
+    std::string s;
+    for (auto& n : names) {
+        if (!s.empty()) s += "\n";
+        s += n;
+    }
+    return DupString(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -SSA_HIP_ERROR;
+    return n;
+}
+
+const char* ssa_version(void) { return "ydb-ssa-hip 0.1 (gfx950)"; }
+
+void ssa_free_string(char* s) { std::free(s); }
+
+int ssa_program_create(const uint8_t* program, size_t program_size, int olap_wrapper, const uint32_t* col_ids,
+                       const char* const* col_names, size_t ncols, const ArrowArray* params,
+                       const ArrowSchema* params_schema, int device, ssa_program_t** out, char** err) {
+    if (err) *err = nullptr;
+    if (!out) return SSA_INVALID;
+    *out = nullptr;
+    TMapColumnResolver resolver;
+    for (size_t i = 0; i < ncols; ++i) resolver.Add(col_ids[i], col_names[i] ? col_names[i] : "");
+    TParameters parameters;
+    Status st = ReadParameters(params, params_schema, parameters);
+    if (!st.ok()) return Fail(st, err);
+    auto p = std::make_unique<ssa_program>();
+    std::string error;
+    if (!p->Container.Init(resolver, program, program_size, olap_wrapper != 0, parameters, error)) {
+        return Fail(Status{ST_PARSE_ERROR, error}, err);
+    }
+    p->Device = device;  // the executor (HIP stream, device buffers) is created at first use
+    *out = p.release();
+    return SSA_OK;
+}
+
+void ssa_program_destroy(ssa_program_t* program) { delete program; }
+
+char* ssa_program_debug_string(const ssa_program_t* program) {
+    return DupString(program->Container.GetProgram()->DebugString());
+}
+
+char* ssa_program_source_columns(const ssa_program_t* program) {
+    return JoinNames(program->Container.GetProgram()->GetProcessingColumns());
+}
+
+char* ssa_program_early_filter_columns(const ssa_program_t* program) {
+    return JoinNames(program->Container.GetProgram()->GetEarlyFilterColumns());
+}
+
+size_t ssa_program_step_count(const ssa_program_t* program) { return program->Container.GetProgram()->Steps.size(); }
+
+char* ssa_program_explain(const ssa_program_t* program, const ArrowSchema* schema, char** err) {
+    if (err) *err = nullptr;
+    std::vector<FieldDesc> fields;
+    Status st = SchemaFields(schema, fields);
+    if (!st.ok()) {
+        Fail(st, err);
+        return nullptr;
+    }
+    std::string text;
+    for (auto& step : program->Container.GetProgram()->Steps) {
+        StepPlan plan;
+        st = CompileStep(*step, fields, CM_FULL, plan);
+        if (!st.ok()) {
+            Fail(st, err);
+            return nullptr;
+        }
+        text += plan.DebugString() + "\n";
+        std::vector<FieldDesc> next;
+        for (auto& oc : plan.Outs) {
+            FieldDesc f;
+            f.Name = oc.Name;
+            f.Type = oc.Type;
+            f.Nullable = oc.Nullable;
+            next.push_back(f);
+        }
+        fields = next;
+    }
+    text += "schema:";
+    for (auto& f : fields) text += " " + f.Name + ":" + std::to_string(f.Type);
+    return DupString(text);
+}
+
+int ssa_program_apply(ssa_program_t* program, const ArrowArray* in, const ArrowSchema* in_schema, ArrowArray* out,
+                      ArrowSchema* out_schema, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    BatchPtr batch, result;
+    Status st = program->Exec->ImportBatch(in, in_schema, batch);
+    if (!st.ok()) return Fail(st, err);
+    st = program->Exec->ApplyProgram(*program->Container.GetProgram(), batch, result);
+    if (!st.ok()) return Fail(st, err);
+    st = program->Exec->ExportBatch(*result, out, out_schema);
+    if (!st.ok()) return Fail(st, err);
+    return SSA_OK;
+}
+
+int ssa_program_build_filter(ssa_program_t* program, size_t step_index, const ArrowArray* in, const ArrowSchema* in_schema,
+                             uint8_t* out_bits, int64_t* out_selected, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    auto& steps = program->Container.GetProgram()->Steps;
+    if (step_index >= steps.size()) return Fail(Status::Invalid("no such step"), err);
+    BatchPtr batch;
+    Status st = program->Exec->ImportBatch(in, in_schema, batch);
+    if (!st.ok()) return Fail(st, err);
+    if (steps[step_index]->Filters.empty()) {  // BuildFilter returns nullptr: everything passes
+        std::memset(out_bits, 0xFF, size_t((batch->Rows + 7) / 8));
+        if (batch->Rows & 7) out_bits[batch->Rows / 8] = uint8_t((1u << (batch->Rows & 7)) - 1);
+        if (out_selected) *out_selected = batch->Rows;
+        return SSA_OK;
+    }
+    std::vector<uint8_t> bits;
+    int64_t selected = 0;
+    st = program->Exec->BuildFilter(*steps[step_index], batch, bits, selected);
+    if (!st.ok()) return Fail(st, err);
+    std::memcpy(out_bits, bits.data(), bits.size());
+    if (out_selected) *out_selected = selected;
+    return SSA_OK;
+}
+
+int ssa_batch_import(ssa_program_t* program, const ArrowArray* in, const ArrowSchema* in_schema, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    BatchPtr batch;
+    Status st = program->Exec->ImportBatch(in, in_schema, batch);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_batch{batch};
+    return SSA_OK;
+}
+
+int ssa_batch_from_device(const ssa_device_column* cols, size_t ncols, int64_t rows, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    auto batch = std::make_shared<Batch>();
+    batch->Rows = rows;
+    for (size_t i = 0; i < ncols; ++i) {
+        const ssa_device_column& c = cols[i];
+        Column col;
+        col.Field.Name = c.name ? c.name : "";
+        col.Field.Type = c.type;
+        col.Length = rows;
+        if (c.type < T_BOOL || c.type > T_DEC128) return Fail(Status::Invalid("bad column type"), err);
+        const int w = IsStringLike(c.type) ? 4 : TypeWidth(c.type);
+        size_t bytes = (c.type == T_BOOL) ? size_t((rows + 7) / 8) : size_t(rows + (IsStringLike(c.type) ? 1 : 0)) * w;
+        col.Values = Buffer::Wrap(const_cast<void*>(c.values), bytes);
+        if (c.validity && c.null_count != 0) {
+            col.Validity = Buffer::Wrap(const_cast<uint8_t*>(c.validity), size_t((rows + 7) / 8));
+            col.Field.Nullable = true;
+        }
+        col.NullCount = c.validity ? c.null_count : 0;
+        if (IsStringLike(c.type)) col.Chars = Buffer::Wrap(const_cast<uint8_t*>(c.chars), size_t(c.chars_size) + 16);
+        batch->Cols.push_back(std::move(col));
+    }
+    *out = new ssa_batch{batch};
+    return SSA_OK;
+}
+
+int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    BatchPtr result;
+    Status st = program->Exec->ApplyProgram(*program->Container.GetProgram(), in->Batch, result);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_batch{result};
+    return SSA_OK;
+}
+
+int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, ArrowArray* out, ArrowSchema* out_schema, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    Status st = program->Exec->ExportBatch(*batch->Batch, out, out_schema);
+    if (!st.ok()) return Fail(st, err);
+    return SSA_OK;
+}
+
+int64_t ssa_batch_rows(const ssa_batch_t* batch) { return batch->Batch->Rows; }
+size_t ssa_batch_columns(const ssa_batch_t* batch) { return batch->Batch->Cols.size(); }
+void ssa_batch_destroy(ssa_batch_t* batch) { delete batch; }
+
+void ssa_profile_enable(ssa_program_t* program, int enabled) {
+    std::lock_guard<std::mutex> g(program->Lock);
+    if (!EnsureExecutor(program).ok()) return;
+    program->Exec->Profile.Enabled = enabled != 0;
+}
+
+void ssa_profile_read(ssa_program_t* program, double* scan_ms, int64_t* launches, int64_t* algorithmic_bytes) {
+    std::lock_guard<std::mutex> g(program->Lock);
+    if (scan_ms) *scan_ms = 0;
+    if (launches) *launches = 0;
+    if (algorithmic_bytes) *algorithmic_bytes = 0;
+    if (!program->Exec) return;
+    KernelProfile& p = program->Exec->Profile;
+    if (scan_ms) *scan_ms = p.ScanMs;
+    if (launches) *launches = p.ScanLaunches;
+    if (algorithmic_bytes) *algorithmic_bytes = p.ScanBytes;
+    p.ScanMs = 0;
+    p.ScanLaunches = 0;
+    p.ScanBytes = 0;
+}
+
+int ssa_gen_lineitem(const ssa_lineitem_columns* cols, int64_t row0, int64_t nrows, uint64_t seed, int device) {
+    if (hipSetDevice(device) != hipSuccess) return SSA_HIP_ERROR;
+    LineitemColumns c{};
+    c.l_shipdate = cols->l_shipdate;
+    c.l_quantity = cols->l_quantity;
+    c.l_extendedprice = cols->l_extendedprice;
+    c.l_discount = cols->l_discount;
+    c.l_tax = cols->l_tax;
+    c.rf_offsets = cols->rf_offsets;
+    c.rf_chars = cols->rf_chars;
+    c.ls_offsets = cols->ls_offsets;
+    c.ls_chars = cols->ls_chars;
+    c.rf_code = cols->rf_code;
+    c.ls_code = cols->ls_code;
+    if (LaunchGenLineitem(c, row0, nrows, seed, nullptr) != hipSuccess) return SSA_HIP_ERROR;
+    if (hipDeviceSynchronize() != hipSuccess) return SSA_HIP_ERROR;
+    return SSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,970 @@
+#include "exec.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "vm_ops.h"
+
+namespace ssa {
+
+#define SSA_HIP(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return Status::Hip(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+#define SSA_RETURN_NOT_OK(expr)     \
+    do {                            \
+        Status s_ = (expr);         \
+        if (!s_.ok()) return s_;    \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device memory
+// ---------------------------------------------------------------------------------------------
+namespace {
+size_t BucketSize(size_t bytes) {
+    size_t b = 256;
+    while (b < bytes) b <<= 1;
+    if (b > (size_t(1) << 26)) b = (bytes + (size_t(1) << 26) - 1) & ~((size_t(1) << 26) - 1);  // 64 MiB steps above 64 MiB
+    return b;
+}
+}  // namespace
+
+DevPool& DevPool::Instance() {
+    static DevPool pool;
+    return pool;
+}
+
+void* DevPool::Alloc(size_t bytes) {
+    const size_t b = BucketSize(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> g(Lock);
+        auto it = FreeLists.find(b);
+        if (it != FreeLists.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            InUse += b;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, b) != hipSuccess) {
+        Trim();
+        if (hipMalloc(&p, b) != hipSuccess) return nullptr;
+    }
+    std::lock_guard<std::mutex> g(Lock);
+    InUse += b;
+    return p;
+}
+
+void DevPool::Free(void* p, size_t bytes) {
+    if (!p) return;
+    const size_t b = BucketSize(bytes ? bytes : 1);
+    std::lock_guard<std::mutex> g(Lock);
+    InUse -= b;
+    FreeLists[b].push_back(p);
+}
+
+void DevPool::Trim() {
+    std::lock_guard<std::mutex> g(Lock);
+    for (auto& kv : FreeLists) {
+        for (void* p : kv.second) (void)hipFree(p);
+        kv.second.clear();
+    }
+}
+
+Buffer::~Buffer() {
+    if (Owned) DevPool::Instance().Free(Ptr, Size);
+}
+
+BufferPtr Buffer::Alloc(size_t bytes) {
+    auto b = std::make_shared<Buffer>();
+    b->Ptr = DevPool::Instance().Alloc(bytes);
+    b->Size = bytes;
+    b->Owned = true;
+    if (!b->Ptr) return nullptr;
+    return b;
+}
+
+BufferPtr Buffer::Wrap(void* p, size_t bytes) {
+    auto b = std::make_shared<Buffer>();
+    b->Ptr = p;
+    b->Size = bytes;
+    b->Owned = false;
+    return b;
+}
+
+const void* Column::ValuesPtr() const {
+    if (!Values) return nullptr;
+    const int w = IsStringLike(Field.Type) ? 4 : TypeWidth(Field.Type);
+    return static_cast<const char*>(Values->Ptr) + ElemOffset * w;
+}
+
+std::vector<FieldDesc> Batch::Schema() const {
+    std::vector<FieldDesc> s;
+    for (auto& c : Cols) s.push_back(c.Field);
+    return s;
+}
+
+int Batch::FindColumn(const std::string& name) const {
+    int found = -1, count = 0;
+    for (size_t i = 0; i < Cols.size(); ++i) {
+        if (Cols[i].Field.Name == name) {
+            found = int(i);
+            ++count;
+        }
+    }
+    return count == 1 ? found : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// executor basics
+// ---------------------------------------------------------------------------------------------
+Executor::Executor(int device) : Device(device) {
+    (void)hipSetDevice(device);
+    (void)hipStreamCreateWithFlags(&StreamHandle, hipStreamNonBlocking);
+    (void)hipEventCreate(&EvStart);
+    (void)hipEventCreate(&EvStop);
+    (void)ConfigureScanKernels(160 * 1024);
+    StatusWord = Buffer::Alloc(256);
+    if (StatusWord) (void)hipMemset(StatusWord->Ptr, 0, 256);
+}
+
+Executor::~Executor() {
+    if (StreamHandle) (void)hipStreamSynchronize(StreamHandle);
+    if (EvStart) (void)hipEventDestroy(EvStart);
+    if (EvStop) (void)hipEventDestroy(EvStop);
+    if (StreamHandle) (void)hipStreamDestroy(StreamHandle);
+}
+
+Status Executor::Sync() {
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    return Status::OK();
+}
+
+void Executor::ProfileBegin() {
+    if (Profile.Enabled) (void)hipEventRecord(EvStart, StreamHandle);
+}
+
+void Executor::ProfileEnd(const char* kernel, int64_t algoBytes) {
+    if (!Profile.Enabled) return;
+    (void)hipEventRecord(EvStop, StreamHandle);
+    (void)hipEventSynchronize(EvStop);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, EvStart, EvStop);
+    Profile.ScanMs += ms;
+    Profile.ScanLaunches += 1;
+    Profile.ScanBytes += algoBytes;
+    Profile.LastKernel = kernel;
+}
+
+Status Executor::CheckScanStatus() {
+    uint32_t st = 0;
+    SSA_HIP(hipMemcpyAsync(&st, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    if (st == 0) return Status::OK();
+    SSA_HIP(hipMemsetAsync(StatusWord->Ptr, 0, sizeof(st), StreamHandle));
+    if (st & SCAN_DIV_BY_ZERO) return Status::Invalid("divide by zero");
+    if (st & SCAN_CAST_OVERFLOW) return Status::Invalid("Integer value not in range");
+    return Status::Invalid("scan kernel reported status " + std::to_string(st));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Arrow C Data Interface: import (host -> HBM)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+bool ParseFormat(const char* fmt, int32_t& type, int32_t& prec, int32_t& scale) {
+    prec = scale = 0;
+    const std::string f(fmt ? fmt : "");
+    if (f == "b") type = T_BOOL;
+    else if (f == "c") type = T_I8;
+    else if (f == "C") type = T_U8;
+    else if (f == "s") type = T_I16;
+    else if (f == "S") type = T_U16;
+    else if (f == "i") type = T_I32;
+    else if (f == "I") type = T_U32;
+    else if (f == "l") type = T_I64;
+    else if (f == "L") type = T_U64;
+    else if (f == "f") type = T_F32;
+    else if (f == "g") type = T_F64;
+    else if (f == "u") type = T_STRING;
+    else if (f == "z") type = T_BINARY;
+    else if (f.rfind("tsu:", 0) == 0) type = T_TS;
+    else if (f == "tDu") type = T_DUR;
+    else if (f.rfind("d:", 0) == 0) {
+        type = T_DEC128;
+        int bits = 128;
+        if (sscanf(f.c_str(), "d:%d,%d,%d", &prec, &scale, &bits) < 2) return false;
+        if (bits != 128) return false;
+    } else {
+        return false;
+    }
+    return true;
+}
+
+std::string FormatOf(const FieldDesc& f) {
+    switch (f.Type) {
+        case T_BOOL: return "b";
+        case T_I8: return "c";
+        case T_U8: return "C";
+        case T_I16: return "s";
+        case T_U16: return "S";
+        case T_I32: return "i";
+        case T_U32: return "I";
+        case T_I64: return "l";
+        case T_U64: return "L";
+        case T_F32: return "f";
+        case T_F64: return "g";
+        case T_STRING: return "u";
+        case T_BINARY: return "z";
+        case T_TS: return "tsu:";
+        case T_DUR: return "tDu";
+        case T_DEC128: return "d:" + std::to_string(f.Precision) + "," + std::to_string(f.Scale);
+        default: return "n";
+    }
+}
+
+// Copy `nbits` bits starting at bit `off` of `src` into a fresh bitmap that starts at bit 0.
+std::vector<uint8_t> RealignBits(const uint8_t* src, int64_t off, int64_t nbits) {
+    std::vector<uint8_t> out(size_t((nbits + 7) / 8), 0);
+    if ((off & 7) == 0) {
+        std::memcpy(out.data(), src + (off >> 3), out.size());
+    } else {
+        for (int64_t i = 0; i < nbits; ++i) {
+            const int64_t b = off + i;
+            if ((src[b >> 3] >> (b & 7)) & 1) out[size_t(i >> 3)] |= uint8_t(1u << (i & 7));
+        }
+    }
+    if (nbits & 7) out.back() &= uint8_t((1u << (nbits & 7)) - 1);
+    return out;
+}
+
+int64_t CountSetBits(const std::vector<uint8_t>& bits) {
+    int64_t c = 0;
+    for (uint8_t b : bits) c += __builtin_popcount(b);
+    return c;
+}
+
+}  // namespace
+
+Status SchemaFields(const ArrowSchema* schema, std::vector<FieldDesc>& out) {
+    if (!schema || !schema->format || std::string(schema->format) != "+s") return Status::Invalid("expected a struct schema");
+    for (int64_t i = 0; i < schema->n_children; ++i) {
+        const ArrowSchema* s = schema->children[i];
+        FieldDesc f;
+        f.Name = s->name ? s->name : "";
+        if (!ParseFormat(s->dictionary ? s->dictionary->format : s->format, f.Type, f.Precision, f.Scale)) {
+            return Status::Unsupported(std::string("Arrow format '") + (s->format ? s->format : "") + "'");
+        }
+        f.Nullable = (s->flags & ARROW_FLAG_NULLABLE) != 0;
+        out.push_back(f);
+    }
+    return Status::OK();
+}
+
+Status Executor::ImportBatch(const ArrowArray* array, const ArrowSchema* schema, BatchPtr& out) {
+    if (!array || !schema || !schema->format) return Status::Invalid("null ArrowArray / ArrowSchema");
+    if (std::string(schema->format) != "+s") return Status::Invalid("expected a struct array (an exported RecordBatch)");
+    if (array->n_children != schema->n_children) return Status::Invalid("schema / array children mismatch");
+    if (array->offset != 0) return Status::Unsupported("sliced top-level struct array");
+    (void)hipSetDevice(Device);
+    auto batch = std::make_shared<Batch>();
+    batch->Rows = array->length;
+    for (int64_t ci = 0; ci < array->n_children; ++ci) {
+        const ArrowArray* a = array->children[ci];
+        const ArrowSchema* s = schema->children[ci];
+        Column col;
+        col.Field.Name = s->name ? s->name : "";
+        if (a->length != array->length) return Status::Invalid("column '" + col.Field.Name + "' has a different length");
+        const ArrowArray* dictArr = a->dictionary;
+        const ArrowSchema* dictSchema = s->dictionary;
+        int32_t type, prec, scale;
+        if (!ParseFormat(dictSchema ? dictSchema->format : s->format, type, prec, scale)) {
+            return Status::Unsupported(std::string("Arrow format '") + (s->format ? s->format : "") + "' of column '" +
+                                       col.Field.Name + "'");
+        }
+        col.Field.Type = type;
+        col.Field.Precision = prec;
+        col.Field.Scale = scale;
+        col.Length = a->length;
+        const int64_t n = a->length, off = a->offset;
+
+        // validity
+        const uint8_t* validity = (a->n_buffers > 0) ? static_cast<const uint8_t*>(a->buffers[0]) : nullptr;
+        std::vector<uint8_t> validBits;
+        if (validity && a->null_count != 0) {
+            validBits = RealignBits(validity, off, n);
+            col.NullCount = n - CountSetBits(validBits);
+        } else {
+            col.NullCount = 0;
+        }
+
+        if (dictArr) {
+            // Dictionary-encoded strings: the SSA executor of the reference only ever sees decoded columns
+            // (ydb/core/formats/arrow/dictionary/conversion.h:13-15); decode here with the same result.
+            if (!IsStringLike(type)) return Status::Unsupported("dictionary of non-string values");
+            int32_t itype, p2, s2;
+            if (!ParseFormat(s->format, itype, p2, s2) || !IsInt(itype)) return Status::Unsupported("dictionary index type");
+            const int iw = TypeWidth(itype);
+            const char* idx = static_cast<const char*>(a->buffers[1]) + off * iw;
+            const int32_t* doffs = static_cast<const int32_t*>(dictArr->buffers[1]) + dictArr->offset;
+            const char* dchars = static_cast<const char*>(dictArr->buffers[2]);
+            std::vector<int32_t> offs(size_t(n) + 1, 0);
+            std::string chars;
+            for (int64_t i = 0; i < n; ++i) {
+                const bool valid = validBits.empty() || ((validBits[size_t(i >> 3)] >> (i & 7)) & 1);
+                if (valid) {
+                    int64_t k = 0;
+                    switch (itype) {
+                        case T_I8: k = reinterpret_cast<const int8_t*>(idx)[i]; break;
+                        case T_U8: k = reinterpret_cast<const uint8_t*>(idx)[i]; break;
+                        case T_I16: k = reinterpret_cast<const int16_t*>(idx)[i]; break;
+                        case T_U16: k = reinterpret_cast<const uint16_t*>(idx)[i]; break;
+                        case T_I32: k = reinterpret_cast<const int32_t*>(idx)[i]; break;
+                        case T_U32: k = reinterpret_cast<const uint32_t*>(idx)[i]; break;
+                        case T_I64: k = reinterpret_cast<const int64_t*>(idx)[i]; break;
+                        default: k = int64_t(reinterpret_cast<const uint64_t*>(idx)[i]); break;
+                    }
+                    if (k < 0 || k >= dictArr->length) return Status::Invalid("dictionary index out of range");
+                    chars.append(dchars + doffs[k], size_t(doffs[k + 1] - doffs[k]));
+                }
+                offs[size_t(i) + 1] = int32_t(chars.size());
+            }
+            col.Values = Buffer::Alloc((size_t(n) + 1) * 4);
+            col.Chars = Buffer::Alloc(chars.size() + 16);
+            if (!col.Values || !col.Chars) return Status::Hip("out of device memory");
+            SSA_HIP(hipMemcpy(col.Values->Ptr, offs.data(), offs.size() * 4, hipMemcpyHostToDevice));
+            if (!chars.empty()) SSA_HIP(hipMemcpy(col.Chars->Ptr, chars.data(), chars.size(), hipMemcpyHostToDevice));
+        } else if (IsStringLike(type)) {
+            if (a->n_buffers < 3) return Status::Invalid("string column without offsets / data buffers");
+            const int32_t* offs = static_cast<const int32_t*>(a->buffers[1]);
+            const char* chars = static_cast<const char*>(a->buffers[2]);
+            std::vector<int32_t> rebased(size_t(n) + 1, 0);
+            int32_t first = 0, last = 0;
+            if (offs) {
+                first = offs[off];
+                last = offs[off + n];
+                for (int64_t i = 0; i <= n; ++i) rebased[size_t(i)] = offs[off + i] - first;
+            }
+            col.Values = Buffer::Alloc((size_t(n) + 1) * 4);
+            col.Chars = Buffer::Alloc(size_t(last - first) + 16);
+            if (!col.Values || !col.Chars) return Status::Hip("out of device memory");
+            SSA_HIP(hipMemcpy(col.Values->Ptr, rebased.data(), rebased.size() * 4, hipMemcpyHostToDevice));
+            if (last > first) SSA_HIP(hipMemcpy(col.Chars->Ptr, chars + first, size_t(last - first), hipMemcpyHostToDevice));
+        } else if (type == T_BOOL) {
+            if (a->n_buffers < 2) return Status::Invalid("boolean column without a data buffer");
+            std::vector<uint8_t> bits = RealignBits(static_cast<const uint8_t*>(a->buffers[1]), off, n);
+            col.Values = Buffer::Alloc(bits.size() + 16);
+            if (!col.Values) return Status::Hip("out of device memory");
+            if (!bits.empty()) SSA_HIP(hipMemcpy(col.Values->Ptr, bits.data(), bits.size(), hipMemcpyHostToDevice));
+        } else {
+            if (a->n_buffers < 2) return Status::Invalid("column without a data buffer");
+            const int w = TypeWidth(type);
+            col.Values = Buffer::Alloc(size_t(n) * w + 16);
+            if (!col.Values) return Status::Hip("out of device memory");
+            if (n > 0) {
+                SSA_HIP(hipMemcpy(col.Values->Ptr, static_cast<const char*>(a->buffers[1]) + off * w, size_t(n) * w,
+                                  hipMemcpyHostToDevice));
+            }
+        }
+        if (!validBits.empty() && col.NullCount != 0) {
+            col.Validity = Buffer::Alloc(validBits.size() + 16);
+            if (!col.Validity) return Status::Hip("out of device memory");
+            SSA_HIP(hipMemcpy(col.Validity->Ptr, validBits.data(), validBits.size(), hipMemcpyHostToDevice));
+        }
+        // TDatumBatch treats a key as nullable when MayHaveNulls(): a validity buffer with a non-zero null count.
+        col.Field.Nullable = (col.Validity != nullptr);
+        batch->Cols.push_back(std::move(col));
+    }
+    out = batch;
+    return Status::OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Arrow C Data Interface: export (HBM -> host)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct ExportedArray {
+    std::vector<void*> Owned;          // malloc'd blocks
+    std::vector<const void*> Buffers;
+    std::vector<ArrowArray*> Children;
+};
+
+struct ExportedSchema {
+    std::string Format, Name;
+    std::vector<ArrowSchema*> Children;
+};
+
+void ReleaseArray(ArrowArray* a) {
+    if (!a || !a->release) return;
+    auto* p = static_cast<ExportedArray*>(a->private_data);
+    for (ArrowArray* c : p->Children) {
+        if (c->release) c->release(c);
+        delete c;
+    }
+    for (void* m : p->Owned) std::free(m);
+    delete p;
+    a->release = nullptr;
+}
+
+void ReleaseSchema(ArrowSchema* s) {
+    if (!s || !s->release) return;
+    auto* p = static_cast<ExportedSchema*>(s->private_data);
+    for (ArrowSchema* c : p->Children) {
+        if (c->release) c->release(c);
+        delete c;
+    }
+    delete p;
+    s->release = nullptr;
+}
+
+void InitSchema(ArrowSchema* s, const std::string& format, const std::string& name, bool nullable) {
+    auto* p = new ExportedSchema();
+    p->Format = format;
+    p->Name = name;
+    std::memset(s, 0, sizeof(*s));
+    s->format = p->Format.c_str();
+    s->name = p->Name.c_str();
+    s->flags = nullable ? ARROW_FLAG_NULLABLE : 0;
+    s->release = ReleaseSchema;
+    s->private_data = p;
+}
+
+}  // namespace
+
+Status Executor::ExportBatch(const Batch& batch, ArrowArray* outArray, ArrowSchema* outSchema) {
+    (void)hipSetDevice(Device);
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    InitSchema(outSchema, "+s", "", false);
+    auto* sp = static_cast<ExportedSchema*>(outSchema->private_data);
+    auto* ap = new ExportedArray();
+    std::memset(outArray, 0, sizeof(*outArray));
+    outArray->length = batch.Rows;
+    outArray->release = ReleaseArray;
+    outArray->private_data = ap;
+    ap->Buffers.push_back(nullptr);
+
+    auto fail = [&](Status st) {
+        outArray->n_children = int64_t(ap->Children.size());
+        outSchema->n_children = int64_t(sp->Children.size());
+        outArray->children = ap->Children.data();
+        outSchema->children = sp->Children.data();
+        ReleaseArray(outArray);
+        ReleaseSchema(outSchema);
+        return st;
+    };
+
+    for (const Column& col : batch.Cols) {
+        if (col.Field.IsScalar) return fail(Status::Invalid("internal: scalar column in an exported batch"));
+        auto* cs = new ArrowSchema();
+        InitSchema(cs, FormatOf(col.Field), col.Field.Name, true);
+        sp->Children.push_back(cs);
+        auto* ca = new ArrowArray();
+        auto* cp = new ExportedArray();
+        std::memset(ca, 0, sizeof(*ca));
+        ca->length = col.Length;
+        ca->release = ReleaseArray;
+        ca->private_data = cp;
+        ap->Children.push_back(ca);
+
+        const int64_t n = col.Length;
+        auto download = [&](const void* dev, size_t bytes, void*& host) -> Status {
+            host = std::malloc(bytes + 8);
+            if (!host) return Status::Invalid("out of host memory");
+            cp->Owned.push_back(host);
+            if (bytes && dev) SSA_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+            return Status::OK();
+        };
+        // validity
+        void* vhost = nullptr;
+        if (col.Validity) {
+            const size_t rawBytes = size_t((col.ValidBitOff + n + 7) / 8);
+            void* raw = nullptr;
+            Status st = download(col.Validity->Ptr, rawBytes, raw);
+            if (!st.ok()) return fail(st);
+            if (col.ValidBitOff != 0) {
+                std::vector<uint8_t> re = RealignBits(static_cast<uint8_t*>(raw), col.ValidBitOff, n);
+                std::memcpy(raw, re.data(), re.size());
+            }
+            vhost = raw;
+            int64_t set = 0;
+            const uint8_t* vb = static_cast<const uint8_t*>(vhost);
+            for (int64_t i = 0; i < n; ++i) set += (vb[i >> 3] >> (i & 7)) & 1;
+            ca->null_count = n - set;
+        } else {
+            ca->null_count = 0;
+        }
+        cp->Buffers.push_back(vhost);
+        if (IsStringLike(col.Field.Type)) {
+            void* offs = nullptr;
+            Status st = download(col.ValuesPtr(), size_t(n + 1) * 4, offs);
+            if (!st.ok()) return fail(st);
+            int32_t* o = static_cast<int32_t*>(offs);
+            if (n == 0 && !col.Values) o[0] = 0;
+            const int32_t first = o[0], last = o[n];
+            void* chars = nullptr;
+            st = download(col.Chars ? static_cast<const char*>(col.Chars->Ptr) + first : nullptr, size_t(last - first), chars);
+            if (!st.ok()) return fail(st);
+            if (first != 0) {
+                for (int64_t i = 0; i <= n; ++i) o[i] -= first;
+            }
+            cp->Buffers.push_back(offs);
+            cp->Buffers.push_back(chars);
+        } else if (col.Field.Type == T_BOOL) {
+            const size_t rawBytes = size_t((col.ValBitOff + n + 7) / 8);
+            void* raw = nullptr;
+            Status st = download(col.Values ? col.Values->Ptr : nullptr, rawBytes, raw);
+            if (!st.ok()) return fail(st);
+            if (col.ValBitOff != 0) {
+                std::vector<uint8_t> re = RealignBits(static_cast<uint8_t*>(raw), col.ValBitOff, n);
+                std::memcpy(raw, re.data(), re.size());
+            }
+            cp->Buffers.push_back(raw);
+        } else {
+            void* vals = nullptr;
+            Status st = download(col.ValuesPtr(), size_t(n) * TypeWidth(col.Field.Type), vals);
+            if (!st.ok()) return fail(st);
+            cp->Buffers.push_back(vals);
+        }
+        ca->n_buffers = int64_t(cp->Buffers.size());
+        ca->buffers = cp->Buffers.data();
+    }
+    outArray->n_buffers = 1;
+    outArray->buffers = ap->Buffers.data();
+    outArray->n_children = int64_t(ap->Children.size());
+    outArray->children = ap->Children.data();
+    outSchema->n_children = int64_t(sp->Children.size());
+    outSchema->children = sp->Children.data();
+    return Status::OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan argument block
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kLdsPerCU = 160 * 1024;
+constexpr int kLdsStageBudget = 64 * 1024;  // staged column tiles per workgroup (keeps >= 2 workgroups per CU)
+}  // namespace
+
+Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, ScanArgs& args, LaunchCfg& cfg,
+                              int64_t& algoBytes) {
+    std::memset(&args, 0, sizeof(args));
+    args.nrows = in.Rows;
+    args.ncols = int32_t(plan.SourceColumns.size());
+    args.ncode = int32_t(plan.Code.size());
+    args.nconsts = int32_t(plan.Consts.size());
+    args.nullable = plan.Nullable;
+    args.status = static_cast<uint32_t*>(StatusWord->Ptr);
+    algoBytes = 0;
+    int lds = 0;
+    for (int c = 0; c < args.ncols; ++c) {
+        const Column& col = in.Cols[size_t(plan.SourceColumns[size_t(c)])];
+        DevColumn& d = args.cols[c];
+        d.values = col.ValuesPtr();
+        d.validity = col.Validity ? static_cast<const uint8_t*>(col.Validity->Ptr) : nullptr;
+        d.chars = col.Chars ? static_cast<const uint8_t*>(col.Chars->Ptr) : nullptr;
+        d.type = col.Field.Type;
+        d.val_bit_off = col.ValBitOff;
+        d.valid_bit_off = col.ValidBitOff;
+        args.lds_col_off[c] = -1;
+        const int w = TypeWidth(col.Field.Type);
+        if (w >= 1 && w <= 8 && (reinterpret_cast<uintptr_t>(d.values) & 15) == 0 &&
+            lds + kTileRows * w <= kLdsStageBudget) {
+            args.lds_col_off[c] = lds;
+            lds += kTileRows * w;
+        }
+        // algorithmic bytes: every referenced source column once
+        if (IsStringLike(col.Field.Type)) {
+            algoBytes += (in.Rows + 1) * 4;
+            algoBytes += col.Chars ? int64_t(col.Chars->Size > 16 ? col.Chars->Size - 16 : 0) : 0;
+        } else if (col.Field.Type == T_BOOL) {
+            algoBytes += (in.Rows + 7) / 8;
+        } else {
+            algoBytes += in.Rows * w;
+        }
+        if (d.validity) algoBytes += (in.Rows + 7) / 8;
+    }
+    for (size_t i = 0; i < plan.Code.size(); ++i) args.code[i] = plan.Code[i];
+    for (size_t i = 0; i < plan.Consts.size(); ++i) args.consts[i] = plan.Consts[i];
+    std::memcpy(args.pattern, plan.PatternBytes.data(), plan.PatternBytes.size());
+    args.nregs = plan.NumRegsUsed;
+    args.lds_reg_off = lds;
+    lds += plan.NumRegsUsed * kTileRows * 8;
+    args.lds_regok_off = lds;
+    lds += plan.NumRegsUsed * kBlock;
+    lds = (lds + 15) & ~15;
+    args.lds_sink_off = lds;
+    lds += sinkLdsBytes;
+    if (lds > kLdsPerCU - 1024) return Status::Unsupported("step needs more LDS than one CU has");
+
+    const int64_t ntiles = (in.Rows + kTileRows - 1) / kTileRows;
+    int perCU = lds > 0 ? (kLdsPerCU - 2048) / lds : 8;
+    perCU = std::max(1, std::min(perCU, 8));
+    int64_t grid = std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU);
+    cfg.grid = int(grid);
+    cfg.lds_bytes = uint32_t(lds);
+    cfg.stream = StreamHandle;
+    return Status::OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers producing output columns
+// ---------------------------------------------------------------------------------------------
+Status Executor::PackValidity(const BufferPtr& validBytes, int64_t rows, Column& col) {
+    col.Validity = Buffer::Alloc(size_t((rows + 7) / 8) + 16);
+    BufferPtr counter = Buffer::Alloc(256);
+    if (!col.Validity || !counter) return Status::Hip("out of device memory");
+    SSA_HIP(hipMemsetAsync(counter->Ptr, 0, 8, StreamHandle));
+    SSA_HIP(LaunchPackBytesToBits(static_cast<const uint8_t*>(validBytes->Ptr), rows, static_cast<uint8_t*>(col.Validity->Ptr),
+                                  static_cast<unsigned long long*>(counter->Ptr), StreamHandle));
+    unsigned long long zeros = 0;
+    SSA_HIP(hipMemcpyAsync(&zeros, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    col.NullCount = int64_t(zeros);
+    col.ValidBitOff = 0;
+    if (zeros == 0) col.Validity = nullptr;
+    col.Field.Nullable = (col.Validity != nullptr);
+    return Status::OK();
+}
+
+Status Executor::MaterializeScalar(const OutColumn& oc, int64_t rows, Column& dst) {
+    // TDatumBatch::ToRecordBatch -> arrow::MakeArrayFromScalar (program.cpp:582-598)
+    dst = Column();
+    dst.Field.Name = oc.Name;
+    dst.Field.Type = oc.Type;
+    dst.Length = rows;
+    const TScalar& s = oc.Scalar;
+    if (IsStringLike(oc.Type)) {
+        std::vector<int32_t> offs(size_t(rows) + 1);
+        std::string chars;
+        const size_t len = s.Valid ? s.Bytes.size() : 0;
+        for (int64_t i = 0; i <= rows; ++i) offs[size_t(i)] = int32_t(size_t(i) * len);
+        for (int64_t i = 0; i < rows; ++i) chars.append(s.Bytes.data(), len);
+        dst.Values = Buffer::Alloc(offs.size() * 4);
+        dst.Chars = Buffer::Alloc(chars.size() + 16);
+        if (!dst.Values || !dst.Chars) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemcpyAsync(dst.Values->Ptr, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, StreamHandle));
+        if (!chars.empty()) SSA_HIP(hipMemcpyAsync(dst.Chars->Ptr, chars.data(), chars.size(), hipMemcpyHostToDevice, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+    } else if (oc.Type == T_BOOL) {
+        const size_t bytes = size_t((rows + 7) / 8);
+        dst.Values = Buffer::Alloc(bytes + 16);
+        if (!dst.Values) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemsetAsync(dst.Values->Ptr, (s.Valid && s.Bits) ? 0xFF : 0, bytes + 16, StreamHandle));
+    } else {
+        const int w = TypeWidth(oc.Type);
+        dst.Values = Buffer::Alloc(size_t(rows) * w + 16);
+        if (!dst.Values) return Status::Hip("out of device memory");
+        uint64_t stored = s.Valid ? s.Bits : 0;
+        if (oc.Type == T_F32) {
+            float f = float(BitsToF64(stored));
+            uint32_t b;
+            std::memcpy(&b, &f, 4);
+            stored = b;
+        }
+        SSA_HIP(LaunchFill(dst.Values->Ptr, w, stored, rows, StreamHandle));
+    }
+    if (!s.Valid) {
+        const size_t bytes = size_t((rows + 7) / 8);
+        dst.Validity = Buffer::Alloc(bytes + 16);
+        if (!dst.Validity) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemsetAsync(dst.Validity->Ptr, 0, bytes + 16, StreamHandle));
+        dst.NullCount = rows;
+        dst.Field.Nullable = true;
+    }
+    return Status::OK();
+}
+
+Status Executor::CompactColumn(const Column& src, int64_t rows, const BufferPtr& bitmap, const BufferPtr& tileOffsets,
+                               int64_t selected, Column& dst) {
+    const uint64_t* bm = static_cast<const uint64_t*>(bitmap->Ptr);
+    const int64_t* to = static_cast<const int64_t*>(tileOffsets->Ptr);
+    dst = Column();
+    dst.Field = src.Field;
+    dst.Length = selected;
+    const int type = src.Field.Type;
+    if (IsStringLike(type)) {
+        BufferPtr lens = Buffer::Alloc(size_t(selected + 1) * 4 + 16);
+        dst.Values = Buffer::Alloc(size_t(selected + 1) * 4 + 16);
+        const int64_t nblocks = (selected + 4095) / 4096 + 2;
+        BufferPtr tmp = Buffer::Alloc(size_t(nblocks) * 8 + 16);
+        if (!lens || !dst.Values || !tmp) return Status::Hip("out of device memory");
+        const int32_t* offs = static_cast<const int32_t*>(src.ValuesPtr());
+        SSA_HIP(LaunchCompactStringLens(offs, static_cast<int32_t*>(lens->Ptr), rows, bm, to, StreamHandle));
+        SSA_HIP(LaunchExclusiveScanI32(static_cast<const int32_t*>(lens->Ptr), static_cast<int32_t*>(dst.Values->Ptr), selected,
+                                       static_cast<int64_t*>(tmp->Ptr), StreamHandle));
+        int32_t total = 0;
+        SSA_HIP(hipMemcpyAsync(&total, static_cast<const int32_t*>(dst.Values->Ptr) + selected, 4, hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        dst.Chars = Buffer::Alloc(size_t(total) + 16);
+        if (!dst.Chars) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchCompactStringBytes(offs, static_cast<const uint8_t*>(src.Chars->Ptr), static_cast<const int32_t*>(dst.Values->Ptr),
+                                         static_cast<uint8_t*>(dst.Chars->Ptr), rows, bm, to, StreamHandle));
+    } else if (type == T_BOOL) {
+        BufferPtr bytes = Buffer::Alloc(size_t(selected) + 16);
+        dst.Values = Buffer::Alloc(size_t((selected + 7) / 8) + 16);
+        if (!bytes || !dst.Values) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchCompactBits(static_cast<const uint8_t*>(src.Values->Ptr), src.ValBitOff, static_cast<uint8_t*>(bytes->Ptr), rows, bm,
+                                  to, StreamHandle));
+        SSA_HIP(LaunchPackBytesToBits(static_cast<const uint8_t*>(bytes->Ptr), selected, static_cast<uint8_t*>(dst.Values->Ptr), nullptr,
+                                      StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+    } else {
+        const int w = TypeWidth(type);
+        dst.Values = Buffer::Alloc(size_t(selected) * w + 16);
+        if (!dst.Values) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchCompactFixed(src.ValuesPtr(), dst.Values->Ptr, w, rows, bm, to, StreamHandle));
+    }
+    if (src.Validity) {
+        BufferPtr bytes = Buffer::Alloc(size_t(selected) + 16);
+        if (!bytes) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchCompactBits(static_cast<const uint8_t*>(src.Validity->Ptr), src.ValidBitOff, static_cast<uint8_t*>(bytes->Ptr), rows,
+                                  bm, to, StreamHandle));
+        SSA_RETURN_NOT_OK(PackValidity(bytes, selected, dst));
+    }
+    return Status::OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// steps
+// ---------------------------------------------------------------------------------------------
+Status Executor::RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,
+                                 int64_t& selected) {
+    const int64_t rows = in.Rows;
+    const int64_t nwords = (rows + 63) / 64;
+    const int64_t ntiles = (rows + kTileRows - 1) / kTileRows;
+    bitmap = Buffer::Alloc(size_t(nwords) * 8 + 64);
+    BufferPtr tileCounts = Buffer::Alloc(size_t(ntiles) * 4 + 64);
+    const int64_t scanBlocks = (ntiles + 4095) / 4096 + 2;
+    tileOffsets = Buffer::Alloc(size_t(ntiles + 1 + scanBlocks) * 8 + 64);
+    BufferPtr total = Buffer::Alloc(256);
+    if (!bitmap || !tileCounts || !tileOffsets || !total) return Status::Hip("out of device memory");
+    ScanArgs args;
+    LaunchCfg cfg;
+    int64_t algoBytes;
+    SSA_RETURN_NOT_OK(FillScanArgs(filterPlan, in, 0, args, cfg, algoBytes));
+    FilterSink sink{static_cast<uint64_t*>(bitmap->Ptr), static_cast<uint32_t*>(tileCounts->Ptr)};
+    if (rows > 0) {
+        ProfileBegin();
+        SSA_HIP(LaunchScanFilter(args, sink, cfg));
+        ProfileEnd("ScanFilterKernel", algoBytes);
+    }
+    SSA_HIP(LaunchTileScan(static_cast<const uint32_t*>(tileCounts->Ptr), ntiles, static_cast<int64_t*>(tileOffsets->Ptr),
+                           static_cast<int64_t*>(total->Ptr), StreamHandle));
+    int64_t sel = 0;
+    SSA_HIP(hipMemcpyAsync(&sel, total->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    SSA_RETURN_NOT_OK(CheckScanStatus());
+    selected = sel;
+    return Status::OK();
+}
+
+Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) {
+    ScanArgs args;
+    LaunchCfg cfg;
+    int64_t algoBytes;
+    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, 0, args, cfg, algoBytes));
+    const int naggs = int(plan.Aggs.size());
+    BufferPtr partial = Buffer::Alloc(size_t(cfg.grid) * kMaxAggs * 8);
+    BufferPtr seen = Buffer::Alloc(size_t(cfg.grid) * 4);
+    BufferPtr outVals = Buffer::Alloc(kMaxAggs * 8 + kMaxAggs);
+    if (!partial || !seen || !outVals) return Status::Hip("out of device memory");
+    NoKeySink sink{};
+    sink.naggs = naggs;
+    for (int k = 0; k < naggs; ++k) sink.aggs[k] = plan.Aggs[size_t(k)].Spec;
+    sink.partial = static_cast<uint64_t*>(partial->Ptr);
+    sink.partial_seen = static_cast<uint32_t*>(seen->Ptr);
+    ProfileBegin();
+    SSA_HIP(LaunchScanNoKey(args, sink, cfg));
+    ProfileEnd("ScanNoKeyKernel", algoBytes);
+    uint64_t* dv = static_cast<uint64_t*>(outVals->Ptr);
+    uint8_t* dvalid = reinterpret_cast<uint8_t*>(dv + kMaxAggs);
+    SSA_HIP(LaunchNoKeyFinalize(sink, cfg.grid, dv, dvalid, StreamHandle));
+    uint64_t hv[kMaxAggs + 2] = {0};
+    SSA_HIP(hipMemcpyAsync(hv, outVals->Ptr, kMaxAggs * 8 + kMaxAggs, hipMemcpyDeviceToHost, StreamHandle));
+    SSA_RETURN_NOT_OK(CheckScanStatus());
+    const uint8_t* hvalid = reinterpret_cast<const uint8_t*>(hv + kMaxAggs);
+
+    // One output row; columns follow plan.Outs (aggregates in GroupBy order unless a projection reorders them).
+    out = std::make_shared<Batch>();
+    out->Rows = 1;
+    for (const OutColumn& oc : plan.Outs) {
+        const AggPlan& ap = plan.Aggs[size_t(oc.Index)];
+        uint64_t v = hv[oc.Index];
+        bool valid = hvalid[oc.Index] != 0;
+        Column col;
+        col.Field.Name = oc.Name;
+        col.Field.Type = oc.Type;
+        col.Length = 1;
+        uint64_t stored = v;
+        if (ap.SomeInputColumn >= 0) {
+            // `v` is the smallest row index with a non-null argument: fetch that value.
+            stored = 0;
+            if (valid) {
+                const Column& src = in.Cols[size_t(ap.SomeInputColumn)];
+                const int w = TypeWidth(src.Field.Type);
+                SSA_HIP(hipMemcpy(&stored, static_cast<const char*>(src.ValuesPtr()) + v * w, size_t(w), hipMemcpyDeviceToHost));
+            }
+        } else if (oc.Type == T_F32) {
+            float f = float(BitsToF64(v));
+            uint32_t b;
+            std::memcpy(&b, &f, 4);
+            stored = b;
+        }
+        if (!valid) stored = 0;
+        col.Values = Buffer::Alloc(32);
+        if (!col.Values) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemcpy(col.Values->Ptr, &stored, 8, hipMemcpyHostToDevice));
+        if (!valid) {
+            col.Validity = Buffer::Alloc(32);
+            if (!col.Validity) return Status::Hip("out of device memory");
+            uint64_t zero = 0;
+            SSA_HIP(hipMemcpy(col.Validity->Ptr, &zero, 8, hipMemcpyHostToDevice));
+            col.NullCount = 1;
+            col.Field.Nullable = true;
+        }
+        out->Cols.push_back(std::move(col));
+    }
+    return Status::OK();
+}
+
+Status Executor::RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& inPtr, BatchPtr& out) {
+    const Batch& in = *inPtr;
+    const int64_t rows = in.Rows;
+    BufferPtr bitmap, tileOffsets;
+    int64_t selected = rows;
+    bool filtered = false;
+    if (plan.HasFilter) {
+        StepPlan filterPlan;
+        SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_FILTER_ONLY, filterPlan));
+        SSA_RETURN_NOT_OK(RunFilterBitmap(filterPlan, in, bitmap, tileOffsets, selected));
+        filtered = (selected != rows);  // TColumnFilter::IsTotalAllowFilter -> nothing to do
+    }
+    out = std::make_shared<Batch>();
+    out->Rows = selected;
+    out->Cols.resize(plan.Outs.size());
+
+    // computed columns: one more scan that writes the output registers at the compacted positions
+    std::vector<int> regOuts;
+    for (size_t i = 0; i < plan.Outs.size(); ++i) {
+        if (plan.Outs[i].Source == OutColumn::FROM_REG) regOuts.push_back(int(i));
+    }
+    if (!regOuts.empty()) {
+        if (regOuts.size() > size_t(kMaxOuts)) return Status::Unsupported("too many computed output columns");
+        StepPlan outPlan;
+        SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_OUTPUTS_ONLY, outPlan));
+        ScanArgs args;
+        LaunchCfg cfg;
+        int64_t algoBytes;
+        SSA_RETURN_NOT_OK(FillScanArgs(outPlan, in, 0, args, cfg, algoBytes));
+        ProjectSink sink{};
+        sink.bitmap = filtered ? static_cast<const uint64_t*>(bitmap->Ptr) : nullptr;
+        sink.tile_offsets = filtered ? static_cast<const int64_t*>(tileOffsets->Ptr) : nullptr;
+        sink.nouts = int32_t(regOuts.size());
+        std::vector<BufferPtr> validBytes(regOuts.size()), boolBytes(regOuts.size());
+        for (size_t k = 0; k < regOuts.size(); ++k) {
+            const OutColumn& oc = outPlan.Outs[size_t(regOuts[k])];
+            Column& col = out->Cols[size_t(regOuts[k])];
+            col.Field.Name = oc.Name;
+            col.Field.Type = oc.Type;
+            col.Length = selected;
+            const int w = (oc.Type == T_BOOL) ? 1 : TypeWidth(oc.Type);
+            BufferPtr vals = Buffer::Alloc(size_t(selected) * w + 16);
+            if (!vals) return Status::Hip("out of device memory");
+            if (oc.Type == T_BOOL) boolBytes[k] = vals; else col.Values = vals;
+            sink.outs[k].values = vals->Ptr;
+            sink.outs[k].type = oc.Type;
+            sink.outs[k].reg = oc.Index;
+            sink.outs[k].valid_bytes = nullptr;
+            if (oc.Nullable) {
+                validBytes[k] = Buffer::Alloc(size_t(selected) + 16);
+                if (!validBytes[k]) return Status::Hip("out of device memory");
+                sink.outs[k].valid_bytes = static_cast<uint8_t*>(validBytes[k]->Ptr);
+            }
+        }
+        if (rows > 0) {
+            ProfileBegin();
+            SSA_HIP(LaunchScanProject(args, sink, cfg));
+            ProfileEnd("ScanProjectKernel", algoBytes);
+        }
+        for (size_t k = 0; k < regOuts.size(); ++k) {
+            Column& col = out->Cols[size_t(regOuts[k])];
+            if (boolBytes[k]) {
+                col.Values = Buffer::Alloc(size_t((selected + 7) / 8) + 16);
+                if (!col.Values) return Status::Hip("out of device memory");
+                SSA_HIP(LaunchPackBytesToBits(static_cast<const uint8_t*>(boolBytes[k]->Ptr), selected,
+                                              static_cast<uint8_t*>(col.Values->Ptr), nullptr, StreamHandle));
+            }
+            if (validBytes[k]) SSA_RETURN_NOT_OK(PackValidity(validBytes[k], selected, col));
+        }
+        SSA_RETURN_NOT_OK(CheckScanStatus());
+    }
+
+    for (size_t i = 0; i < plan.Outs.size(); ++i) {
+        const OutColumn& oc = plan.Outs[i];
+        Column& col = out->Cols[i];
+        if (oc.Source == OutColumn::FROM_INPUT) {
+            const Column& src = in.Cols[size_t(oc.Index)];
+            if (!filtered) {
+                col = src;  // zero-copy: buffers are shared
+            } else {
+                SSA_RETURN_NOT_OK(CompactColumn(src, rows, bitmap, tileOffsets, selected, col));
+            }
+            col.Field.Name = oc.Name;
+        } else if (oc.Source == OutColumn::FROM_SCALAR) {
+            SSA_RETURN_NOT_OK(MaterializeScalar(oc, selected, col));
+        }
+    }
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    return Status::OK();
+}
+
+Status Executor::RunKeyed(const StepPlan&, const Batch&, BatchPtr&) {
+    return Status::Unsupported("keyed GROUP BY");
+}
+
+Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out) {
+    StepPlan plan;
+    SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FULL, plan));
+    switch (plan.Kind) {
+        case StepPlan::PASS_THROUGH:
+        case StepPlan::PROJECT:
+            return RunProject(step, plan, in, out);
+        case StepPlan::AGG_NOKEY:
+            return RunNoKey(plan, *in, out);
+        case StepPlan::AGG_KEYED:
+            return RunKeyed(plan, *in, out);
+        default:
+            return Status::Invalid("internal: unexpected plan kind");
+    }
+}
+
+Status Executor::ApplyProgram(const TProgram& program, const BatchPtr& in, BatchPtr& out) {
+    (void)hipSetDevice(Device);
+    BatchPtr cur = in;
+    for (auto& step : program.Steps) {
+        BatchPtr next;
+        SSA_RETURN_NOT_OK(ApplyStep(*step, cur, next));
+        cur = next;
+    }
+    out = cur;
+    return Status::OK();
+}
+
+Status Executor::BuildFilter(const TProgramStep& step, const BatchPtr& in, std::vector<uint8_t>& bits, int64_t& selected) {
+    (void)hipSetDevice(Device);
+    StepPlan plan;
+    SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FILTER_ONLY, plan));
+    BufferPtr bitmap, tileOffsets;
+    SSA_RETURN_NOT_OK(RunFilterBitmap(plan, *in, bitmap, tileOffsets, selected));
+    bits.assign(size_t((in->Rows + 7) / 8), 0);
+    if (!bits.empty()) SSA_HIP(hipMemcpy(bits.data(), bitmap->Ptr, bits.size(), hipMemcpyDeviceToHost));
+    return Status::OK();
+}
+
+}  // namespace ssa

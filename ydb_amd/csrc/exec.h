@@ -1,0 +1,123 @@
+// Device-resident record batches and the step executor.
+//
+// The executor is the GPU counterpart of NSsa::TProgram::ApplyTo / TProgramStep::Apply
+// (ydb/core/formats/arrow/program.h:435-447, program.cpp:869-902 of the reference): it runs the steps
+// of a parsed program in order, each as a fused scan over an HBM-resident batch, and produces a new
+// HBM-resident batch.  Host <-> device crossings happen only in Import/Export (the Arrow C Data
+// Interface boundary) and for the handful of scalars a step needs on the host (row counts).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "arrow_abi.h"
+#include "kernels.h"
+#include "plan.h"
+#include "program.h"
+
+namespace ssa {
+
+// Size-bucketed cache of device allocations (hipMalloc / hipFree are synchronising and slow).
+class DevPool {
+public:
+    static DevPool& Instance();
+    void* Alloc(size_t bytes);
+    void Free(void* p, size_t bytes);
+    void Trim();
+    size_t BytesInUse() const { return InUse; }
+
+private:
+    std::mutex Lock;
+    std::map<size_t, std::vector<void*>> FreeLists;
+    size_t InUse = 0;
+};
+
+struct Buffer {
+    void* Ptr = nullptr;
+    size_t Size = 0;
+    bool Owned = false;  // allocated from DevPool (else: caller-owned device memory that outlives the batch)
+    ~Buffer();
+    static std::shared_ptr<Buffer> Alloc(size_t bytes);
+    static std::shared_ptr<Buffer> Wrap(void* p, size_t bytes);
+};
+using BufferPtr = std::shared_ptr<Buffer>;
+
+struct Column {
+    FieldDesc Field;         // name, type, nullable (validity present), scalar flag + value
+    int64_t Length = 0;
+    int64_t NullCount = 0;   // -1: unknown
+    BufferPtr Values;        // fixed width: values; BOOL: bitmap; strings: int32 offsets (Length + 1)
+    BufferPtr Validity;      // may be null
+    BufferPtr Chars;         // strings
+    int64_t ElemOffset = 0;  // element offset of row 0 inside Values (fixed width / offsets)
+    int32_t ValBitOff = 0;   // BOOL: bit offset of row 0 inside Values
+    int32_t ValidBitOff = 0;
+    const void* ValuesPtr() const;  // address of row 0
+};
+
+struct Batch {
+    std::vector<Column> Cols;
+    int64_t Rows = 0;
+    std::vector<FieldDesc> Schema() const;
+    int FindColumn(const std::string& name) const;  // -1 if absent or duplicated
+};
+using BatchPtr = std::shared_ptr<Batch>;
+
+// Timing of the dominant scan kernel of the most recent Apply calls (HIP events on the executor's stream).
+struct KernelProfile {
+    bool Enabled = false;
+    double ScanMs = 0;       // accumulated elapsed time of the fused scan kernels
+    int64_t ScanLaunches = 0;
+    int64_t ScanBytes = 0;   // algorithmic bytes of those launches (source columns touched once)
+    std::string LastKernel;
+};
+
+// Column descriptions of a struct ArrowSchema (no data): used to explain / type-check a program on the host.
+Status SchemaFields(const ArrowSchema* schema, std::vector<FieldDesc>& out);
+
+class Executor {
+public:
+    explicit Executor(int device);
+    ~Executor();
+
+    Status ImportBatch(const ArrowArray* array, const ArrowSchema* schema, BatchPtr& out);
+    Status ExportBatch(const Batch& batch, ArrowArray* outArray, ArrowSchema* outSchema);
+
+    // TProgram::ApplyTo: every step in order.
+    Status ApplyProgram(const TProgram& program, const BatchPtr& in, BatchPtr& out);
+    // TProgramStep::BuildFilter for the first step: Arrow-order bitmap (LSB first) of rows*1 bits, on the host.
+    Status BuildFilter(const TProgramStep& step, const BatchPtr& in, std::vector<uint8_t>& bits, int64_t& selected);
+
+    Status Sync();
+    hipStream_t Stream() const { return StreamHandle; }
+    KernelProfile Profile;
+
+private:
+    Status ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
+    Status RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out);
+    Status RunKeyed(const StepPlan& plan, const Batch& in, BatchPtr& out);
+    Status RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& in, BatchPtr& out);
+    Status RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,
+                           int64_t& selected);
+    Status FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, ScanArgs& args, LaunchCfg& cfg,
+                        int64_t& algoBytes);
+    Status CheckScanStatus();
+    Status CompactColumn(const Column& src, int64_t rows, const BufferPtr& bitmap, const BufferPtr& tileOffsets,
+                         int64_t selected, Column& dst);
+    Status MaterializeScalar(const OutColumn& oc, int64_t rows, Column& dst);
+    Status PackValidity(const BufferPtr& validBytes, int64_t rows, Column& col);
+    Status GatherRows(const Column& src, const BufferPtr& rowIdx, int64_t n, Column& dst);
+    void ProfileBegin();
+    void ProfileEnd(const char* kernel, int64_t algoBytes);
+
+    int Device;
+    hipStream_t StreamHandle = nullptr;
+    hipEvent_t EvStart = nullptr, EvStop = nullptr;
+    BufferPtr StatusWord;   // device uint32
+};
+
+}  // namespace ssa

@@ -1,0 +1,149 @@
+// Host-visible launch interface of the HIP kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "vm.h"
+
+namespace ssa {
+
+constexpr int kBlock = 256;           // threads per workgroup = 4 wavefronts of 64
+constexpr int kRowsPerThread = 4;     // U: rows each thread evaluates per tile
+constexpr int kTileRows = kBlock * kRowsPerThread;
+constexpr int kMaxGrid = 256 * 8;     // persistent grid: 256 CUs x up to 8 resident workgroups
+
+// ---- scan sinks ---------------------------------------------------------------------------------
+struct NoKeySink {
+    int32_t naggs;
+    AggSpec aggs[kMaxAggs];
+    uint64_t* partial;       // [grid][kMaxAggs] per-workgroup partial states
+    uint32_t* partial_seen;  // [grid] bit k: aggregate k saw a non-null argument
+};
+
+struct FilterSink {
+    uint64_t* bitmap;        // ceil(nrows / 64) words, bit i of word w = row 64 w + i passes the filter
+    uint32_t* tile_counts;   // [ntiles] selected rows per tile of kTileRows rows
+};
+
+struct ProjectOut {
+    void* values;            // typed output values (BOOL outputs: one byte per row, packed afterwards)
+    uint8_t* valid_bytes;    // one byte per row, packed afterwards; nullptr when the output cannot be null
+    int32_t type;
+    int32_t reg;             // >= 0 R register, <= -2 column slot
+};
+
+struct ProjectSink {
+    const uint64_t* bitmap;      // nullptr: every row is selected (no compaction)
+    const int64_t* tile_offsets; // exclusive prefix sum of tile_counts
+    int32_t nouts;
+    ProjectOut outs[kMaxOuts];
+};
+
+// Group-by: open-addressing table in global memory (the "spill table"), fronted by a small
+// per-workgroup table in LDS that absorbs the hot groups.
+struct KeyedSink {
+    int32_t naggs;
+    int32_t nkeys;
+    AggSpec aggs[kMaxAggs];
+    KeySpec keys[kMaxKeys];
+    int32_t key_words;       // 1: 64-bit key, 2: 128-bit key
+    int32_t hashed;          // keys may exceed 15 bytes: rows carry a representative row index
+    int32_t lds_cap;         // LDS table capacity (power of two, 0 = bypass LDS)
+    int32_t lds_rep;         // accumulator replication factor inside LDS (power of two)
+    uint64_t table_mask;     // global capacity - 1
+    uint64_t* t_key_lo;      // [cap] ~0 = empty
+    uint64_t* t_key_hi;      // [cap] (key_words == 2)
+    uint64_t* t_rep_row;     // [cap] min row index of the group (hashed keys)
+    uint64_t* t_acc;         // [naggs][cap]
+    uint32_t* t_seen;        // [cap] bit k: aggregate k saw a non-null argument
+};
+
+struct LaunchCfg {
+    int grid;
+    uint32_t lds_bytes;   // dynamic LDS per workgroup: staged column tiles + R registers + sink area
+    hipStream_t stream;
+};
+
+hipError_t LaunchScanNoKey(const ScanArgs& a, const NoKeySink& s, LaunchCfg cfg);
+hipError_t LaunchScanFilter(const ScanArgs& a, const FilterSink& s, LaunchCfg cfg);
+hipError_t LaunchScanProject(const ScanArgs& a, const ProjectSink& s, LaunchCfg cfg);
+hipError_t LaunchScanKeyed(const ScanArgs& a, const KeyedSink& s, LaunchCfg cfg);
+// Raise the dynamic-LDS limit of the scan kernels (call once per device).
+hipError_t ConfigureScanKernels(int maxLdsBytes);
+
+// ---- small follow-up kernels ----------------------------------------------------------------------
+// Reduce per-workgroup partials; out_vals[k], out_valid[k] (1 = non-null).
+hipError_t LaunchNoKeyFinalize(const NoKeySink& s, int grid, uint64_t* out_vals, uint8_t* out_valid, hipStream_t st);
+// tile_offsets[i] = sum(tile_counts[0..i)), total[0] = sum of all.
+hipError_t LaunchTileScan(const uint32_t* tile_counts, int64_t ntiles, int64_t* tile_offsets, int64_t* total, hipStream_t st);
+// Order-preserving compaction of one fixed-width column (width 1, 2, 4, 8 or 16 bytes).
+hipError_t LaunchCompactFixed(const void* src, void* dst, int width, int64_t nrows, const uint64_t* bitmap,
+                              const int64_t* tile_offsets, hipStream_t st);
+// Compaction of a bit-packed column (validity bitmap or BOOL values) into one byte per selected row.
+hipError_t LaunchCompactBits(const uint8_t* src_bits, int64_t src_bit_off, uint8_t* dst_bytes, int64_t nrows,
+                             const uint64_t* bitmap, const int64_t* tile_offsets, hipStream_t st);
+// dst bit i = (src_bytes[i] != 0); returns the number of zero bytes through *null_count (device counter, pre-zeroed).
+hipError_t LaunchPackBytesToBits(const uint8_t* src_bytes, int64_t n, uint8_t* dst_bits, unsigned long long* zero_count,
+                                 hipStream_t st);
+// String compaction: lengths of selected rows -> new offsets (exclusive scan) -> byte copy.
+hipError_t LaunchCompactStringLens(const int32_t* offsets, int32_t* out_lens, int64_t nrows, const uint64_t* bitmap,
+                                   const int64_t* tile_offsets, hipStream_t st);
+hipError_t LaunchExclusiveScanI32(const int32_t* in, int32_t* out, int64_t n, int64_t* block_tmp, hipStream_t st);
+hipError_t LaunchCompactStringBytes(const int32_t* offsets, const uint8_t* chars, const int32_t* new_offsets,
+                                    uint8_t* out_chars, int64_t nrows, const uint64_t* bitmap,
+                                    const int64_t* tile_offsets, hipStream_t st);
+// Fill n elements of `width` bytes with the low bytes of `value`.
+hipError_t LaunchFill(void* dst, int width, uint64_t value, int64_t n, hipStream_t st);
+// Popcount of the first nbits of a bitmap starting at bit offset.
+hipError_t LaunchCountBits(const uint8_t* bits, int64_t bit_off, int64_t nbits, unsigned long long* out, hipStream_t st);
+
+// ---- group-by finalize ----------------------------------------------------------------------------
+struct KeyedFinalizeArgs {
+    uint64_t capacity;
+    const uint64_t* t_key_lo;
+    const uint64_t* t_key_hi;
+    const uint64_t* t_rep_row;
+    const uint64_t* t_acc;
+    const uint32_t* t_seen;
+    int32_t naggs;
+    int32_t nkeys;
+    int32_t key_words;
+    int32_t hashed;
+    AggSpec aggs[kMaxAggs];
+    int32_t agg_out_type[kMaxAggs];
+    KeySpec keys[kMaxKeys];
+    // outputs (ngroups rows)
+    void* agg_vals[kMaxAggs];
+    uint8_t* agg_valid_bytes[kMaxAggs];
+    void* key_vals[kMaxKeys];         // fixed-width keys decoded from the packed key
+    uint8_t* key_valid_bytes[kMaxKeys];
+    uint64_t* group_rep_row;          // hashed keys: representative row per output group
+    uint64_t* group_slot;             // table slot per output group
+};
+// Pass 1: count occupied slots per block; pass 2 (after the scan) writes group rows in slot order.
+hipError_t LaunchKeyedCount(const uint64_t* t_key_lo, uint64_t capacity, uint32_t* block_counts, int nblocks, hipStream_t st);
+hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, const int64_t* block_offsets, int nblocks, hipStream_t st);
+// Gather rows of a fixed-width column by 64-bit row index (idx == ~0 -> zero + invalid).
+hipError_t LaunchGatherFixed(const void* src, const uint8_t* src_valid, int64_t src_valid_off, int width,
+                             const uint64_t* rows, int64_t n, void* dst, uint8_t* dst_valid_bytes, hipStream_t st);
+hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, int64_t n, int32_t* out_lens, hipStream_t st);
+hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
+                                   const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);
+
+// ---- synthetic data (benchmark / parity inputs generated in HBM) -----------------------------------
+struct LineitemColumns {
+    int32_t* l_shipdate;
+    double* l_quantity;
+    double* l_extendedprice;
+    double* l_discount;
+    double* l_tax;
+    int32_t* rf_offsets;     // l_returnflag utf8 (rows + 1 offsets), 1 char per row
+    uint8_t* rf_chars;
+    int32_t* ls_offsets;     // l_linestatus utf8
+    uint8_t* ls_chars;
+    int8_t* rf_code;         // dictionary codes (0 = "A", 1 = "N", 2 = "R"), may be nullptr
+    int8_t* ls_code;         // (0 = "F", 1 = "O")
+};
+hipError_t LaunchGenLineitem(const LineitemColumns& c, int64_t row0, int64_t nrows, uint64_t seed, hipStream_t st);
+
+}  // namespace ssa

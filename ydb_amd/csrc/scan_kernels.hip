@@ -1,0 +1,568 @@
+// Fused scan kernels: expression VM + {key-less aggregation | filter bitmap | projection} sinks, and
+// the small follow-up kernels of stream compaction (tile-count scan, column compaction, bit packing).
+//
+// All of these are HBM-streaming kernels: the algorithmic traffic is "each referenced source column
+// once" and the roofline that bounds them is HBM bandwidth.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "scan_vm.h"
+
+namespace ssa {
+
+namespace {
+
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ int LaneId() { return threadIdx.x & 63; }
+__device__ __forceinline__ int WaveId() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint64_t ShflXor64(uint64_t v, int mask) {
+    return uint64_t(__shfl_xor(static_cast<unsigned long long>(v), mask, 64));
+}
+
+__device__ __forceinline__ uint64_t AggIdentity(int kind) {
+    switch (kind) {
+        case AGG_MIN_I: return uint64_t(INT64_MAX);
+        case AGG_MAX_I: return uint64_t(INT64_MIN);
+        case AGG_MIN_U: return ~0ull;
+        case AGG_MIN_F: return 0x7FF0000000000000ull;  // +inf
+        case AGG_MAX_F: return 0xFFF0000000000000ull;  // -inf
+        default: return 0;
+    }
+}
+
+// Combine two partial states of one aggregate.  Floating min/max follow fmin/fmax: a NaN operand is
+// ignored (contrib/libs/apache/arrow/cpp/src/arrow/compute/kernels/aggregate_basic_internal.h:207-228).
+__device__ __forceinline__ uint64_t AggCombine(int kind, uint64_t a, uint64_t b) {
+    switch (kind) {
+        case AGG_COUNT: case AGG_SUM_I: return a + b;
+        case AGG_SUM_F: return F64ToBits(BitsToF64(a) + BitsToF64(b));
+        case AGG_MIN_I: return int64_t(b) < int64_t(a) ? b : a;
+        case AGG_MAX_I: return int64_t(b) > int64_t(a) ? b : a;
+        case AGG_MIN_U: return b < a ? b : a;
+        case AGG_MAX_U: return b > a ? b : a;
+        case AGG_MIN_F: return F64ToBits(fmin(BitsToF64(a), BitsToF64(b)));
+        case AGG_MAX_F: return F64ToBits(fmax(BitsToF64(a), BitsToF64(b)));
+        default: return a;
+    }
+}
+
+// ---- sink: key-less aggregation ---------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(kBlock) void ScanNoKeyKernel(const KArgs<NoKeySink>) {
+    const ScanArgs& a = KernArgs<NoKeySink>().a;
+    const NoKeySink& s = KernArgs<NoKeySink>().s;
+    Machine<U> m(a);
+    uint64_t acc[kMaxAggs];
+    uint32_t seen = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxAggs; ++k) acc[k] = (k < s.naggs) ? AggIdentity(s.aggs[k].kind) : 0;
+
+    const int64_t ntiles = (a.nrows + kBlock * U - 1) / (kBlock * U);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        m.BeginTile(tile * (kBlock * U));
+        m.Run();
+        if (m.P == 0) continue;
+#pragma unroll
+        for (int k = 0; k < kMaxAggs; ++k) {
+            if (k < s.naggs) {
+                const AggSpec spec = s.aggs[k];
+                uint32_t live = m.P;
+                Val<U> x;
+                if (spec.reg != -1) {
+                    m.FetchOperand(spec.reg, x);
+                    if (spec.check_valid) live &= x.ok;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) x.v[u] = 0;
+                }
+                if (live) seen |= 1u << k;
+                if (spec.kind == AGG_COUNT) {
+                    acc[k] += __popc(live);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if ((live >> u) & 1u) acc[k] = AggCombine(spec.kind, acc[k], x.v[u]);
+                    }
+                }
+            }
+        }
+    }
+    m.ReportErrors();
+
+    // workgroup reduction: wave butterflies, then the 4 wave results through LDS
+    __shared__ uint64_t lds[kWaves][kMaxAggs];
+    __shared__ uint32_t ldsSeen[kWaves];
+#pragma unroll
+    for (int k = 0; k < kMaxAggs; ++k) {
+        if (k < s.naggs) {
+            const int kind = s.aggs[k].kind;
+            uint64_t v = acc[k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v = AggCombine(kind, v, ShflXor64(v, off));
+            if (LaneId() == 0) lds[WaveId()][k] = v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) seen |= __shfl_xor(seen, off, 64);
+    if (LaneId() == 0) ldsSeen[WaveId()] = seen;
+    __syncthreads();
+    if (threadIdx.x < kMaxAggs && int(threadIdx.x) < s.naggs) {
+        const int k = threadIdx.x;
+        const int kind = s.aggs[k].kind;
+        uint64_t v = lds[0][k];
+        for (int w = 1; w < kWaves; ++w) v = AggCombine(kind, v, lds[w][k]);
+        s.partial[size_t(blockIdx.x) * kMaxAggs + k] = v;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t sn = 0;
+        for (int w = 0; w < kWaves; ++w) sn |= ldsSeen[w];
+        s.partial_seen[blockIdx.x] = sn;
+    }
+}
+
+// One workgroup folds the per-workgroup partials in a fixed order (bit-reproducible for a fixed grid).
+struct FinalizeArgs {
+    NoKeySink s;
+    int grid;
+    uint64_t* outVals;
+    uint8_t* outValid;
+};
+__global__ __launch_bounds__(kBlock) void NoKeyFinalizeKernel(const FinalizeArgs) {
+    const FinalizeArgs& fa = KernArgsAs<FinalizeArgs>();
+    const NoKeySink& s = fa.s;
+    const int grid = fa.grid;
+    uint64_t* outVals = fa.outVals;
+    uint8_t* outValid = fa.outValid;
+    __shared__ uint64_t lds[kWaves];
+    __shared__ uint32_t ldsSeen[kWaves];
+    uint32_t seen = 0;
+    for (int b = threadIdx.x; b < grid; b += kBlock) seen |= s.partial_seen[b];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) seen |= __shfl_xor(seen, off, 64);
+    if (LaneId() == 0) ldsSeen[WaveId()] = seen;
+    __syncthreads();
+    seen = ldsSeen[0] | ldsSeen[1] | ldsSeen[2] | ldsSeen[3];
+    for (int k = 0; k < s.naggs; ++k) {
+        const int kind = s.aggs[k].kind;
+        uint64_t v = AggIdentity(kind);
+        for (int b = threadIdx.x; b < grid; b += kBlock) v = AggCombine(kind, v, s.partial[size_t(b) * kMaxAggs + k]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = AggCombine(kind, v, ShflXor64(v, off));
+        __syncthreads();
+        if (LaneId() == 0) lds[WaveId()] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t r = lds[0];
+            for (int w = 1; w < kWaves; ++w) r = AggCombine(kind, r, lds[w]);
+            outVals[k] = r;
+            outValid[k] = (kind == AGG_COUNT) ? 1 : ((seen >> k) & 1u);
+        }
+    }
+}
+
+// ---- sink: filter bitmap ----------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(kBlock) void ScanFilterKernel(const KArgs<FilterSink>) {
+    const ScanArgs& a = KernArgs<FilterSink>().a;
+    const FilterSink& s = KernArgs<FilterSink>().s;
+    Machine<U> m(a);
+    __shared__ uint32_t ldsCount[kWaves];
+    const int64_t ntiles = (a.nrows + kBlock * U - 1) / (kBlock * U);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t tileBase = tile * (kBlock * U);
+        m.BeginTile(tileBase);
+        m.Run();
+        uint32_t count = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t word = __ballot((m.P >> u) & 1u);
+            const int64_t firstRow = tileBase + int64_t(u) * kBlock + WaveId() * 64;
+            if (LaneId() == 0 && firstRow < a.nrows) s.bitmap[firstRow >> 6] = word;
+            count += __popcll(word);
+        }
+        if (LaneId() == 0) ldsCount[WaveId()] = count;
+        __syncthreads();
+        if (threadIdx.x == 0) s.tile_counts[tile] = ldsCount[0] + ldsCount[1] + ldsCount[2] + ldsCount[3];
+        __syncthreads();
+    }
+    m.ReportErrors();
+}
+
+// Position of the first row of this wave's 64-row word among the selected rows of its tile.
+// wordInTile = index (0..15) of the word inside the tile of kTileRows rows.
+__device__ __forceinline__ uint32_t SelectedBeforeWord(const uint64_t* bitmap, int64_t tileFirstWord, int wordInTile,
+                                                       int64_t nwords) {
+    const int lane = LaneId();
+    uint32_t c = 0;
+    if (lane < wordInTile && tileFirstWord + lane < nwords) c = __popcll(bitmap[tileFirstWord + lane]);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);  // words live in lanes 0..15
+    return __shfl(c, 0, 64);
+}
+
+// ---- sink: projection (computed columns written at compacted positions) -------------------------------
+template <int U>
+__global__ __launch_bounds__(kBlock) void ScanProjectKernel(const KArgs<ProjectSink>) {
+    const ScanArgs& a = KernArgs<ProjectSink>().a;
+    const ProjectSink& s = KernArgs<ProjectSink>().s;
+    Machine<U> m(a);
+    const int64_t ntiles = (a.nrows + kBlock * U - 1) / (kBlock * U);
+    const int64_t nwords = (a.nrows + 63) >> 6;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t tileBase = tile * (kBlock * U);
+        int64_t pos[U];
+        uint32_t sel = 0;
+        if (s.bitmap != nullptr) {
+            const int64_t tileOff = s.tile_offsets[tile];
+            if (s.tile_offsets[tile + 1] == tileOff) continue;  // nothing selected in this tile
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int wordInTile = u * kWaves + WaveId();
+                const int64_t wordIdx = (tileBase >> 6) + wordInTile;
+                const uint64_t word = wordIdx < nwords ? s.bitmap[wordIdx] : 0;
+                const uint32_t before = SelectedBeforeWord(s.bitmap, tileBase >> 6, wordInTile, nwords);
+                const int lane = LaneId();
+                sel |= uint32_t((word >> lane) & 1ull) << u;
+                pos[u] = tileOff + before + __popcll(word & ((1ull << lane) - 1ull));
+            }
+        }
+        m.BeginTile(tileBase);
+        if (s.bitmap == nullptr) {
+            sel = m.act;
+#pragma unroll
+            for (int u = 0; u < U; ++u) pos[u] = m.Row(u);
+        }
+        m.Run();
+#pragma unroll
+        for (int k = 0; k < kMaxOuts; ++k) {
+            if (k < s.nouts) {
+                const ProjectOut o = s.outs[k];
+                Val<U> x;
+                m.FetchOperand(o.reg, x);
+                const int w = (o.type == T_BOOL) ? 1 : TypeWidth(o.type);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if ((sel >> u) & 1u) {
+                        StoreTyped(o.values, w, pos[u], PayloadToStored(x.v[u], o.type));
+                        if (o.valid_bytes != nullptr) o.valid_bytes[pos[u]] = uint8_t((x.ok >> u) & 1u);
+                    }
+                }
+            }
+        }
+    }
+    m.ReportErrors();
+}
+
+// ---- exclusive scans ------------------------------------------------------------------------------
+constexpr int kScanItems = 16;
+constexpr int kScanChunk = kBlock * kScanItems;  // elements per workgroup
+
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void ScanBlockSumsKernel(const TIn* in, int64_t n, int64_t* blockSums) {
+    __shared__ int64_t lds[kWaves];
+    const int64_t base = int64_t(blockIdx.x) * kScanChunk;
+    int64_t sum = 0;
+    for (int i = threadIdx.x; i < kScanChunk; i += kBlock) {
+        const int64_t idx = base + i;
+        if (idx < n) sum += int64_t(in[idx]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += int64_t(ShflXor64(uint64_t(sum), off));
+    if (LaneId() == 0) lds[WaveId()] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// Single workgroup: exclusive scan of blockSums in place; total -> *total (may be nullptr).
+__global__ __launch_bounds__(kBlock) void ScanOfBlockSumsKernel(int64_t* blockSums, int64_t nblocks, int64_t* total) {
+    __shared__ int64_t lds[kBlock];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblocks; base += kBlock) {
+        const int64_t idx = base + threadIdx.x;
+        const int64_t v = idx < nblocks ? blockSums[idx] : 0;
+        lds[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kBlock; off <<= 1) {  // Hillis-Steele inclusive scan
+            int64_t t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0;
+            __syncthreads();
+            lds[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int64_t incl = lds[threadIdx.x];
+        const int64_t c = carry;
+        if (idx < nblocks) blockSums[idx] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total != nullptr) *total = carry;
+}
+
+// out[i] = blockOffset + exclusive prefix inside the chunk.  When `appendTotal` is set out[n] = total.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(kBlock) void ScanApplyKernel(const TIn* in, int64_t n, const int64_t* blockOffsets, TOut* out,
+                                                        const int64_t* total, int appendTotal) {
+    __shared__ int64_t waveSums[kWaves];
+    const int64_t base = int64_t(blockIdx.x) * kScanChunk + int64_t(threadIdx.x) * kScanItems;
+    int64_t vals[kScanItems];
+    int64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        const int64_t idx = base + i;
+        vals[i] = idx < n ? int64_t(in[idx]) : 0;
+        sum += vals[i];
+    }
+    // exclusive scan of per-thread sums inside the wave, then across waves
+    int64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int64_t t = int64_t(__shfl_up(static_cast<unsigned long long>(incl), off, 64));
+        if (LaneId() >= off) incl += t;
+    }
+    if (LaneId() == 63) waveSums[WaveId()] = incl;
+    __syncthreads();
+    int64_t waveOff = 0;
+    for (int w = 0; w < WaveId(); ++w) waveOff += waveSums[w];
+    int64_t run = blockOffsets[blockIdx.x] + waveOff + incl - sum;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        const int64_t idx = base + i;
+        if (idx < n) out[idx] = TOut(run);
+        run += vals[i];
+    }
+    if (appendTotal && blockIdx.x == 0 && threadIdx.x == 0) out[n] = TOut(*total);
+}
+
+// ---- stream compaction of source columns --------------------------------------------------------------
+// One lane per row; a wave covers exactly one 64-row bitmap word.
+__device__ __forceinline__ bool RowPosition(const uint64_t* bitmap, const int64_t* tileOffsets, int64_t row, int64_t nrows,
+                                            int64_t& pos) {
+    const int64_t nwords = (nrows + 63) >> 6;
+    const int64_t wordIdx = row >> 6;  // wave-uniform
+    const int64_t tile = row / kTileRows;
+    const int64_t tileFirstWord = tile * (kTileRows / 64);
+    const int wordInTile = int(wordIdx - tileFirstWord);
+    const uint64_t word = wordIdx < nwords ? bitmap[wordIdx] : 0;
+    const uint32_t before = SelectedBeforeWord(bitmap, tileFirstWord, wordInTile, nwords);
+    const int lane = LaneId();
+    pos = tileOffsets[tile < (nrows + kTileRows - 1) / kTileRows ? tile : 0] + before + __popcll(word & ((1ull << lane) - 1ull));
+    return row < nrows && ((word >> lane) & 1ull);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void CompactFixedKernel(const T* src, T* dst, int64_t nrows, const uint64_t* bitmap,
+                                                           const int64_t* tileOffsets) {
+    const int64_t nloops = (nrows + int64_t(gridDim.x) * kBlock - 1) / (int64_t(gridDim.x) * kBlock);
+    for (int64_t it = 0; it < nloops; ++it) {
+        const int64_t row = (it * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        if ((row & ~63ll) >= nrows) continue;  // wave-uniform exit
+        int64_t pos;
+        if (RowPosition(bitmap, tileOffsets, row, nrows, pos)) dst[pos] = src[row];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void CompactBitsKernel(const uint8_t* srcBits, int64_t srcBitOff, uint8_t* dstBytes,
+                                                          int64_t nrows, const uint64_t* bitmap, const int64_t* tileOffsets) {
+    const int64_t nloops = (nrows + int64_t(gridDim.x) * kBlock - 1) / (int64_t(gridDim.x) * kBlock);
+    for (int64_t it = 0; it < nloops; ++it) {
+        const int64_t row = (it * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        if ((row & ~63ll) >= nrows) continue;
+        int64_t pos;
+        if (RowPosition(bitmap, tileOffsets, row, nrows, pos)) dstBytes[pos] = uint8_t(LoadBit(srcBits, row + srcBitOff));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void CompactStringLensKernel(const int32_t* offsets, int32_t* outLens, int64_t nrows,
+                                                                const uint64_t* bitmap, const int64_t* tileOffsets) {
+    const int64_t nloops = (nrows + int64_t(gridDim.x) * kBlock - 1) / (int64_t(gridDim.x) * kBlock);
+    for (int64_t it = 0; it < nloops; ++it) {
+        const int64_t row = (it * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        if ((row & ~63ll) >= nrows) continue;
+        int64_t pos;
+        if (RowPosition(bitmap, tileOffsets, row, nrows, pos)) outLens[pos] = offsets[row + 1] - offsets[row];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void CompactStringBytesKernel(const int32_t* offsets, const uint8_t* chars,
+                                                                 const int32_t* newOffsets, uint8_t* outChars, int64_t nrows,
+                                                                 const uint64_t* bitmap, const int64_t* tileOffsets) {
+    const int64_t nloops = (nrows + int64_t(gridDim.x) * kBlock - 1) / (int64_t(gridDim.x) * kBlock);
+    for (int64_t it = 0; it < nloops; ++it) {
+        const int64_t row = (it * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        if ((row & ~63ll) >= nrows) continue;
+        int64_t pos;
+        if (RowPosition(bitmap, tileOffsets, row, nrows, pos)) {
+            const int32_t b = offsets[row], n = offsets[row + 1] - b, o = newOffsets[pos];
+            for (int32_t i = 0; i < n; ++i) outChars[o + i] = chars[b + i];
+        }
+    }
+}
+
+// 8 bytes -> 1 bitmap byte; counts zero bytes (nulls / false values).
+__global__ __launch_bounds__(kBlock) void PackBytesToBitsKernel(const uint8_t* src, int64_t n, uint8_t* dstBits,
+                                                              unsigned long long* zeroCount) {
+    const int64_t nbytes = (n + 7) >> 3;
+    unsigned long long zeros = 0;
+    for (int64_t ob = int64_t(blockIdx.x) * kBlock + threadIdx.x; ob < nbytes; ob += int64_t(gridDim.x) * kBlock) {
+        uint32_t b = 0;
+        for (int i = 0; i < 8; ++i) {
+            const int64_t idx = ob * 8 + i;
+            if (idx < n) {
+                if (src[idx]) b |= 1u << i; else ++zeros;
+            }
+        }
+        dstBits[ob] = uint8_t(b);
+    }
+    if (zeroCount != nullptr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) zeros += ShflXor64(zeros, off);
+        if (LaneId() == 0 && zeros) atomicAdd(zeroCount, zeros);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void CountBitsKernel(const uint8_t* bits, int64_t bitOff, int64_t nbits,
+                                                        unsigned long long* out) {
+    unsigned long long c = 0;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nbits; i += int64_t(gridDim.x) * kBlock) {
+        c += LoadBit(bits, i + bitOff);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += ShflXor64(c, off);
+    if (LaneId() == 0 && c) atomicAdd(out, c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void FillKernel(T* dst, T value, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) dst[i] = value;
+}
+
+struct U128 {
+    uint64_t lo, hi;
+};
+
+int GridFor(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return int(g);
+}
+
+}  // namespace
+
+// ---- launchers ------------------------------------------------------------------------------------
+#define SSA_LAUNCH_SCAN(KERNEL, SINK, A, S, CFG)                                                        \
+    do {                                                                                                \
+        KArgs<SINK> k{A, S};                                                                            \
+        hipLaunchKernelGGL((KERNEL<kRowsPerThread>), dim3((CFG).grid), dim3(kBlock), (CFG).lds_bytes, (CFG).stream, k); \
+        return hipGetLastError();                                                                       \
+    } while (0)
+
+hipError_t LaunchScanNoKey(const ScanArgs& a, const NoKeySink& s, LaunchCfg cfg) {
+    SSA_LAUNCH_SCAN(ScanNoKeyKernel, NoKeySink, a, s, cfg);
+}
+hipError_t LaunchScanFilter(const ScanArgs& a, const FilterSink& s, LaunchCfg cfg) {
+    SSA_LAUNCH_SCAN(ScanFilterKernel, FilterSink, a, s, cfg);
+}
+hipError_t LaunchScanProject(const ScanArgs& a, const ProjectSink& s, LaunchCfg cfg) {
+    SSA_LAUNCH_SCAN(ScanProjectKernel, ProjectSink, a, s, cfg);
+}
+
+hipError_t LaunchNoKeyFinalize(const NoKeySink& s, int grid, uint64_t* outVals, uint8_t* outValid, hipStream_t st) {
+    FinalizeArgs fa{s, grid, outVals, outValid};
+    hipLaunchKernelGGL(NoKeyFinalizeKernel, dim3(1), dim3(kBlock), 0, st, fa);
+    return hipGetLastError();
+}
+
+// block_tmp must hold ceil(n / kScanChunk) int64 values.
+template <typename TIn, typename TOut>
+static hipError_t ExclusiveScan(const TIn* in, TOut* out, int64_t n, int64_t* blockTmp, int64_t* total, bool appendTotal,
+                                hipStream_t st) {
+    if (n <= 0) {
+        if (total != nullptr) (void)hipMemsetAsync(total, 0, sizeof(int64_t), st);
+        if (appendTotal) (void)hipMemsetAsync(out, 0, sizeof(TOut), st);
+        return hipGetLastError();
+    }
+    const int64_t nblocks = (n + kScanChunk - 1) / kScanChunk;
+    hipLaunchKernelGGL((ScanBlockSumsKernel<TIn>), dim3(uint32_t(nblocks)), dim3(kBlock), 0, st, in, n, blockTmp);
+    hipLaunchKernelGGL(ScanOfBlockSumsKernel, dim3(1), dim3(kBlock), 0, st, blockTmp, nblocks, total);
+    hipLaunchKernelGGL((ScanApplyKernel<TIn, TOut>), dim3(uint32_t(nblocks)), dim3(kBlock), 0, st, in, n, blockTmp, out, total,
+                       appendTotal ? 1 : 0);
+    return hipGetLastError();
+}
+
+// tile_offsets has ntiles + 1 entries (the last one = total); the tail of the same buffer is the block scratch.
+hipError_t LaunchTileScan(const uint32_t* tileCounts, int64_t ntiles, int64_t* tileOffsets, int64_t* total, hipStream_t st) {
+    int64_t* blockTmp = tileOffsets + ntiles + 1;
+    return ExclusiveScan<uint32_t, int64_t>(tileCounts, tileOffsets, ntiles, blockTmp, total, true, st);
+}
+
+hipError_t LaunchExclusiveScanI32(const int32_t* in, int32_t* out, int64_t n, int64_t* blockTmp, hipStream_t st) {
+    // blockTmp: ceil(n / kScanChunk) + 1 values, the last one receives the total
+    const int64_t nblocks = (n + kScanChunk - 1) / kScanChunk;
+    return ExclusiveScan<int32_t, int32_t>(in, out, n, blockTmp, blockTmp + nblocks, true, st);
+}
+
+hipError_t LaunchCompactFixed(const void* src, void* dst, int width, int64_t nrows, const uint64_t* bitmap,
+                              const int64_t* tileOffsets, hipStream_t st) {
+    const int grid = GridFor(nrows);
+    switch (width) {
+        case 1: hipLaunchKernelGGL((CompactFixedKernel<uint8_t>), dim3(grid), dim3(kBlock), 0, st, (const uint8_t*)src, (uint8_t*)dst, nrows, bitmap, tileOffsets); break;
+        case 2: hipLaunchKernelGGL((CompactFixedKernel<uint16_t>), dim3(grid), dim3(kBlock), 0, st, (const uint16_t*)src, (uint16_t*)dst, nrows, bitmap, tileOffsets); break;
+        case 4: hipLaunchKernelGGL((CompactFixedKernel<uint32_t>), dim3(grid), dim3(kBlock), 0, st, (const uint32_t*)src, (uint32_t*)dst, nrows, bitmap, tileOffsets); break;
+        case 8: hipLaunchKernelGGL((CompactFixedKernel<uint64_t>), dim3(grid), dim3(kBlock), 0, st, (const uint64_t*)src, (uint64_t*)dst, nrows, bitmap, tileOffsets); break;
+        case 16: hipLaunchKernelGGL((CompactFixedKernel<U128>), dim3(grid), dim3(kBlock), 0, st, (const U128*)src, (U128*)dst, nrows, bitmap, tileOffsets); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t LaunchCompactBits(const uint8_t* srcBits, int64_t srcBitOff, uint8_t* dstBytes, int64_t nrows,
+                             const uint64_t* bitmap, const int64_t* tileOffsets, hipStream_t st) {
+    hipLaunchKernelGGL(CompactBitsKernel, dim3(GridFor(nrows)), dim3(kBlock), 0, st, srcBits, srcBitOff, dstBytes, nrows, bitmap, tileOffsets);
+    return hipGetLastError();
+}
+
+hipError_t LaunchPackBytesToBits(const uint8_t* srcBytes, int64_t n, uint8_t* dstBits, unsigned long long* zeroCount,
+                                 hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(PackBytesToBitsKernel, dim3(GridFor((n + 7) / 8)), dim3(kBlock), 0, st, srcBytes, n, dstBits, zeroCount);
+    return hipGetLastError();
+}
+
+hipError_t LaunchCompactStringLens(const int32_t* offsets, int32_t* outLens, int64_t nrows, const uint64_t* bitmap,
+                                   const int64_t* tileOffsets, hipStream_t st) {
+    hipLaunchKernelGGL(CompactStringLensKernel, dim3(GridFor(nrows)), dim3(kBlock), 0, st, offsets, outLens, nrows, bitmap, tileOffsets);
+    return hipGetLastError();
+}
+
+hipError_t LaunchCompactStringBytes(const int32_t* offsets, const uint8_t* chars, const int32_t* newOffsets,
+                                    uint8_t* outChars, int64_t nrows, const uint64_t* bitmap,
+                                    const int64_t* tileOffsets, hipStream_t st) {
+    hipLaunchKernelGGL(CompactStringBytesKernel, dim3(GridFor(nrows)), dim3(kBlock), 0, st, offsets, chars, newOffsets, outChars, nrows, bitmap, tileOffsets);
+    return hipGetLastError();
+}
+
+hipError_t LaunchFill(void* dst, int width, uint64_t value, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int grid = GridFor(n);
+    switch (width) {
+        case 1: hipLaunchKernelGGL((FillKernel<uint8_t>), dim3(grid), dim3(kBlock), 0, st, (uint8_t*)dst, uint8_t(value), n); break;
+        case 2: hipLaunchKernelGGL((FillKernel<uint16_t>), dim3(grid), dim3(kBlock), 0, st, (uint16_t*)dst, uint16_t(value), n); break;
+        case 4: hipLaunchKernelGGL((FillKernel<uint32_t>), dim3(grid), dim3(kBlock), 0, st, (uint32_t*)dst, uint32_t(value), n); break;
+        case 8: hipLaunchKernelGGL((FillKernel<uint64_t>), dim3(grid), dim3(kBlock), 0, st, (uint64_t*)dst, value, n); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t LaunchCountBits(const uint8_t* bits, int64_t bitOff, int64_t nbits, unsigned long long* out, hipStream_t st) {
+    if (nbits <= 0) return hipSuccess;
+    hipLaunchKernelGGL(CountBitsKernel, dim3(GridFor(nbits)), dim3(kBlock), 0, st, bits, bitOff, nbits, out);
+    return hipGetLastError();
+}
+
+}  // namespace ssa

@@ -1,0 +1,215 @@
+// Shared host/device definitions: column types, the scan-VM instruction set and the
+// argument blocks passed to the HIP kernels.
+//
+// One program step (Assigns -> Filters -> Aggregates|Projection, the order fixed by
+// ydb/core/formats/arrow/program.cpp:869-902 of the reference) is lowered by the plan
+// compiler into ONE pass over the rows: a small accumulator-machine program evaluates
+// every Assign expression that is still needed, ANDs the Filter predicates into a row
+// predicate, and leaves the aggregate arguments / group-by keys / projected values in
+// "output registers" which the kernel's sink consumes.  Intermediates never touch HBM.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SSA_HD __host__ __device__ __forceinline__
+#else
+#define SSA_HD inline
+#endif
+
+namespace ssa {
+
+// Arrow types the column-shard scan path can see (ydb/core/formats/arrow/switch/switch_type.h:125-172).
+enum TypeId : int32_t {
+    T_NONE = 0,
+    T_BOOL = 1,  // bit-packed, LSB first
+    T_I8 = 2,
+    T_I16 = 3,
+    T_I32 = 4,
+    T_I64 = 5,
+    T_U8 = 6,
+    T_U16 = 7,
+    T_U32 = 8,
+    T_U64 = 9,
+    T_F32 = 10,
+    T_F64 = 11,
+    T_TS = 12,      // timestamp[us], int64
+    T_DUR = 13,     // duration[us], int64
+    T_STRING = 14,  // utf8, int32 offsets
+    T_BINARY = 15,  // binary, int32 offsets
+    T_DEC128 = 16,  // decimal128(p, s), 16-byte little-endian two's complement
+};
+
+SSA_HD bool IsSignedInt(int t) { return t >= T_I8 && t <= T_I64; }
+SSA_HD bool IsUnsignedInt(int t) { return t >= T_U8 && t <= T_U64; }
+SSA_HD bool IsInt(int t) { return t >= T_I8 && t <= T_U64; }
+SSA_HD bool IsFloat(int t) { return t == T_F32 || t == T_F64; }
+SSA_HD bool IsNumeric(int t) { return t >= T_I8 && t <= T_F64; }
+SSA_HD bool IsStringLike(int t) { return t == T_STRING || t == T_BINARY; }
+SSA_HD bool IsTemporal(int t) { return t == T_TS || t == T_DUR; }
+SSA_HD int TypeWidth(int t) {  // bytes of one fixed-width value, 0 for bit-packed / variable
+    switch (t) {
+        case T_I8: case T_U8: return 1;
+        case T_I16: case T_U16: return 2;
+        case T_I32: case T_U32: case T_F32: return 4;
+        case T_I64: case T_U64: case T_F64: case T_TS: case T_DUR: return 8;
+        case T_DEC128: return 16;
+        default: return 0;
+    }
+}
+
+// Value classes: how a 64-bit VM payload is interpreted by an instruction.
+enum ValClass : int32_t {
+    CLS_I = 0,    // signed integer, sign-extended to 64 bits
+    CLS_U = 1,    // unsigned integer, zero-extended (also BOOL 0/1)
+    CLS_F64 = 2,  // IEEE double
+    CLS_F32 = 3,  // float value held exactly in a double payload; arithmetic rounds to float
+    CLS_IU = 4,   // compare only: A signed, B unsigned (value-correct mixed compare)
+    CLS_UI = 5,   // compare only: A unsigned, B signed
+};
+SSA_HD int ClassOfType(int t) {
+    if (IsSignedInt(t) || IsTemporal(t)) return CLS_I;
+    if (IsUnsignedInt(t) || t == T_BOOL) return CLS_U;
+    if (t == T_F32) return CLS_F32;
+    return CLS_F64;
+}
+
+enum CmpOp : int32_t { CMP_EQ = 0, CMP_NE = 1, CMP_LT = 2, CMP_LE = 3, CMP_GT = 4, CMP_GE = 5 };
+
+// Null/zero-division conventions of the two kernel families the reference dispatches to.
+enum Dialect : int32_t {
+    DIALECT_ARROW = 0,  // Arrow 5.0 compute: validity = AND of inputs; int x/0 -> error Status
+    DIALECT_YQL = 1,    // YQL block kernels: x/0 and MIN/-1 -> NULL; And/Or are Kleene
+};
+
+enum SrcKind : int32_t { SRC_NONE = 0, SRC_COL = 1, SRC_CONST = 2, SRC_REG = 3 };
+
+enum StrMatchKind : int32_t { STR_CONTAINS = 0, STR_STARTS = 1, STR_ENDS = 2 };
+
+enum OpCode : int32_t {
+    OP_END = 0,
+    OP_LD,        // A = src
+    OP_ST,        // R[si] = A
+    OP_ADD,       // A = A + B            a = class
+    OP_SUB,       // A = A - B
+    OP_RSUB,      // A = B - A
+    OP_MUL,
+    OP_DIV,       // A = A / B            a = class, b = dialect | (result TypeId << 1)
+    OP_RDIV,      // A = B / A
+    OP_MOD,       // A = A % B            (YQL Mod)
+    OP_RMOD,
+    OP_CMP,       // A = A cmp B          a = class, b = CmpOp
+    OP_AND,       // b = dialect (ARROW: null if either null; YQL: Kleene)
+    OP_OR,
+    OP_XOR,
+    OP_NOT,
+    OP_NEG,       // a = class
+    OP_ABS,       // a = class
+    OP_ISNULL,
+    OP_ISVALID,
+    OP_WRAP,      // a = TypeId: wrap integer payload to that type's width
+    OP_CAST,      // a = source class, b = target TypeId (C++ static_cast semantics)
+    OP_CHECK,     // a = source class, b = target TypeId: flag an error if the value does not fit (safe implicit cast)
+    OP_COALESCE,  // A = A.valid ? A : B
+    OP_STRLEN,    // A = byte length of string column si
+    OP_STRMATCH,  // A = match(string column si, pattern const a); b = StrMatchKind | (ignore_case << 4)
+    OP_STRCMP,    // A = string column si  cmp  (const a | column a); b = CmpOp | (rhs_is_column << 4)
+    OP_PRED,      // P &= (A != 0)   -- value bit only, validity ignored (reference: program.cpp:517-527)
+    OP_ROWIDX,    // A.value = global row index; A's validity is kept
+};
+
+SSA_HD uint32_t MakeInsn(int op, int sk = 0, int si = 0, int a = 0, int b = 0) {
+    return uint32_t(op & 0xFF) | (uint32_t(sk & 3) << 8) | (uint32_t(si & 0x3F) << 10) | (uint32_t(a & 0xFF) << 16) |
+           (uint32_t(b & 0xFF) << 24);
+}
+SSA_HD int InsnOp(uint32_t i) { return i & 0xFF; }
+SSA_HD int InsnSk(uint32_t i) { return (i >> 8) & 3; }
+SSA_HD int InsnSi(uint32_t i) { return (i >> 10) & 0x3F; }
+SSA_HD int InsnA(uint32_t i) { return (i >> 16) & 0xFF; }
+SSA_HD int InsnB(uint32_t i) { return (i >> 24) & 0xFF; }
+
+constexpr int kMaxCols = 16;     // source columns referenced by one scan program
+constexpr int kMaxRegs = 16;     // R registers (outputs first, then temporaries); they live in LDS
+constexpr int kMaxConsts = 24;
+constexpr int kMaxCode = 128;
+constexpr int kMaxAggs = 12;
+constexpr int kMaxKeys = 6;
+constexpr int kMaxOuts = 12;
+constexpr int kMaxPatternBytes = 256;  // all string constants of one program, concatenated
+
+// Error bits a scan kernel can raise (OR-ed into ScanArgs::status).
+enum ScanStatus : uint32_t {
+    SCAN_OK = 0,
+    SCAN_DIV_BY_ZERO = 1,      // Arrow integer divide by zero -> Status::Invalid("divide by zero")
+    SCAN_CAST_OVERFLOW = 2,    // safe implicit cast failed -> Status::Invalid("Integer value ... not in range")
+    SCAN_TABLE_FULL = 4,       // group-by spill table ran out of slots (host retries with a bigger one)
+};
+
+struct DevColumn {
+    const void* values;       // fixed width: values; BOOL: bitmap; strings: int32 offsets (rows + 1 entries)
+    const uint8_t* validity;  // validity bitmap or nullptr
+    const uint8_t* chars;     // string bytes
+    int32_t type;
+    int32_t val_bit_off;      // BOOL columns: bit offset of row 0 inside `values`
+    int32_t valid_bit_off;    // bit offset of row 0 inside `validity`
+    int32_t pad;
+};
+
+struct DevConst {
+    uint64_t bits;     // payload (numeric) or (offset << 32 | length) into ScanArgs::pattern for strings
+    int32_t valid;
+    int32_t type;
+};
+
+enum AggKind : int32_t {
+    AGG_NONE = 0,
+    AGG_COUNT,     // counts rows where the argument is valid (or all rows when reg < 0)
+    AGG_SUM_I,     // wrapping 64-bit integer sum (signed and unsigned share the bits)
+    AGG_SUM_F,     // double sum
+    AGG_MIN_I, AGG_MAX_I,
+    AGG_MIN_U, AGG_MAX_U,
+    AGG_MIN_F, AGG_MAX_F,
+    AGG_SOME,      // first non-null in row order
+};
+
+struct AggSpec {
+    int32_t kind;
+    int32_t reg;        // >= 0: R register holding the argument; -1: none (COUNT of rows); <= -2: column slot (-2 - reg)
+    int32_t arg_class;  // ValClass of the argument payload
+    int32_t check_valid; // skip rows whose argument is null (0: the argument's validity is not consulted)
+};
+
+struct KeySpec {
+    int32_t reg;        // fixed width keys: >= 0 R register, <= -2 column slot (-2 - reg); -1 for string keys
+    int32_t col;        // string keys: source column index
+    int32_t type;       // TypeId
+    int32_t nullable;   // key contributes a null flag
+};
+
+enum SinkKind : int32_t {
+    SINK_AGG_NOKEY = 0,   // per-block partial aggregates -> finalize
+    SINK_FILTER_BITS = 1, // predicate bitmap + per-tile selected counts
+    SINK_PROJECT = 2,     // compaction of output registers at precomputed positions
+    SINK_AGG_KEYED = 3,   // LDS-staged hash aggregation with a global spill table
+};
+
+struct ScanArgs {
+    int64_t nrows;
+    int32_t ncols;
+    int32_t ncode;
+    int32_t nconsts;
+    int32_t nullable;        // any nullable input / null-producing op: validity is tracked
+    DevColumn cols[kMaxCols];
+    DevConst consts[kMaxConsts];
+    uint32_t code[kMaxCode];
+    uint8_t pattern[kMaxPatternBytes];
+    uint32_t* status;        // device word, OR-ed with ScanStatus bits
+    // LDS plan of one workgroup (byte offsets into dynamic shared memory)
+    int32_t lds_col_off[kMaxCols];  // staged tile of column c, or -1: read from global memory on demand
+    int32_t lds_reg_off;            // R register values: nregs x tile rows x 8 bytes
+    int32_t lds_regok_off;          // R register validity: nregs x lanes bytes
+    int32_t nregs;
+    int32_t lds_sink_off;           // first byte available to the sink (group-by table)
+};
+
+}  // namespace ssa

@@ -1,0 +1,238 @@
+// Per-element semantics of the scan-VM instructions, shared by the HIP kernels and by the
+// plan compiler's constant folder so a scalar-scalar expression folds to exactly what the
+// kernel would have computed row by row.
+//
+// Semantics restated from the reference's delegates:
+//  * Arrow 5.0 arithmetic: unchecked wrap-around integers, int x/0 -> error, MIN/-1 -> 0
+//    (contrib/libs/apache/arrow/cpp/src/arrow/compute/kernels/scalar_arithmetic.cc:122-327)
+//  * Arrow compare on the common numeric type (scalar_compare.cc:36-66, codegen_internal.cc:226-278)
+//  * YQL block kernels: value-correct mixed-sign compare, x/0 and MIN/-1 -> NULL
+//    (ydb/library/yql/minikql/invoke_builtins/mkql_builtins_equals.cpp:13-44,
+//     mkql_builtins_less.cpp:13-44, mkql_builtins_div.cpp:30-48)
+#pragma once
+#include "vm.h"
+
+namespace ssa {
+
+SSA_HD double BitsToF64(uint64_t b) {
+    double d;
+    __builtin_memcpy(&d, &b, 8);
+    return d;
+}
+SSA_HD uint64_t F64ToBits(double d) {
+    uint64_t b;
+    __builtin_memcpy(&b, &d, 8);
+    return b;
+}
+SSA_HD float BitsToF32(uint32_t b) {
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+
+// Wrap an integer payload to the width/signedness of integer type `t`.
+SSA_HD uint64_t WrapTo(uint64_t v, int t) {
+    switch (t) {
+        case T_I8: return uint64_t(int64_t(int8_t(v)));
+        case T_I16: return uint64_t(int64_t(int16_t(v)));
+        case T_I32: return uint64_t(int64_t(int32_t(v)));
+        case T_U8: return uint64_t(uint8_t(v));
+        case T_U16: return uint64_t(uint16_t(v));
+        case T_U32: return uint64_t(uint32_t(v));
+        case T_BOOL: return v != 0 ? 1 : 0;
+        default: return v;
+    }
+}
+
+// static_cast between numeric representations.  `from` is the payload class, `to` a TypeId.
+SSA_HD uint64_t CastVal(uint64_t v, int from, int to) {
+    const bool toF = (to == T_F32 || to == T_F64);
+    if (from == CLS_I || from == CLS_U) {
+        if (to == T_BOOL) return v != 0 ? 1 : 0;
+        if (!toF) return WrapTo(v, to);
+        double d = (from == CLS_I) ? double(int64_t(v)) : double(v);
+        if (to == T_F32) {
+            float f = (from == CLS_I) ? float(int64_t(v)) : float(v);
+            d = double(f);
+        }
+        return F64ToBits(d);
+    }
+    // floating source (F32 payloads are exact doubles)
+    double d = BitsToF64(v);
+    if (to == T_F64) return v;
+    if (to == T_F32) return F64ToBits(double(float(d)));
+    if (to == T_BOOL) return d != 0.0 ? 1 : 0;
+    if (IsUnsignedInt(to)) return WrapTo(uint64_t(d), to);
+    return WrapTo(uint64_t(int64_t(d)), to);
+}
+
+// Would a *safe* cast of this value to `to` succeed?  (Arrow's implicit casts inserted by
+// DispatchBest are CastOptions::Safe: compute/cast.cc:256-270.)
+SSA_HD bool FitsType(uint64_t v, int from, int to) {
+    if (from == CLS_I) {
+        int64_t s = int64_t(v);
+        switch (to) {
+            case T_I8: return s >= -128 && s <= 127;
+            case T_I16: return s >= -32768 && s <= 32767;
+            case T_I32: return s >= -2147483648LL && s <= 2147483647LL;
+            case T_U8: return s >= 0 && s <= 255;
+            case T_U16: return s >= 0 && s <= 65535;
+            case T_U32: return s >= 0 && s <= 4294967295LL;
+            case T_U64: return s >= 0;
+            case T_F32: return s >= -(1LL << 24) && s <= (1LL << 24);
+            case T_F64: return s >= -(1LL << 53) && s <= (1LL << 53);
+            default: return true;
+        }
+    }
+    if (from == CLS_U) {
+        switch (to) {
+            case T_I8: return v <= 127;
+            case T_I16: return v <= 32767;
+            case T_I32: return v <= 2147483647ULL;
+            case T_I64: return v <= 9223372036854775807ULL;
+            case T_U8: return v <= 255;
+            case T_U16: return v <= 65535;
+            case T_U32: return v <= 4294967295ULL;
+            case T_F32: return v <= (1ULL << 24);
+            case T_F64: return v <= (1ULL << 53);
+            default: return true;
+        }
+    }
+    return true;
+}
+
+struct ArithResult {
+    uint64_t v;
+    bool null;   // YQL: result is NULL
+    bool error;  // Arrow: divide by zero
+};
+
+// ADD/SUB/MUL on payloads; integer results still need WrapTo(result type).
+SSA_HD uint64_t ArithBasic(int op, int cls, uint64_t a, uint64_t b) {
+    if (cls == CLS_F64) {
+        double x = BitsToF64(a), y = BitsToF64(b);
+        double r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : x * y;
+        return F64ToBits(r);
+    }
+    if (cls == CLS_F32) {
+        float x = float(BitsToF64(a)), y = float(BitsToF64(b));
+        float r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : x * y;
+        return F64ToBits(double(r));
+    }
+    return op == OP_ADD ? a + b : op == OP_SUB ? a - b : a * b;
+}
+
+// `t` is the result integer type: INT_MIN of *that* width divided by -1 is the overflow case.
+SSA_HD ArithResult ArithDiv(bool mod, int cls, int dialect, int t, uint64_t a, uint64_t b) {
+    ArithResult r{0, false, false};
+    if (cls == CLS_F64) {
+        double x = BitsToF64(a), y = BitsToF64(b);
+        r.v = F64ToBits(mod ? __builtin_fmod(x, y) : x / y);
+        return r;
+    }
+    if (cls == CLS_F32) {
+        float x = float(BitsToF64(a)), y = float(BitsToF64(b));
+        r.v = F64ToBits(double(mod ? __builtin_fmodf(x, y) : x / y));
+        return r;
+    }
+    if (b == 0) {
+        if (dialect == DIALECT_YQL) r.null = true; else r.error = true;
+        return r;
+    }
+    if (cls == CLS_U) {
+        r.v = mod ? a % b : a / b;
+        return r;
+    }
+    int64_t x = int64_t(a), y = int64_t(b);
+    int64_t lo = (t == T_I8) ? -128 : (t == T_I16) ? -32768 : (t == T_I32) ? -2147483648LL : INT64_MIN;
+    if (y == -1 && x == lo) {
+        if (dialect == DIALECT_YQL) r.null = true;  // mkql_builtins_div.cpp / mod: MIN / -1 -> NULL
+        r.v = 0;                                   // Arrow: result = 0
+        return r;
+    }
+    r.v = uint64_t(mod ? x % y : x / y);
+    return r;
+}
+
+SSA_HD bool CompareVals(int cmp, int cls, uint64_t a, uint64_t b) {
+    int lt, eq;  // a < b, a == b (unordered floats: both 0 and ne = 1)
+    bool unordered = false;
+    if (cls == CLS_F64 || cls == CLS_F32) {
+        double x = BitsToF64(a), y = BitsToF64(b);
+        lt = x < y;
+        eq = x == y;
+        unordered = (x != x) || (y != y);
+    } else if (cls == CLS_I) {
+        lt = int64_t(a) < int64_t(b);
+        eq = a == b;
+    } else if (cls == CLS_U) {
+        lt = a < b;
+        eq = a == b;
+    } else if (cls == CLS_IU) {  // a signed, b unsigned
+        bool neg = int64_t(a) < 0;
+        lt = neg || a < b;
+        eq = !neg && a == b;
+    } else {  // CLS_UI: a unsigned, b signed
+        bool neg = int64_t(b) < 0;
+        lt = !neg && a < b;
+        eq = !neg && a == b;
+    }
+    switch (cmp) {
+        case CMP_EQ: return eq;
+        case CMP_NE: return !eq;
+        case CMP_LT: return lt;
+        case CMP_LE: return lt || eq;
+        case CMP_GT: return !unordered && !lt && !eq;
+        default: return !unordered && !lt;  // CMP_GE
+    }
+}
+
+SSA_HD uint8_t AsciiLower(uint8_t c) { return (c >= 'A' && c <= 'Z') ? uint8_t(c + 32) : c; }
+
+// Byte-wise substring / prefix / suffix test (std::string_view semantics; an empty pattern
+// matches everything).  ignore_case folds ASCII letters only.
+SSA_HD bool StrMatch(int kind, bool icase, const uint8_t* s, int32_t n, const uint8_t* p, int32_t m) {
+    if (m > n) return false;
+    if (m == 0) return true;
+    int32_t first = 0, last = 0;
+    if (kind == STR_STARTS) {
+        first = last = 0;
+    } else if (kind == STR_ENDS) {
+        first = last = n - m;
+    } else {
+        first = 0;
+        last = n - m;
+    }
+    for (int32_t i = first; i <= last; ++i) {
+        int32_t j = 0;
+        if (icase) {
+            while (j < m && AsciiLower(s[i + j]) == AsciiLower(p[j])) ++j;
+        } else {
+            while (j < m && s[i + j] == p[j]) ++j;
+        }
+        if (j == m) return true;
+    }
+    return false;
+}
+
+// memcmp-style ordering of two byte strings (std::string_view operator<=>).
+SSA_HD int StrCompare(const uint8_t* a, int32_t n, const uint8_t* b, int32_t m) {
+    int32_t k = n < m ? n : m;
+    for (int32_t i = 0; i < k; ++i) {
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    }
+    return n < m ? -1 : (n > m ? 1 : 0);
+}
+
+SSA_HD bool CmpFromOrder(int cmp, int ord) {
+    switch (cmp) {
+        case CMP_EQ: return ord == 0;
+        case CMP_NE: return ord != 0;
+        case CMP_LT: return ord < 0;
+        case CMP_LE: return ord <= 0;
+        case CMP_GT: return ord > 0;
+        default: return ord >= 0;
+    }
+}
+
+}  // namespace ssa

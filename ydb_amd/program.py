@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's program objects over the C-ABI.
+
+`ProgramContainer` follows NOlap::TProgramContainer (ydb/core/tx/program/program.h:55-127):
+`Init(resolver, serialized)` parses a TOlapProgram / TProgram and returns (ok, error);
+`ApplyProgram(batch)` runs NSsa::TProgram::ApplyTo on the GPU.  The error behaviour matches the
+reference: parse failures are soft (False + message), execution failures raise `SsaError` carrying the
+arrow::Status-like code.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from .arrow_c import ArrowArray, ArrowSchema, Col, HostBatch, ResultColumn, read_batch
+from .ssa_pb import Program, olap_program
+
+
+class SsaError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{_lib.STATUS_NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.message = message
+
+
+class DeviceBatch:
+    """Record batch resident in HBM (ssa_batch_t)."""
+
+    def __init__(self, lib, handle, keep=None):
+        self._lib = lib
+        self._h = handle
+        self._keep = keep
+
+    @property
+    def rows(self) -> int:
+        return self._lib.ssa_batch_rows(self._h)
+
+    @property
+    def num_columns(self) -> int:
+        return self._lib.ssa_batch_columns(self._h)
+
+    def close(self):
+        if self._h:
+            self._lib.ssa_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+ColumnResolver = Sequence[Tuple[int, str]]  # (column id, column name), the IColumnResolver of the reference
+
+
+class ProgramContainer:
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        self._h = None
+        self._device = device
+
+    # -- TProgramContainer::Init -------------------------------------------------------------------
+    def Init(self, resolver: ColumnResolver, program: Union[Program, bytes], olap_wrapper: Optional[bool] = None,
+             parameters: Optional[HostBatch] = None) -> Tuple[bool, str]:
+        if isinstance(program, Program):
+            data = olap_program(program)
+            wrapper = True
+        else:
+            data = bytes(program)
+            wrapper = True if olap_wrapper is None else olap_wrapper
+        ids = (ctypes.c_uint32 * max(1, len(resolver)))(*[i for i, _ in resolver])
+        names_b = [n.encode() for _, n in resolver]
+        names = (ctypes.c_char_p * max(1, len(resolver)))(*names_b)
+        out = ctypes.c_void_p()
+        err = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(data, len(data))
+        pa = ctypes.byref(parameters.array) if parameters is not None else None
+        ps = ctypes.byref(parameters.schema) if parameters is not None else None
+        rc = self._lib.ssa_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), 1 if wrapper else 0, ids, names,
+                                          len(resolver), pa, ps, self._device, ctypes.byref(out), ctypes.byref(err))
+        msg = _lib.take_string(self._lib, err.value)
+        if rc != _lib.SSA_OK:
+            if rc != _lib.SSA_PARSE_ERROR:
+                raise SsaError(rc, msg)
+            return False, msg
+        self.close()
+        self._h = out.value
+        return True, ""
+
+    def HasProgram(self) -> bool:
+        return self._h is not None
+
+    def DebugString(self) -> str:
+        return _lib.take_string(self._lib, self._lib.ssa_program_debug_string(self._h))
+
+    def GetSourceColumns(self) -> List[str]:
+        s = _lib.take_string(self._lib, self._lib.ssa_program_source_columns(self._h))
+        return [x for x in s.split("\n") if x]
+
+    def GetEarlyFilterColumns(self) -> List[str]:
+        s = _lib.take_string(self._lib, self._lib.ssa_program_early_filter_columns(self._h))
+        return [x for x in s.split("\n") if x]
+
+    def StepCount(self) -> int:
+        return self._lib.ssa_program_step_count(self._h)
+
+    def Explain(self, batch: Union[HostBatch, Dict[str, object]]) -> str:
+        """Scan plans + output schema for this input schema (host only, no GPU needed)."""
+        hb = batch if isinstance(batch, HostBatch) else HostBatch(batch)
+        err = ctypes.c_void_p()
+        ptr = self._lib.ssa_program_explain(self._h, ctypes.byref(hb.schema), ctypes.byref(err))
+        msg = _lib.take_string(self._lib, err.value)
+        if not ptr:
+            raise SsaError(_lib.SSA_INVALID if "nsupported" not in msg else _lib.SSA_UNSUPPORTED, msg)
+        return _lib.take_string(self._lib, ptr)
+
+    # -- TProgram::ApplyTo ---------------------------------------------------------------------------
+    def _check(self, rc: int, err: ctypes.c_void_p):
+        msg = _lib.take_string(self._lib, err.value)
+        if rc != _lib.SSA_OK:
+            raise SsaError(rc, msg)
+
+    def ApplyProgram(self, batch: Union[HostBatch, Dict[str, object]]) -> Dict[str, ResultColumn]:
+        """Host batch in, host batch out (the drop-in seam, PCIe crossing included)."""
+        hb = batch if isinstance(batch, HostBatch) else HostBatch(batch)
+        out_a, out_s, err = ArrowArray(), ArrowSchema(), ctypes.c_void_p()
+        rc = self._lib.ssa_program_apply(self._h, ctypes.byref(hb.array), ctypes.byref(hb.schema), ctypes.byref(out_a),
+                                         ctypes.byref(out_s), ctypes.byref(err))
+        self._check(rc, err)
+        return read_batch(out_a, out_s)
+
+    def BuildFilter(self, batch: Union[HostBatch, Dict[str, object]], step: int = 0) -> Tuple[np.ndarray, int]:
+        """TProgramStep::BuildFilter: boolean mask of the rows that pass the step's filters."""
+        hb = batch if isinstance(batch, HostBatch) else HostBatch(batch)
+        bits = np.zeros((hb.rows + 7) // 8 + 8, dtype=np.uint8)
+        selected = ctypes.c_int64(0)
+        err = ctypes.c_void_p()
+        rc = self._lib.ssa_program_build_filter(self._h, step, ctypes.byref(hb.array), ctypes.byref(hb.schema),
+                                                bits.ctypes.data, ctypes.byref(selected), ctypes.byref(err))
+        self._check(rc, err)
+        mask = np.unpackbits(bits, bitorder="little")[:hb.rows].astype(np.bool_)
+        return mask, selected.value
+
+    # -- HBM-resident path ----------------------------------------------------------------------------
+    def Import(self, batch: Union[HostBatch, Dict[str, object]]) -> DeviceBatch:
+        hb = batch if isinstance(batch, HostBatch) else HostBatch(batch)
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = self._lib.ssa_batch_import(self._h, ctypes.byref(hb.array), ctypes.byref(hb.schema), ctypes.byref(out),
+                                        ctypes.byref(err))
+        self._check(rc, err)
+        return DeviceBatch(self._lib, out.value)
+
+    def ApplyDevice(self, batch: DeviceBatch) -> DeviceBatch:
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = self._lib.ssa_program_apply_device(self._h, batch._h, ctypes.byref(out), ctypes.byref(err))
+        self._check(rc, err)
+        return DeviceBatch(self._lib, out.value)
+
+    def Export(self, batch: DeviceBatch) -> Dict[str, ResultColumn]:
+        out_a, out_s, err = ArrowArray(), ArrowSchema(), ctypes.c_void_p()
+        rc = self._lib.ssa_batch_export(self._h, batch._h, ctypes.byref(out_a), ctypes.byref(out_s), ctypes.byref(err))
+        self._check(rc, err)
+        return read_batch(out_a, out_s)
+
+    def EnableProfile(self, enabled: bool = True):
+        self._lib.ssa_profile_enable(self._h, 1 if enabled else 0)
+
+    def ReadProfile(self) -> Tuple[float, int, int]:
+        ms, n, b = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._lib.ssa_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b))
+        return ms.value, n.value, b.value
+
+    def close(self):
+        if self._h:
+            self._lib.ssa_program_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_batch(columns: Sequence[Tuple[str, int, int, int, int, int, int]], rows: int, keep=None) -> DeviceBatch:
+    """Wraps device pointers: (name, ssa_type, values_ptr, validity_ptr, chars_ptr, chars_size, null_count)."""
+    lib = _lib.load()
+    arr = (_lib.DeviceColumn * len(columns))()
+    names = []
+    for i, (name, typ, values, validity, chars, chars_size, null_count) in enumerate(columns):
+        nb = name.encode()
+        names.append(nb)
+        arr[i].name = nb
+        arr[i].type = typ
+        arr[i].values = values
+        arr[i].validity = validity or None
+        arr[i].chars = chars or None
+        arr[i].chars_size = chars_size
+        arr[i].null_count = null_count
+    out, err = ctypes.c_void_p(), ctypes.c_void_p()
+    rc = lib.ssa_batch_from_device(arr, len(columns), rows, ctypes.byref(out), ctypes.byref(err))
+    msg = _lib.take_string(lib, err.value)
+    if rc != _lib.SSA_OK:
+        raise SsaError(rc, msg)
+    return DeviceBatch(lib, out.value, keep=(keep, names))
