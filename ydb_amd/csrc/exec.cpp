@@ -561,6 +561,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     args.nconsts = int32_t(plan.Consts.size());
     args.nullable = plan.Nullable;
     args.status = static_cast<uint32_t*>(StatusWord->Ptr);
+    if (const char* dbg = std::getenv("SSA_DEBUG_FLAGS")) args.debug_flags = std::atoi(dbg);
     algoBytes = 0;
     int lds = 0;
     for (int c = 0; c < args.ncols; ++c) {
@@ -604,7 +605,8 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     if (lds > kLdsPerCU - 1024) return Status::Unsupported("step needs more LDS than one CU has");
 
     const int64_t ntiles = (in.Rows + kTileRows - 1) / kTileRows;
-    int perCU = lds > 0 ? (kLdsPerCU - 2048) / lds : 8;
+    int perCU = lds > 0 ? (kLdsPerCU - 8192) / lds : 8;
+    if (const char* pc = std::getenv("SSA_BLOCKS_PER_CU")) perCU = std::atoi(pc);
     perCU = std::max(1, std::min(perCU, 8));
     int64_t grid = std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU);
     cfg.grid = int(grid);
@@ -768,8 +770,8 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
     ScanArgs args;
     LaunchCfg cfg;
     int64_t algoBytes;
-    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, 0, args, cfg, algoBytes));
     const int naggs = int(plan.Aggs.size());
+    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, naggs * kBlock * 8, args, cfg, algoBytes));
     BufferPtr partial = Buffer::Alloc(size_t(cfg.grid) * kMaxAggs * 8);
     BufferPtr seen = Buffer::Alloc(size_t(cfg.grid) * 4);
     BufferPtr outVals = Buffer::Alloc(kMaxAggs * 8 + kMaxAggs);

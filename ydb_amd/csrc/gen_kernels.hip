@@ -21,8 +21,9 @@ __device__ __forceinline__ uint64_t SplitMix64(uint64_t x) {
     return z ^ (z >> 31);
 }
 
-__device__ __forceinline__ uint64_t Draw(uint64_t seed, uint64_t col, uint64_t row) {
-    return SplitMix64(seed ^ (col << 56) ^ row);
+// Upper 32 bits of the mixed word: every range reduction below is a 32-bit modulo.
+__device__ __forceinline__ uint32_t Draw(uint64_t seed, uint64_t col, uint64_t row) {
+    return uint32_t(SplitMix64(seed ^ (col << 56) ^ row) >> 32);
 }
 
 __global__ __launch_bounds__(kBlock) void GenLineitemKernel(const LineitemColumns c, int64_t row0, int64_t nrows, uint64_t seed) {

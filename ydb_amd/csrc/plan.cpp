@@ -728,20 +728,20 @@ struct Compiler {
                 Expr* col = Strip(e->L.get());
                 int slot = ColSlot(col, st);
                 if (e->Op == OP_STRLEN) {
-                    Emit(MakeInsn(OP_STRLEN, SRC_COL, slot), st);
+                    Emit(MakeInsn(OP_STRLEN, SRC_NONE, slot), st);
                 } else if (e->Op == OP_STRMATCH) {
                     int k = ConstIndex(e->R->Scalar, st);
                     if (!e->R->Scalar.Valid) Plan.Nullable = true;
-                    Emit(MakeInsn(OP_STRMATCH, SRC_COL, slot, k, e->B), st);
+                    Emit(MakeInsn(OP_STRMATCH, SRC_NONE, slot, k, e->B), st);
                 } else {
                     Expr* rhs = Strip(e->R.get());
                     if (rhs->Kind == Expr::CONST) {
                         int k = ConstIndex(rhs->Scalar, st);
                         if (!rhs->Scalar.Valid) Plan.Nullable = true;
-                        Emit(MakeInsn(OP_STRCMP, SRC_COL, slot, k, e->B), st);
+                        Emit(MakeInsn(OP_STRCMP, SRC_NONE, slot, k, e->B), st);
                     } else {
                         int slot2 = ColSlot(rhs, st);
-                        Emit(MakeInsn(OP_STRCMP, SRC_COL, slot, slot2, e->B | 16), st);
+                        Emit(MakeInsn(OP_STRCMP, SRC_NONE, slot, slot2, e->B | 16), st);
                     }
                 }
                 break;
@@ -757,6 +757,26 @@ struct Compiler {
             Emit(MakeInsn(OP_ST, 0, e->Reg), st);
         }
         e->Done = true;
+    }
+
+    // Filter of the form <column> cmp <constant> that nothing else reads: one fused instruction.
+    bool TryPredCmp(Expr* f, Status& st) {
+        f = Strip(f);
+        if (f->Kind != Expr::BINARY || f->Op != OP_CMP || f->Uses != 1 || f->Reg >= 0 || f->Done) return false;
+        Expr* l = Strip(f->L.get());
+        Expr* r = Strip(f->R.get());
+        int cls = f->A, cmp = f->B;
+        if (l->Kind == Expr::CONST && r->Kind == Expr::COL) {
+            std::swap(l, r);
+            int op = ReverseOp(OP_CMP, cls, cmp);
+            (void)op;
+        }
+        if (l->Kind != Expr::COL || IsStringLike(l->Type) || r->Kind != Expr::CONST) return false;
+        const int slot = ColSlot(l, st);
+        const int k = ConstIndex(r->Scalar, st);
+        Emit(MakeInsn(OP_PREDCMP, SRC_COL, slot, k, cmp | (cls << 4)), st);
+        f->Done = true;
+        return true;
     }
 
     // Evaluate `e` and make sure its value sits in output register `reg`.
@@ -1052,6 +1072,7 @@ struct Compiler {
         // code: filters first, then outputs
         if (mode != CM_OUTPUTS_ONLY) {
             for (auto& f : filters) {
+                if (TryPredCmp(f.get(), st)) continue;
                 Gen(f.get(), st);
                 Emit(MakeInsn(OP_PRED), st);
             }

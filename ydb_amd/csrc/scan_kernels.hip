@@ -49,44 +49,45 @@ __device__ __forceinline__ uint64_t AggCombine(int kind, uint64_t a, uint64_t b)
 }
 
 // ---- sink: key-less aggregation ---------------------------------------------------------------------
+// Per-lane accumulators live in the sink area of LDS ([aggregate][lane], 8 bytes each) so that the
+// aggregate loop is an ordinary runtime loop: the U rows of a lane are folded in registers first and
+// merged into the lane's slot once per tile.
 template <int U>
 __global__ __launch_bounds__(kBlock) void ScanNoKeyKernel(const KArgs<NoKeySink>) {
     const ScanArgs& a = KernArgs<NoKeySink>().a;
     const NoKeySink& s = KernArgs<NoKeySink>().s;
     Machine<U> m(a);
-    uint64_t acc[kMaxAggs];
+    uint64_t* acc = reinterpret_cast<uint64_t*>(gLds + a.lds_sink_off);  // [naggs][kBlock]
     uint32_t seen = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxAggs; ++k) acc[k] = (k < s.naggs) ? AggIdentity(s.aggs[k].kind) : 0;
+    for (int k = 0; k < s.naggs; ++k) acc[k * kBlock + threadIdx.x] = AggIdentity(s.aggs[k].kind);
 
-    const int64_t ntiles = (a.nrows + kBlock * U - 1) / (kBlock * U);
+    const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         m.BeginTile(tile * (kBlock * U));
         m.Run();
         if (m.P == 0) continue;
+        for (int k = 0; k < s.naggs; ++k) {
+            const AggSpec spec = s.aggs[k];
+            uint32_t live = m.P;
+            Val<U> x;
+            if (spec.reg != -1) {
+                m.FetchOperand(spec.reg, x);
+                if (spec.check_valid) live &= x.ok;
+            }
+            if (live == 0) continue;
+            seen |= 1u << k;
+            uint64_t v;
+            if (spec.kind == AGG_COUNT) {
+                v = __popc(live);
+            } else {
+                v = AggIdentity(spec.kind);
 #pragma unroll
-        for (int k = 0; k < kMaxAggs; ++k) {
-            if (k < s.naggs) {
-                const AggSpec spec = s.aggs[k];
-                uint32_t live = m.P;
-                Val<U> x;
-                if (spec.reg != -1) {
-                    m.FetchOperand(spec.reg, x);
-                    if (spec.check_valid) live &= x.ok;
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) x.v[u] = 0;
-                }
-                if (live) seen |= 1u << k;
-                if (spec.kind == AGG_COUNT) {
-                    acc[k] += __popc(live);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if ((live >> u) & 1u) acc[k] = AggCombine(spec.kind, acc[k], x.v[u]);
-                    }
+                for (int u = 0; u < U; ++u) {
+                    if ((live >> u) & 1u) v = AggCombine(spec.kind, v, x.v[u]);
                 }
             }
+            uint64_t* slot = acc + k * kBlock + threadIdx.x;
+            *slot = AggCombine(spec.kind, *slot, v);
         }
     }
     m.ReportErrors();
@@ -94,15 +95,12 @@ __global__ __launch_bounds__(kBlock) void ScanNoKeyKernel(const KArgs<NoKeySink>
     // workgroup reduction: wave butterflies, then the 4 wave results through LDS
     __shared__ uint64_t lds[kWaves][kMaxAggs];
     __shared__ uint32_t ldsSeen[kWaves];
+    for (int k = 0; k < s.naggs; ++k) {
+        const int kind = s.aggs[k].kind;
+        uint64_t v = acc[k * kBlock + threadIdx.x];
 #pragma unroll
-    for (int k = 0; k < kMaxAggs; ++k) {
-        if (k < s.naggs) {
-            const int kind = s.aggs[k].kind;
-            uint64_t v = acc[k];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v = AggCombine(kind, v, ShflXor64(v, off));
-            if (LaneId() == 0) lds[WaveId()][k] = v;
-        }
+        for (int off = 32; off >= 1; off >>= 1) v = AggCombine(kind, v, ShflXor64(v, off));
+        if (LaneId() == 0) lds[WaveId()][k] = v;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) seen |= __shfl_xor(seen, off, 64);
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void ScanFilterKernel(const KArgs<FilterSin
     const FilterSink& s = KernArgs<FilterSink>().s;
     Machine<U> m(a);
     __shared__ uint32_t ldsCount[kWaves];
-    const int64_t ntiles = (a.nrows + kBlock * U - 1) / (kBlock * U);
+    const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t tileBase = tile * (kBlock * U);
         m.BeginTile(tileBase);
@@ -208,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void ScanProjectKernel(const KArgs<ProjectS
     const ScanArgs& a = KernArgs<ProjectSink>().a;
     const ProjectSink& s = KernArgs<ProjectSink>().s;
     Machine<U> m(a);
-    const int64_t ntiles = (a.nrows + kBlock * U - 1) / (kBlock * U);
+    const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     const int64_t nwords = (a.nrows + 63) >> 6;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t tileBase = tile * (kBlock * U);
@@ -235,19 +233,16 @@ __global__ __launch_bounds__(kBlock) void ScanProjectKernel(const KArgs<ProjectS
             for (int u = 0; u < U; ++u) pos[u] = m.Row(u);
         }
         m.Run();
+        for (int k = 0; k < s.nouts; ++k) {
+            const ProjectOut o = s.outs[k];
+            Val<U> x;
+            m.FetchOperand(o.reg, x);
+            const int w = (o.type == T_BOOL) ? 1 : TypeWidth(o.type);
 #pragma unroll
-        for (int k = 0; k < kMaxOuts; ++k) {
-            if (k < s.nouts) {
-                const ProjectOut o = s.outs[k];
-                Val<U> x;
-                m.FetchOperand(o.reg, x);
-                const int w = (o.type == T_BOOL) ? 1 : TypeWidth(o.type);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if ((sel >> u) & 1u) {
-                        StoreTyped(o.values, w, pos[u], PayloadToStored(x.v[u], o.type));
-                        if (o.valid_bytes != nullptr) o.valid_bytes[pos[u]] = uint8_t((x.ok >> u) & 1u);
-                    }
+            for (int u = 0; u < U; ++u) {
+                if ((sel >> u) & 1u) {
+                    StoreTyped(o.values, w, pos[u], PayloadToStored(x.v[u], o.type));
+                    if (o.valid_bytes != nullptr) o.valid_bytes[pos[u]] = uint8_t((x.ok >> u) & 1u);
                 }
             }
         }

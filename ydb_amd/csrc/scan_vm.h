@@ -87,10 +87,91 @@ __device__ __forceinline__ uint64_t LdsLoadRaw(const unsigned char* base, int wi
     }
 }
 
+// Rarely executed, code-heavy helpers are kept out of line so the interpreter loop stays small enough
+// for the instruction cache (a 64-bit integer division alone expands to a few hundred instructions).
+__device__ __noinline__ ArithResult ArithDivOutlined(bool mod, int cls, int dialect, int rtype, uint64_t x, uint64_t y) {
+    return ArithDiv(mod, cls, dialect, rtype, x, y);
+}
+__device__ __noinline__ bool StrMatchOutlined(int kind, bool icase, const uint8_t* s, int32_t n, const uint8_t* p, int32_t m) {
+    return StrMatch(kind, icase, s, n, p, m);
+}
+__device__ __noinline__ int StrCompareOutlined(const uint8_t* a, int32_t n, const uint8_t* b, int32_t m) {
+    return StrCompare(a, n, b, m);
+}
+__device__ __noinline__ uint64_t CastValOutlined(uint64_t v, int from, int to) { return CastVal(v, from, to); }
+__device__ __noinline__ bool FitsTypeOutlined(uint64_t v, int from, int to) { return FitsType(v, from, to); }
+
+// lt / eq / unordered bit masks of U element pairs for one value class.
+template <int U>
+__device__ __forceinline__ void CompareMasks(int cls, const uint64_t* x, const uint64_t* y, uint32_t& lt, uint32_t& eq,
+                                             uint32_t& un) {
+    lt = eq = un = 0;
+    switch (cls) {
+        case CLS_I:
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                lt |= (int64_t(x[u]) < int64_t(y[u]) ? 1u : 0u) << u;
+                eq |= (x[u] == y[u] ? 1u : 0u) << u;
+            }
+            break;
+        case CLS_U:
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                lt |= (x[u] < y[u] ? 1u : 0u) << u;
+                eq |= (x[u] == y[u] ? 1u : 0u) << u;
+            }
+            break;
+        case CLS_IU:
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool neg = int64_t(x[u]) < 0;
+                lt |= ((neg || x[u] < y[u]) ? 1u : 0u) << u;
+                eq |= ((!neg && x[u] == y[u]) ? 1u : 0u) << u;
+            }
+            break;
+        case CLS_UI:
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool neg = int64_t(y[u]) < 0;
+                lt |= ((!neg && x[u] < y[u]) ? 1u : 0u) << u;
+                eq |= ((!neg && x[u] == y[u]) ? 1u : 0u) << u;
+            }
+            break;
+        default:
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double p = BitsToF64(x[u]), q = BitsToF64(y[u]);
+                lt |= (p < q ? 1u : 0u) << u;
+                eq |= (p == q ? 1u : 0u) << u;
+                un |= ((p != p || q != q) ? 1u : 0u) << u;
+            }
+            break;
+    }
+}
+
+__device__ __forceinline__ uint32_t CompareResult(int cmp, uint32_t lt, uint32_t eq, uint32_t un) {
+    switch (cmp) {
+        case CMP_EQ: return eq;
+        case CMP_NE: return ~eq;
+        case CMP_LT: return lt;
+        case CMP_LE: return lt | eq;
+        case CMP_GT: return ~(un | lt | eq);
+        default: return ~(un | lt);
+    }
+}
+
+__device__ __forceinline__ uint32_t ReadLane32(uint32_t v, int lane) {
+    return uint32_t(__builtin_amdgcn_readlane(int(v), lane));
+}
+__device__ __forceinline__ uint64_t ReadLane64(uint64_t v, int lane) {
+    const uint32_t lo = ReadLane32(uint32_t(v), lane), hi = ReadLane32(uint32_t(v >> 32), lane);
+    return (uint64_t(hi) << 32) | lo;
+}
+
 template <int U>
 struct Machine {
     static constexpr int kTile = kBlock * U;
-    const ScanArgs& a;   // lives in the kernel-argument segment: uniform scalar loads
+    const ScanArgs& a;   // kernel-argument segment (read once at kernel start)
     int64_t row0;        // row of u = 0 for this lane
     uint32_t act;        // bit u: row0 + u * kBlock < nrows
     uint32_t P;          // bit u: row passes every Filter so far
@@ -98,66 +179,126 @@ struct Machine {
     bool staged;         // the current tile's columns sit in LDS (full tiles only)
     Val<U> A;
 
-    __device__ __forceinline__ explicit Machine(const ScanArgs& args) : a(args), err(0), staged(false) {}
+    // The step program, spread over the lanes of each wave: lane i holds instruction i, the
+    // description of column slot i, constant i and staging piece i.  Decode is a v_readlane with a
+    // wave-uniform index -- no memory access, no latency -- instead of dependent scalar loads.
+    uint32_t tCode0, tCode1;                 // instructions [lane], [64 + lane]
+    uint32_t tColOff, tColType, tColW;       // column slot (lane & 15): LDS offset (or -1), TypeId, width
+    uint32_t tColValBit, tColValidBit;
+    uint64_t tColVal, tColValid, tColChars;
+    uint64_t tConstBits;                     // constant (lane)
+    uint32_t tConstValid;
+    uint64_t tPieceSrc;                      // staging piece (lane): column base + piece offset
+    uint32_t tPieceLds, tPieceW;
+    int nPieces;
+    int64_t nrows;
+    int ncode;
+
+    __device__ __forceinline__ explicit Machine(const ScanArgs& args) : a(args), err(0), staged(false) {
+        const int lane = threadIdx.x & 63;
+        nrows = a.nrows;
+        ncode = a.ncode;
+        tCode0 = lane < ncode ? a.code[lane] : 0u;
+        tCode1 = (64 + lane) < ncode ? a.code[64 + lane] : 0u;
+        const int c = lane & (kMaxCols - 1);
+        tColOff = uint32_t(a.lds_col_off[c]);
+        tColType = uint32_t(a.cols[c].type);
+        tColW = uint32_t(TypeWidth(a.cols[c].type));
+        tColValBit = uint32_t(a.cols[c].val_bit_off);
+        tColValidBit = uint32_t(a.cols[c].valid_bit_off);
+        tColVal = reinterpret_cast<uint64_t>(a.cols[c].values);
+        tColValid = reinterpret_cast<uint64_t>(a.cols[c].validity);
+        tColChars = reinterpret_cast<uint64_t>(a.cols[c].chars);
+        const int k = lane < kMaxConsts ? lane : 0;
+        tConstBits = a.consts[k].bits;
+        tConstValid = uint32_t(a.consts[k].valid);
+        // staging pieces: one wave-instruction (64 lanes x 16 bytes = 1 KiB) each
+        tPieceSrc = 0;
+        tPieceLds = 0;
+        tPieceW = 0;
+        int acc = 0;
+        for (int col = 0; col < a.ncols; ++col) {
+            const int off = a.lds_col_off[col];
+            if (off < 0) continue;
+            const int w = TypeWidth(a.cols[col].type);
+            const int np = (kTile * w) >> 10;
+            if (lane >= acc && lane < acc + np) {
+                tPieceSrc = reinterpret_cast<uint64_t>(a.cols[col].values) + uint64_t(lane - acc) * 1024u;
+                tPieceLds = uint32_t(off + (lane - acc) * 1024);
+                tPieceW = uint32_t(w);
+            }
+            acc += np;
+        }
+        nPieces = acc;
+    }
 
     __device__ __forceinline__ int64_t Row(int u) const { return row0 + int64_t(u) * kBlock; }
 
+    __device__ __forceinline__ uint32_t Insn(int pc) const {
+        return pc < 64 ? ReadLane32(tCode0, pc) : ReadLane32(tCode1, pc - 64);
+    }
+
     // Stage the tile's fixed-width source columns into LDS with direct global->LDS loads
     // (global_load_lds_dwordx4: one wave-instruction moves 1 KiB, no VGPRs are involved), then
-    // make them visible to the workgroup.  Callers must have passed a barrier since the last
-    // read of the previous tile.  Partial tiles are read from global memory on demand instead.
+    // make them visible to the workgroup.  Partial tiles are read from global memory on demand instead.
     __device__ __forceinline__ void BeginTile(int64_t tileBase) {
         row0 = tileBase + threadIdx.x;
         act = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) act |= (Row(u) < a.nrows ? 1u : 0u) << u;
-        staged = (tileBase + kTile <= a.nrows);
+        for (int u = 0; u < U; ++u) act |= (Row(u) < nrows ? 1u : 0u) << u;
+        staged = (tileBase + kTile <= nrows);
         __syncthreads();  // every wave is done reading the previous tile
-        if (staged) {
+        if (staged && !(a.debug_flags & 1)) {
             const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
             const int lane = threadIdx.x & 63;
-            int piece = 0;
-            for (int c = 0; c < a.ncols; ++c) {
-                const int off = a.lds_col_off[c];
-                if (off < 0) continue;
-                const int w = TypeWidth(a.cols[c].type);
-                const unsigned char* src = static_cast<const unsigned char*>(a.cols[c].values) + tileBase * w;
-                const int npieces = (kTile * w) >> 10;
-                for (int p = 0; p < npieces; ++p, ++piece) {
-                    if ((piece & (kBlock / 64 - 1)) == wave) {
-                        __builtin_amdgcn_global_load_lds((GlobalPtr)(src + p * 1024 + lane * 16),
-                                                         (LdsPtr)(gLds + off + p * 1024), 16, 0, 0);
-                    }
-                }
+            for (int p = wave; p < nPieces; p += kBlock / 64) {
+                const uint64_t src = ReadLane64(tPieceSrc, p);
+                const uint32_t ldsOff = ReadLane32(tPieceLds, p);
+                const uint32_t w = ReadLane32(tPieceW, p);
+                const unsigned char* g = reinterpret_cast<const unsigned char*>(src) + tileBase * w + lane * 16;
+                __builtin_amdgcn_global_load_lds((GlobalPtr)g, (LdsPtr)(gLds + ldsOff), 16, 0, 0);
             }
         }
         __syncthreads();  // waits for the LDS-DMA (vmcnt(0)) before the barrier
     }
 
+    __device__ __forceinline__ uint32_t ValidityOf(int c) const {
+        const uint8_t* validity = reinterpret_cast<const uint8_t*>(ReadLane64(tColValid, c));
+        if (validity == nullptr) return AllMask<U>();
+        const int64_t bitOff = int64_t(ReadLane32(tColValidBit, c));
+        uint32_t ok = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((act >> u) & 1u) ok |= LoadBit(validity, Row(u) + bitOff) << u;
+        }
+        return ok;
+    }
+
     __device__ __forceinline__ void FetchCol(int c, Val<U>& out) {
-        const DevColumn& col = a.cols[c];
-        const int type = col.type;
-        const int w = TypeWidth(type);
+        const int type = int(ReadLane32(tColType, c));
+        const int w = int(ReadLane32(tColW, c));
         if (w > 0 && w <= 8) {
-            const int off = a.lds_col_off[c];
+            const int off = int(ReadLane32(tColOff, c));
             if (staged && off >= 0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) out.v[u] = LdsLoadRaw(gLds + off, w, u * kBlock + int(threadIdx.x));
             } else {
+                const void* values = reinterpret_cast<const void*>(ReadLane64(tColVal, c));
 #pragma unroll
-                for (int u = 0; u < U; ++u) out.v[u] = ((act >> u) & 1u) ? LoadRaw(col.values, w, Row(u)) : 0;
+                for (int u = 0; u < U; ++u) out.v[u] = ((act >> u) & 1u) ? LoadRaw(values, w, Row(u)) : 0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) out.v[u] = ConvertRaw(out.v[u], type);
         } else if (type == T_BOOL) {
-            const uint8_t* bits = static_cast<const uint8_t*>(col.values);
+            const uint8_t* bits = reinterpret_cast<const uint8_t*>(ReadLane64(tColVal, c));
+            const int64_t bitOff = int64_t(ReadLane32(tColValBit, c));
 #pragma unroll
-            for (int u = 0; u < U; ++u) out.v[u] = ((act >> u) & 1u) ? LoadBit(bits, Row(u) + col.val_bit_off) : 0;
+            for (int u = 0; u < U; ++u) out.v[u] = ((act >> u) & 1u) ? LoadBit(bits, Row(u) + bitOff) : 0;
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) out.v[u] = 0;  // strings / wide values carry only validity here
         }
-        out.ok = ColValidity(col);
+        out.ok = ValidityOf(c);
     }
 
     // R registers live in LDS: lane t owns elements [u * kBlock + t] of every register, so no
@@ -177,10 +318,10 @@ struct Machine {
     }
 
     __device__ __forceinline__ void FetchConst(int k, Val<U>& out) {
-        const uint64_t bits = a.consts[k].bits;
+        const uint64_t bits = ReadLane64(tConstBits, k);
 #pragma unroll
         for (int u = 0; u < U; ++u) out.v[u] = bits;
-        out.ok = a.consts[k].valid ? AllMask<U>() : 0u;
+        out.ok = ReadLane32(tConstValid, k) ? AllMask<U>() : 0u;
     }
 
     __device__ __forceinline__ void Fetch(int sk, int si, Val<U>& out) {
@@ -202,21 +343,12 @@ struct Machine {
         }
     }
 
-    __device__ __forceinline__ void StringAt(const DevColumn& col, int64_t row, const uint8_t*& p, int32_t& n) const {
-        const int32_t* offs = static_cast<const int32_t*>(col.values);
+    __device__ __forceinline__ void StringAt(int c, int64_t row, const uint8_t*& p, int32_t& n) const {
+        const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, c));
+        const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
         const int32_t b = offs[row], e = offs[row + 1];
-        p = col.chars + b;
+        p = chars + b;
         n = e - b;
-    }
-
-    __device__ __forceinline__ uint32_t ColValidity(const DevColumn& col) const {
-        if (col.validity == nullptr) return AllMask<U>();
-        uint32_t ok = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if ((act >> u) & 1u) ok |= LoadBit(col.validity, Row(u) + col.valid_bit_off) << u;
-        }
-        return ok;
     }
 
     // Runs the step program for the current tile.  Leaves outputs in R[] and the row predicate in P.
@@ -226,34 +358,49 @@ struct Machine {
 #pragma unroll
         for (int u = 0; u < U; ++u) A.v[u] = 0;
 
-        for (int pc = 0; pc < a.ncode; ++pc) {
-            const uint32_t ins = a.code[pc];
+        const int ncodeEff = (a.debug_flags & 2) ? 0 : ncode;
+        for (int pc = 0; pc < ncodeEff; ++pc) {
+            const uint32_t ins = Insn(pc);
             const int op = InsnOp(ins);
             if (op == OP_END) break;
             const int sk = InsnSk(ins), si = InsnSi(ins), fa = InsnA(ins), fb = InsnB(ins);
+            // The one operand fetch of the instruction (kept out of the switch so that the fetch code,
+            // with its width / type dispatch, exists once in the kernel).
+            Val<U> B;
+            if (sk != SRC_NONE) Fetch(sk, si, B);
             switch (op) {
                 case OP_LD:
-                    Fetch(sk, si, A);
+                    A = B;
                     break;
                 case OP_ST:
                     StoreReg(si, A);
                     break;
                 case OP_ADD: case OP_SUB: case OP_RSUB: case OP_MUL: {
-                    Val<U> B;
-                    Fetch(sk, si, B);
-                    const int bop = (op == OP_RSUB) ? OP_SUB : op;
+                    if (fa == CLS_F64) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint64_t x = (op == OP_RSUB) ? B.v[u] : A.v[u];
-                        const uint64_t y = (op == OP_RSUB) ? A.v[u] : B.v[u];
-                        A.v[u] = ArithBasic(bop, fa, x, y);
+                        for (int u = 0; u < U; ++u) {
+                            const double x = BitsToF64(A.v[u]), y = BitsToF64(B.v[u]);
+                            const double r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
+                            A.v[u] = F64ToBits(r);
+                        }
+                    } else if (fa == CLS_F32) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const float x = float(BitsToF64(A.v[u])), y = float(BitsToF64(B.v[u]));
+                            const float r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
+                            A.v[u] = F64ToBits(double(r));
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint64_t x = A.v[u], y = B.v[u];
+                            A.v[u] = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
+                        }
                     }
                     A.ok &= B.ok;
                     break;
                 }
                 case OP_DIV: case OP_RDIV: case OP_MOD: case OP_RMOD: {
-                    Val<U> B;
-                    Fetch(sk, si, B);
                     const bool rev = (op == OP_RDIV || op == OP_RMOD);
                     const bool mod = (op == OP_MOD || op == OP_RMOD);
                     const int dialect = fb & 1, rtype = fb >> 1;
@@ -266,7 +413,7 @@ struct Machine {
                         if (dialect == DIALECT_ARROW && !live) {
                             A.v[u] = 0;  // the not-null kernel variant leaves 0 under a null slot and never divides there
                         } else {
-                            ArithResult r = ArithDiv(mod, fa, dialect, rtype, x, y);
+                            ArithResult r = ArithDivOutlined(mod, fa, dialect, rtype, x, y);
                             A.v[u] = r.v;
                             if (r.null) ok &= ~(1u << u);
                             if (r.error && ((act >> u) & 1u)) err |= SCAN_DIV_BY_ZERO;
@@ -276,16 +423,26 @@ struct Machine {
                     break;
                 }
                 case OP_CMP: {
-                    Val<U> B;
-                    Fetch(sk, si, B);
+                    uint32_t lt, eq, un;
+                    CompareMasks<U>(fa, A.v, B.v, lt, eq, un);
+                    const uint32_t r = CompareResult(fb, lt, eq, un);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = CompareVals(fb, fa, A.v[u], B.v[u]) ? 1 : 0;
+                    for (int u = 0; u < U; ++u) A.v[u] = (r >> u) & 1u;
                     A.ok &= B.ok;
                     break;
                 }
+                case OP_PREDCMP: {
+                    // fused "column <cmp> constant, AND into the row predicate": B = column si, constant fa
+                    uint64_t c[U];
+                    const uint64_t cbits = ReadLane64(tConstBits, fa);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) c[u] = cbits;
+                    uint32_t lt, eq, un;
+                    CompareMasks<U>(fb >> 4, B.v, c, lt, eq, un);
+                    P &= CompareResult(fb & 15, lt, eq, un);
+                    break;
+                }
                 case OP_AND: case OP_OR: case OP_XOR: {
-                    Val<U> B;
-                    Fetch(sk, si, B);
                     uint32_t av = 0, bv = 0;
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -330,19 +487,17 @@ struct Machine {
                     break;
                 case OP_CAST:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = CastVal(A.v[u], fa, fb);
+                    for (int u = 0; u < U; ++u) A.v[u] = CastValOutlined(A.v[u], fa, fb);
                     break;
                 case OP_CHECK:
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (((act & A.ok) >> u) & 1u) {
-                            if (!FitsType(A.v[u], fa, fb)) err |= SCAN_CAST_OVERFLOW;
+                            if (!FitsTypeOutlined(A.v[u], fa, fb)) err |= SCAN_CAST_OVERFLOW;
                         }
                     }
                     break;
                 case OP_COALESCE: {
-                    Val<U> B;
-                    Fetch(sk, si, B);
 #pragma unroll
                     for (int u = 0; u < U; ++u) A.v[u] = ((A.ok >> u) & 1u) ? A.v[u] : B.v[u];
                     A.ok |= B.ok;
@@ -353,9 +508,8 @@ struct Machine {
                     for (int u = 0; u < U; ++u) A.v[u] = uint64_t(Row(u));
                     break;
                 case OP_STRLEN: {
-                    const DevColumn& col = a.cols[si];
-                    A.ok = ColValidity(col);
-                    const int32_t* offs = static_cast<const int32_t*>(col.values);
+                    A.ok = ValidityOf(si);
+                    const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, si));
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         uint64_t len = 0;
@@ -365,37 +519,35 @@ struct Machine {
                     break;
                 }
                 case OP_STRMATCH: {
-                    const DevColumn& col = a.cols[si];
-                    const uint64_t pat = a.consts[fa].bits;
+                    const uint64_t pat = ReadLane64(tConstBits, fa);
                     const uint8_t* pp = a.pattern + uint32_t(pat >> 32);
                     const int32_t pn = int32_t(uint32_t(pat));
-                    A.ok = ColValidity(col) & (a.consts[fa].valid ? AllMask<U>() : 0u);
+                    A.ok = ValidityOf(si) & (ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u);
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         uint64_t m = 0;
                         if ((act >> u) & 1u) {
                             const uint8_t* s;
                             int32_t n;
-                            StringAt(col, Row(u), s, n);
-                            m = StrMatch(fb & 15, (fb & 16) != 0, s, n, pp, pn) ? 1 : 0;
+                            StringAt(si, Row(u), s, n);
+                            m = StrMatchOutlined(fb & 15, (fb & 16) != 0, s, n, pp, pn) ? 1 : 0;
                         }
                         A.v[u] = m;
                     }
                     break;
                 }
                 case OP_STRCMP: {
-                    const DevColumn& col = a.cols[si];
-                    uint32_t ok = ColValidity(col);
+                    uint32_t ok = ValidityOf(si);
                     const bool rhsCol = (fb & 16) != 0;
                     const uint8_t* pp = nullptr;
                     int32_t pn = 0;
                     if (!rhsCol) {
-                        const uint64_t pat = a.consts[fa].bits;
+                        const uint64_t pat = ReadLane64(tConstBits, fa);
                         pp = a.pattern + uint32_t(pat >> 32);
                         pn = int32_t(uint32_t(pat));
-                        ok &= a.consts[fa].valid ? AllMask<U>() : 0u;
+                        ok &= ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u;
                     } else {
-                        ok &= ColValidity(a.cols[fa]);
+                        ok &= ValidityOf(fa);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -403,9 +555,9 @@ struct Machine {
                         if ((act >> u) & 1u) {
                             const uint8_t* s;
                             int32_t n;
-                            StringAt(col, Row(u), s, n);
-                            if (rhsCol) StringAt(a.cols[fa], Row(u), pp, pn);
-                            m = CmpFromOrder(fb & 15, StrCompare(s, n, pp, pn)) ? 1 : 0;
+                            StringAt(si, Row(u), s, n);
+                            if (rhsCol) StringAt(fa, Row(u), pp, pn);
+                            m = CmpFromOrder(fb & 15, StrCompareOutlined(s, n, pp, pn)) ? 1 : 0;
                         }
                         A.v[u] = m;
                     }

@@ -111,11 +111,12 @@ enum OpCode : int32_t {
     OP_CAST,      // a = source class, b = target TypeId (C++ static_cast semantics)
     OP_CHECK,     // a = source class, b = target TypeId: flag an error if the value does not fit (safe implicit cast)
     OP_COALESCE,  // A = A.valid ? A : B
-    OP_STRLEN,    // A = byte length of string column si
+    OP_STRLEN,    // A = byte length of string column si (sk = SRC_NONE: the column values are not fetched)
     OP_STRMATCH,  // A = match(string column si, pattern const a); b = StrMatchKind | (ignore_case << 4)
     OP_STRCMP,    // A = string column si  cmp  (const a | column a); b = CmpOp | (rhs_is_column << 4)
     OP_PRED,      // P &= (A != 0)   -- value bit only, validity ignored (reference: program.cpp:517-527)
     OP_ROWIDX,    // A.value = global row index; A's validity is kept
+    OP_PREDCMP,   // P &= (column si  cmp  constant a); b = CmpOp | (class << 4).  Fusion of LD col; CMP const; PRED
 };
 
 SSA_HD uint32_t MakeInsn(int op, int sk = 0, int si = 0, int a = 0, int b = 0) {
@@ -210,6 +211,7 @@ struct ScanArgs {
     int32_t lds_regok_off;          // R register validity: nregs x lanes bytes
     int32_t nregs;
     int32_t lds_sink_off;           // first byte available to the sink (group-by table)
+    int32_t debug_flags;            // diagnostics only: 1 = skip staging, 2 = skip evaluation (timing experiments)
 };
 
 }  // namespace ssa
