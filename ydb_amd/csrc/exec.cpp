@@ -552,6 +552,37 @@ constexpr int kLdsPerCU = 160 * 1024;
 constexpr int kLdsStageBudget = 64 * 1024;  // staged column tiles per workgroup (keeps >= 2 workgroups per CU)
 }  // namespace
 
+// (FetchKind, payload) for an operand given as an R register (>= 0) or a column slot (<= -2).
+void EncodeOperand(const ScanArgs& args, int reg, uint32_t& fk, uint32_t& payload) {
+    if (reg >= 0) {
+        fk = FK_REG;
+        payload = uint32_t(reg);
+        return;
+    }
+    const int c = -2 - reg;
+    const DevColumn& col = args.cols[c];
+    const int off = args.lds_col_off[c];
+    fk = FK_SLOW;
+    payload = uint32_t(c) << 24;
+    if (off >= 0) {
+        switch (col.type) {
+            case T_I64: case T_U64: case T_F64: case T_TS: case T_DUR: fk = FK_LDS_64; break;
+            case T_I32: fk = FK_LDS_I32; break;
+            case T_U32: fk = FK_LDS_U32; break;
+            case T_I16: fk = FK_LDS_I16; break;
+            case T_U16: fk = FK_LDS_U16; break;
+            case T_I8: fk = FK_LDS_I8; break;
+            case T_U8: fk = FK_LDS_U8; break;
+            case T_F32: fk = FK_LDS_F32; break;
+            default: break;
+        }
+        if (fk != FK_SLOW) {
+            payload |= uint32_t(off);
+            if (col.validity) fk |= FK_HAS_VALIDITY;
+        }
+    }
+}
+
 Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, ScanArgs& args, LaunchCfg& cfg,
                               int64_t& algoBytes) {
     std::memset(&args, 0, sizeof(args));
@@ -591,8 +622,33 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
         }
         if (d.validity) algoBytes += (in.Rows + 7) / 8;
     }
-    for (size_t i = 0; i < plan.Code.size(); ++i) args.code[i] = plan.Code[i];
     for (size_t i = 0; i < plan.Consts.size(); ++i) args.consts[i] = plan.Consts[i];
+    if (plan.Code.size() > size_t(kMaxCode)) return Status::Unsupported("step too long for one scan program");
+    for (size_t i = 0; i < plan.Code.size(); ++i) {
+        const uint32_t ins = plan.Code[i];
+        const int op = InsnOp(ins), sk = InsnSk(ins), si = InsnSi(ins), fa = InsnA(ins), fb = InsnB(ins);
+        uint32_t fk = FK_NONE, payload = 0;
+        if (sk == SRC_COL) EncodeOperand(args, -2 - si, fk, payload);
+        else if (sk == SRC_REG) EncodeOperand(args, si, fk, payload);
+        else if (sk == SRC_CONST) { fk = FK_CONST; payload = uint32_t(si); }
+        uint32_t ok = OK_GENERIC, a8 = uint32_t(fa), b8 = uint32_t(fb);
+        switch (op) {
+            case OP_LD: ok = OK_LD; break;
+            case OP_ST: ok = OK_ST; payload = uint32_t(si); break;
+            case OP_PRED: ok = OK_PRED; break;
+            case OP_PREDCMP: ok = OK_PREDCMP; b8 = CmpMaskOf(fb & 15) | (uint32_t(fb >> 4) << 4); break;
+            case OP_CMP: ok = OK_CMP; b8 = CmpMaskOf(fb); break;
+            case OP_ADD: ok = fa == CLS_F64 ? OK_ADD_F64 : (fa == CLS_I || fa == CLS_U) ? OK_ADD_I : OK_GENERIC; break;
+            case OP_SUB: ok = fa == CLS_F64 ? OK_SUB_F64 : (fa == CLS_I || fa == CLS_U) ? OK_SUB_I : OK_GENERIC; break;
+            case OP_RSUB: ok = fa == CLS_F64 ? OK_RSUB_F64 : OK_GENERIC; break;
+            case OP_MUL: ok = fa == CLS_F64 ? OK_MUL_F64 : (fa == CLS_I || fa == CLS_U) ? OK_MUL_I : OK_GENERIC; break;
+            default: break;
+        }
+        args.code[3 * i] = ok | (fk << 8) | (a8 << 16) | (b8 << 24);
+        args.code[3 * i + 1] = payload;
+        args.code[3 * i + 2] = ins;
+    }
+
     std::memcpy(args.pattern, plan.PatternBytes.data(), plan.PatternBytes.size());
     args.nregs = plan.NumRegsUsed;
     args.lds_reg_off = lds;
@@ -778,7 +834,10 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
     if (!partial || !seen || !outVals) return Status::Hip("out of device memory");
     NoKeySink sink{};
     sink.naggs = naggs;
-    for (int k = 0; k < naggs; ++k) sink.aggs[k] = plan.Aggs[size_t(k)].Spec;
+    for (int k = 0; k < naggs; ++k) {
+        sink.aggs[k] = plan.Aggs[size_t(k)].Spec;
+        if (sink.aggs[k].reg != -1) EncodeOperand(args, sink.aggs[k].reg, sink.aggs[k].fetch_kind, sink.aggs[k].fetch_payload);
+    }
     sink.partial = static_cast<uint64_t*>(partial->Ptr);
     sink.partial_seen = static_cast<uint32_t*>(seen->Ptr);
     ProfileBegin();
@@ -882,6 +941,7 @@ Status Executor::RunProject(const TProgramStep& step, const StepPlan& plan, cons
             sink.outs[k].values = vals->Ptr;
             sink.outs[k].type = oc.Type;
             sink.outs[k].reg = oc.Index;
+            EncodeOperand(args, oc.Index, sink.outs[k].fetch_kind, sink.outs[k].fetch_payload);
             sink.outs[k].valid_bytes = nullptr;
             if (oc.Nullable) {
                 validBytes[k] = Buffer::Alloc(size_t(selected) + 16);

@@ -30,6 +30,8 @@ struct ProjectOut {
     uint8_t* valid_bytes;    // one byte per row, packed afterwards; nullptr when the output cannot be null
     int32_t type;
     int32_t reg;             // >= 0 R register, <= -2 column slot
+    uint32_t fetch_kind;     // pre-decoded operand for `reg`
+    uint32_t fetch_payload;
 };
 
 struct ProjectSink {

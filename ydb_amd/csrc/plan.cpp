@@ -615,7 +615,7 @@ struct Compiler {
     }
 
     void Emit(uint32_t insn, Status& st) {
-        if (Plan.Code.size() >= size_t(kMaxCode) - 1) {
+        if (Plan.Code.size() >= size_t(kMaxCode) - 1) {  // one lane of a wave per instruction
             st = Status::Unsupported("step too long for one scan program");
             return;
         }

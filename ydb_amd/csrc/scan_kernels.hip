@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void ScanNoKeyKernel(const KArgs<NoKeySink>
             uint32_t live = m.P;
             Val<U> x;
             if (spec.reg != -1) {
-                m.FetchOperand(spec.reg, x);
+                m.FetchOperand(spec.fetch_kind, spec.fetch_payload, x);
                 if (spec.check_valid) live &= x.ok;
             }
             if (live == 0) continue;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void ScanProjectKernel(const KArgs<ProjectS
         for (int k = 0; k < s.nouts; ++k) {
             const ProjectOut o = s.outs[k];
             Val<U> x;
-            m.FetchOperand(o.reg, x);
+            m.FetchOperand(o.fetch_kind, o.fetch_payload, x);
             const int w = (o.type == T_BOOL) ? 1 : TypeWidth(o.type);
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -176,30 +176,30 @@ struct Machine {
     uint32_t act;        // bit u: row0 + u * kBlock < nrows
     uint32_t P;          // bit u: row passes every Filter so far
     uint32_t err;        // ScanStatus bits raised by this lane
-    bool staged;         // the current tile's columns sit in LDS (full tiles only)
     Val<U> A;
 
     // The step program, spread over the lanes of each wave: lane i holds instruction i, the
     // description of column slot i, constant i and staging piece i.  Decode is a v_readlane with a
     // wave-uniform index -- no memory access, no latency -- instead of dependent scalar loads.
-    uint32_t tCode0, tCode1;                 // instructions [lane], [64 + lane]
+    uint32_t tCode0, tCode1, tCode2;         // pre-decoded instruction [lane]: dispatch word, operand payload, generic form
     uint32_t tColOff, tColType, tColW;       // column slot (lane & 15): LDS offset (or -1), TypeId, width
     uint32_t tColValBit, tColValidBit;
     uint64_t tColVal, tColValid, tColChars;
     uint64_t tConstBits;                     // constant (lane)
     uint32_t tConstValid;
     uint64_t tPieceSrc;                      // staging piece (lane): column base + piece offset
-    uint32_t tPieceLds, tPieceW;
+    uint32_t tPieceLds, tPieceW, tPieceOff;  // LDS offset, element width, byte offset of the piece inside the tile
     int nPieces;
     int64_t nrows;
     int ncode;
 
-    __device__ __forceinline__ explicit Machine(const ScanArgs& args) : a(args), err(0), staged(false) {
+    __device__ __forceinline__ explicit Machine(const ScanArgs& args) : a(args), err(0) {
         const int lane = threadIdx.x & 63;
         nrows = a.nrows;
         ncode = a.ncode;
-        tCode0 = lane < ncode ? a.code[lane] : 0u;
-        tCode1 = (64 + lane) < ncode ? a.code[64 + lane] : 0u;
+        tCode0 = lane < ncode ? a.code[3 * lane] : 0u;
+        tCode1 = lane < ncode ? a.code[3 * lane + 1] : 0u;
+        tCode2 = lane < ncode ? a.code[3 * lane + 2] : 0u;
         const int c = lane & (kMaxCols - 1);
         tColOff = uint32_t(a.lds_col_off[c]);
         tColType = uint32_t(a.cols[c].type);
@@ -216,6 +216,7 @@ struct Machine {
         tPieceSrc = 0;
         tPieceLds = 0;
         tPieceW = 0;
+        tPieceOff = 0;
         int acc = 0;
         for (int col = 0; col < a.ncols; ++col) {
             const int off = a.lds_col_off[col];
@@ -226,6 +227,7 @@ struct Machine {
                 tPieceSrc = reinterpret_cast<uint64_t>(a.cols[col].values) + uint64_t(lane - acc) * 1024u;
                 tPieceLds = uint32_t(off + (lane - acc) * 1024);
                 tPieceW = uint32_t(w);
+                tPieceOff = uint32_t((lane - acc) * 1024);
             }
             acc += np;
         }
@@ -234,21 +236,19 @@ struct Machine {
 
     __device__ __forceinline__ int64_t Row(int u) const { return row0 + int64_t(u) * kBlock; }
 
-    __device__ __forceinline__ uint32_t Insn(int pc) const {
-        return pc < 64 ? ReadLane32(tCode0, pc) : ReadLane32(tCode1, pc - 64);
-    }
-
     // Stage the tile's fixed-width source columns into LDS with direct global->LDS loads
     // (global_load_lds_dwordx4: one wave-instruction moves 1 KiB, no VGPRs are involved), then
-    // make them visible to the workgroup.  Partial tiles are read from global memory on demand instead.
+    // make them visible to the workgroup.  In the last, partial tile the lanes whose 16-byte chunk
+    // starts past the end of the column issue nothing (those rows are inactive); a chunk that straddles
+    // the end reads at most 15 bytes of the allocation's tail padding.
     __device__ __forceinline__ void BeginTile(int64_t tileBase) {
         row0 = tileBase + threadIdx.x;
         act = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) act |= (Row(u) < nrows ? 1u : 0u) << u;
-        staged = (tileBase + kTile <= nrows);
+        const bool full = (tileBase + kTile <= nrows);
         __syncthreads();  // every wave is done reading the previous tile
-        if (staged && !(a.debug_flags & 1)) {
+        if (!(a.debug_flags & 1)) {
             const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
             const int lane = threadIdx.x & 63;
             for (int p = wave; p < nPieces; p += kBlock / 64) {
@@ -256,7 +256,11 @@ struct Machine {
                 const uint32_t ldsOff = ReadLane32(tPieceLds, p);
                 const uint32_t w = ReadLane32(tPieceW, p);
                 const unsigned char* g = reinterpret_cast<const unsigned char*>(src) + tileBase * w + lane * 16;
-                __builtin_amdgcn_global_load_lds((GlobalPtr)g, (LdsPtr)(gLds + ldsOff), 16, 0, 0);
+                // byte position of this lane's chunk inside the column
+                const int64_t pos = tileBase * w + int64_t(ReadLane32(tPieceOff, p)) + lane * 16;
+                if (full || pos < nrows * int64_t(w)) {
+                    __builtin_amdgcn_global_load_lds((GlobalPtr)g, (LdsPtr)(gLds + ldsOff), 16, 0, 0);
+                }
             }
         }
         __syncthreads();  // waits for the LDS-DMA (vmcnt(0)) before the barrier
@@ -279,7 +283,7 @@ struct Machine {
         const int w = int(ReadLane32(tColW, c));
         if (w > 0 && w <= 8) {
             const int off = int(ReadLane32(tColOff, c));
-            if (staged && off >= 0) {
+            if (off >= 0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) out.v[u] = LdsLoadRaw(gLds + off, w, u * kBlock + int(threadIdx.x));
             } else {
@@ -334,21 +338,77 @@ struct Machine {
         }
     }
 
-    // Aggregate argument / key / output operand: register (>= 0) or column slot (<= -2).
-    __device__ __forceinline__ void FetchOperand(int reg, Val<U>& out) {
-        if (reg >= 0) {
-            FetchReg(reg, out);
-        } else {
-            FetchCol(-2 - reg, out);
-        }
-    }
-
     __device__ __forceinline__ void StringAt(int c, int64_t row, const uint8_t*& p, int32_t& n) const {
         const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, c));
         const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
         const int32_t b = offs[row], e = offs[row + 1];
         p = chars + b;
         n = e - b;
+    }
+
+    // Operand fetch by pre-decoded kind: the host resolved column type, width and LDS offset, so a
+    // staged column costs U LDS reads and no further dispatch.
+    __device__ __forceinline__ void FetchFast(uint32_t fk, uint32_t w1, Val<U>& B) {
+        const unsigned char* base = gLds + (w1 & 0xFFFFFFu);
+        const int idx = threadIdx.x;
+        switch (fk & 0x7Fu) {
+            case FK_NONE:
+                return;
+            case FK_LDS_64:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint64_t*>(base)[u * kBlock + idx];
+                break;
+            case FK_LDS_I32:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int32_t*>(base)[u * kBlock + idx]));
+                break;
+            case FK_LDS_U32:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint32_t*>(base)[u * kBlock + idx];
+                break;
+            case FK_LDS_I16:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int16_t*>(base)[u * kBlock + idx]));
+                break;
+            case FK_LDS_U16:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint16_t*>(base)[u * kBlock + idx];
+                break;
+            case FK_LDS_I8:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int8_t*>(base)[u * kBlock + idx]));
+                break;
+            case FK_LDS_U8:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint8_t*>(base)[u * kBlock + idx];
+                break;
+            case FK_LDS_F32:
+#pragma unroll
+                for (int u = 0; u < U; ++u) B.v[u] = F64ToBits(double(reinterpret_cast<const float*>(base)[u * kBlock + idx]));
+                break;
+            case FK_REG:
+                FetchReg(int(w1 & 0xFFFFFFu), B);
+                return;
+            case FK_CONST:
+                FetchConst(int(w1 & 0xFFFFFFu), B);
+                return;
+            default:  // FK_SLOW: unstaged / bit-packed / string column
+                FetchCol(int(w1 >> 24), B);
+                return;
+        }
+        B.ok = (fk & 0x80u) ? ValidityOf(int(w1 >> 24)) : AllMask<U>();
+    }
+
+    // Aggregate argument / key / output operand described by a pre-decoded (kind, payload) pair.
+    __device__ __forceinline__ void FetchOperand(uint32_t fk, uint32_t w1, Val<U>& out) { FetchFast(fk, w1, out); }
+
+    // cmpMask: bit 0 = lt, 1 = eq, 2 = gt, 3 = unordered contribute to the result.
+    __device__ __forceinline__ uint32_t CompareByMask(int cls, uint32_t cmpMask, const uint64_t* x, const uint64_t* y) {
+        uint32_t lt, eq, un;
+        CompareMasks<U>(cls, x, y, lt, eq, un);
+        const uint32_t gt = ~(lt | eq | un);
+        return ((lt & (0u - (cmpMask & 1u))) | (eq & (0u - ((cmpMask >> 1) & 1u))) | (gt & (0u - ((cmpMask >> 2) & 1u))) |
+                (un & (0u - ((cmpMask >> 3) & 1u)))) & AllMask<U>();
     }
 
     // Runs the step program for the current tile.  Leaves outputs in R[] and the row predicate in P.
@@ -360,220 +420,275 @@ struct Machine {
 
         const int ncodeEff = (a.debug_flags & 2) ? 0 : ncode;
         for (int pc = 0; pc < ncodeEff; ++pc) {
-            const uint32_t ins = Insn(pc);
-            const int op = InsnOp(ins);
-            if (op == OP_END) break;
-            const int sk = InsnSk(ins), si = InsnSi(ins), fa = InsnA(ins), fb = InsnB(ins);
-            // The one operand fetch of the instruction (kept out of the switch so that the fetch code,
-            // with its width / type dispatch, exists once in the kernel).
+            const uint32_t w0 = ReadLane32(tCode0, pc);
+            const uint32_t w1 = ReadLane32(tCode1, pc);
+            const uint32_t ok = w0 & 0xFFu, fk = (w0 >> 8) & 0xFFu;
+            const int fa = int((w0 >> 16) & 0xFFu), fb = int(w0 >> 24);
             Val<U> B;
-            if (sk != SRC_NONE) Fetch(sk, si, B);
-            switch (op) {
-                case OP_LD:
+            FetchFast(fk, w1, B);
+            switch (ok) {
+                case OK_LD:
                     A = B;
                     break;
-                case OP_ST:
-                    StoreReg(si, A);
+                case OK_ST:
+                    StoreReg(int(w1 & 0xFFFFFFu), A);
                     break;
-                case OP_ADD: case OP_SUB: case OP_RSUB: case OP_MUL: {
-                    if (fa == CLS_F64) {
+                case OK_PREDCMP: {  // B = column, constant fa, class fb >> 4, mask fb & 15
+                    uint64_t c[U];
+                    const uint64_t cbits = ReadLane64(tConstBits, fa);
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const double x = BitsToF64(A.v[u]), y = BitsToF64(B.v[u]);
-                            const double r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
-                            A.v[u] = F64ToBits(r);
-                        }
-                    } else if (fa == CLS_F32) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const float x = float(BitsToF64(A.v[u])), y = float(BitsToF64(B.v[u]));
-                            const float r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
-                            A.v[u] = F64ToBits(double(r));
-                        }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const uint64_t x = A.v[u], y = B.v[u];
-                            A.v[u] = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
-                        }
-                    }
-                    A.ok &= B.ok;
+                    for (int u = 0; u < U; ++u) c[u] = cbits;
+                    P &= CompareByMask(fb >> 4, uint32_t(fb & 15), B.v, c);
                     break;
                 }
-                case OP_DIV: case OP_RDIV: case OP_MOD: case OP_RMOD: {
-                    const bool rev = (op == OP_RDIV || op == OP_RMOD);
-                    const bool mod = (op == OP_MOD || op == OP_RMOD);
-                    const int dialect = fb & 1, rtype = fb >> 1;
-                    uint32_t ok = A.ok & B.ok;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint64_t x = rev ? B.v[u] : A.v[u];
-                        const uint64_t y = rev ? A.v[u] : B.v[u];
-                        const bool live = (ok >> u) & 1u;
-                        if (dialect == DIALECT_ARROW && !live) {
-                            A.v[u] = 0;  // the not-null kernel variant leaves 0 under a null slot and never divides there
-                        } else {
-                            ArithResult r = ArithDivOutlined(mod, fa, dialect, rtype, x, y);
-                            A.v[u] = r.v;
-                            if (r.null) ok &= ~(1u << u);
-                            if (r.error && ((act >> u) & 1u)) err |= SCAN_DIV_BY_ZERO;
-                        }
-                    }
-                    A.ok = ok;
-                    break;
-                }
-                case OP_CMP: {
-                    uint32_t lt, eq, un;
-                    CompareMasks<U>(fa, A.v, B.v, lt, eq, un);
-                    const uint32_t r = CompareResult(fb, lt, eq, un);
+                case OK_CMP: {
+                    const uint32_t r = CompareByMask(fa, uint32_t(fb), A.v, B.v);
 #pragma unroll
                     for (int u = 0; u < U; ++u) A.v[u] = (r >> u) & 1u;
                     A.ok &= B.ok;
                     break;
                 }
-                case OP_PREDCMP: {
-                    // fused "column <cmp> constant, AND into the row predicate": B = column si, constant fa
-                    uint64_t c[U];
-                    const uint64_t cbits = ReadLane64(tConstBits, fa);
+                case OK_ADD_F64:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) c[u] = cbits;
-                    uint32_t lt, eq, un;
-                    CompareMasks<U>(fb >> 4, B.v, c, lt, eq, un);
-                    P &= CompareResult(fb & 15, lt, eq, un);
+                    for (int u = 0; u < U; ++u) A.v[u] = F64ToBits(BitsToF64(A.v[u]) + BitsToF64(B.v[u]));
+                    A.ok &= B.ok;
                     break;
-                }
-                case OP_AND: case OP_OR: case OP_XOR: {
-                    uint32_t av = 0, bv = 0;
+                case OK_SUB_F64:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        av |= (A.v[u] != 0 ? 1u : 0u) << u;
-                        bv |= (B.v[u] != 0 ? 1u : 0u) << u;
-                    }
-                    uint32_t rv, rok = A.ok & B.ok;
-                    if (op == OP_AND) {
-                        rv = av & bv;
-                        // Kleene: a definite false on either side decides the result
-                        if (fb == DIALECT_YQL) rok |= (A.ok & ~av) | (B.ok & ~bv);
-                    } else if (op == OP_OR) {
-                        rv = av | bv;
-                        if (fb == DIALECT_YQL) rok |= (A.ok & av) | (B.ok & bv);
-                    } else {
-                        rv = av ^ bv;
-                    }
-                    // the value byte is the plain and/or/xor of the value bytes, also under null slots
-                    // (ydb/library/yql/minikql/comp_nodes/mkql_block_logical.cpp:190-192)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = (rv >> u) & 1u;
-                    A.ok = rok;
+                    for (int u = 0; u < U; ++u) A.v[u] = F64ToBits(BitsToF64(A.v[u]) - BitsToF64(B.v[u]));
+                    A.ok &= B.ok;
                     break;
-                }
-                case OP_NOT:
+                case OK_RSUB_F64:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = A.v[u] ? 0 : 1;
+                    for (int u = 0; u < U; ++u) A.v[u] = F64ToBits(BitsToF64(B.v[u]) - BitsToF64(A.v[u]));
+                    A.ok &= B.ok;
                     break;
-                case OP_ISNULL:
+                case OK_MUL_F64:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = ((A.ok >> u) & 1u) ? 0 : 1;
-                    A.ok = AllMask<U>();
+                    for (int u = 0; u < U; ++u) A.v[u] = F64ToBits(BitsToF64(A.v[u]) * BitsToF64(B.v[u]));
+                    A.ok &= B.ok;
                     break;
-                case OP_ISVALID:
+                case OK_ADD_I:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = (A.ok >> u) & 1u;
-                    A.ok = AllMask<U>();
+                    for (int u = 0; u < U; ++u) A.v[u] = A.v[u] + B.v[u];
+                    A.ok &= B.ok;
                     break;
-                case OP_WRAP:
+                case OK_SUB_I:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = WrapTo(A.v[u], fa);
+                    for (int u = 0; u < U; ++u) A.v[u] = A.v[u] - B.v[u];
+                    A.ok &= B.ok;
                     break;
-                case OP_CAST:
+                case OK_MUL_I:
 #pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = CastValOutlined(A.v[u], fa, fb);
+                    for (int u = 0; u < U; ++u) A.v[u] = A.v[u] * B.v[u];
+                    A.ok &= B.ok;
                     break;
-                case OP_CHECK:
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (((act & A.ok) >> u) & 1u) {
-                            if (!FitsTypeOutlined(A.v[u], fa, fb)) err |= SCAN_CAST_OVERFLOW;
-                        }
-                    }
-                    break;
-                case OP_COALESCE: {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = ((A.ok >> u) & 1u) ? A.v[u] : B.v[u];
-                    A.ok |= B.ok;
-                    break;
-                }
-                case OP_ROWIDX:
-#pragma unroll
-                    for (int u = 0; u < U; ++u) A.v[u] = uint64_t(Row(u));
-                    break;
-                case OP_STRLEN: {
-                    A.ok = ValidityOf(si);
-                    const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, si));
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        uint64_t len = 0;
-                        if (((act & A.ok) >> u) & 1u) len = uint64_t(int64_t(offs[Row(u) + 1] - offs[Row(u)]));
-                        A.v[u] = len;  // 0 under null slots (not-null kernel variant)
-                    }
-                    break;
-                }
-                case OP_STRMATCH: {
-                    const uint64_t pat = ReadLane64(tConstBits, fa);
-                    const uint8_t* pp = a.pattern + uint32_t(pat >> 32);
-                    const int32_t pn = int32_t(uint32_t(pat));
-                    A.ok = ValidityOf(si) & (ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        uint64_t m = 0;
-                        if ((act >> u) & 1u) {
-                            const uint8_t* s;
-                            int32_t n;
-                            StringAt(si, Row(u), s, n);
-                            m = StrMatchOutlined(fb & 15, (fb & 16) != 0, s, n, pp, pn) ? 1 : 0;
-                        }
-                        A.v[u] = m;
-                    }
-                    break;
-                }
-                case OP_STRCMP: {
-                    uint32_t ok = ValidityOf(si);
-                    const bool rhsCol = (fb & 16) != 0;
-                    const uint8_t* pp = nullptr;
-                    int32_t pn = 0;
-                    if (!rhsCol) {
-                        const uint64_t pat = ReadLane64(tConstBits, fa);
-                        pp = a.pattern + uint32_t(pat >> 32);
-                        pn = int32_t(uint32_t(pat));
-                        ok &= ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u;
-                    } else {
-                        ok &= ValidityOf(fa);
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        uint64_t m = 0;
-                        if ((act >> u) & 1u) {
-                            const uint8_t* s;
-                            int32_t n;
-                            StringAt(si, Row(u), s, n);
-                            if (rhsCol) StringAt(fa, Row(u), pp, pn);
-                            m = CmpFromOrder(fb & 15, StrCompareOutlined(s, n, pp, pn)) ? 1 : 0;
-                        }
-                        A.v[u] = m;
-                    }
-                    A.ok = ok;
-                    break;
-                }
-                case OP_PRED: {
+                case OK_PRED: {
                     uint32_t t = 0;
 #pragma unroll
                     for (int u = 0; u < U; ++u) t |= (A.v[u] != 0 ? 1u : 0u) << u;
                     P &= t;
                     break;
                 }
-                default:
+                default: {
+                    const uint32_t w2 = ReadLane32(tCode2, pc);
+                    GenericOp(InsnOp(w2), InsnSi(w2), InsnA(w2), InsnB(w2), B);
                     break;
+                }
             }
+        }
+    }
+
+    // Every other instruction, in its generic (op, class, type) form.  B was fetched by the caller.
+    __device__ __forceinline__ void GenericOp(int op, int si, int fa, int fb, Val<U>& B) {
+    switch (op) {
+        case OP_ADD: case OP_SUB: case OP_RSUB: case OP_MUL: {
+            if (fa == CLS_F64) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double x = BitsToF64(A.v[u]), y = BitsToF64(B.v[u]);
+                    const double r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
+                    A.v[u] = F64ToBits(r);
+                }
+            } else if (fa == CLS_F32) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float x = float(BitsToF64(A.v[u])), y = float(BitsToF64(B.v[u]));
+                    const float r = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
+                    A.v[u] = F64ToBits(double(r));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint64_t x = A.v[u], y = B.v[u];
+                    A.v[u] = op == OP_ADD ? x + y : op == OP_SUB ? x - y : op == OP_RSUB ? y - x : x * y;
+                }
+            }
+            A.ok &= B.ok;
+            break;
+        }
+        case OP_DIV: case OP_RDIV: case OP_MOD: case OP_RMOD: {
+            const bool rev = (op == OP_RDIV || op == OP_RMOD);
+            const bool mod = (op == OP_MOD || op == OP_RMOD);
+            const int dialect = fb & 1, rtype = fb >> 1;
+            uint32_t ok = A.ok & B.ok;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t x = rev ? B.v[u] : A.v[u];
+                const uint64_t y = rev ? A.v[u] : B.v[u];
+                const bool live = (ok >> u) & 1u;
+                if (dialect == DIALECT_ARROW && !live) {
+                    A.v[u] = 0;  // the not-null kernel variant leaves 0 under a null slot and never divides there
+                } else {
+                    ArithResult r = ArithDivOutlined(mod, fa, dialect, rtype, x, y);
+                    A.v[u] = r.v;
+                    if (r.null) ok &= ~(1u << u);
+                    if (r.error && ((act >> u) & 1u)) err |= SCAN_DIV_BY_ZERO;
+                }
+            }
+            A.ok = ok;
+            break;
+        }
+        case OP_CMP: {
+            uint32_t lt, eq, un;
+            CompareMasks<U>(fa, A.v, B.v, lt, eq, un);
+            const uint32_t r = CompareResult(fb, lt, eq, un);
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = (r >> u) & 1u;
+            A.ok &= B.ok;
+            break;
+        }
+        case OP_AND: case OP_OR: case OP_XOR: {
+            uint32_t av = 0, bv = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                av |= (A.v[u] != 0 ? 1u : 0u) << u;
+                bv |= (B.v[u] != 0 ? 1u : 0u) << u;
+            }
+            uint32_t rv, rok = A.ok & B.ok;
+            if (op == OP_AND) {
+                rv = av & bv;
+                // Kleene: a definite false on either side decides the result
+                if (fb == DIALECT_YQL) rok |= (A.ok & ~av) | (B.ok & ~bv);
+            } else if (op == OP_OR) {
+                rv = av | bv;
+                if (fb == DIALECT_YQL) rok |= (A.ok & av) | (B.ok & bv);
+            } else {
+                rv = av ^ bv;
+            }
+            // the value byte is the plain and/or/xor of the value bytes, also under null slots
+            // (ydb/library/yql/minikql/comp_nodes/mkql_block_logical.cpp:190-192)
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = (rv >> u) & 1u;
+            A.ok = rok;
+            break;
+        }
+        case OP_NOT:
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = A.v[u] ? 0 : 1;
+            break;
+        case OP_ISNULL:
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = ((A.ok >> u) & 1u) ? 0 : 1;
+            A.ok = AllMask<U>();
+            break;
+        case OP_ISVALID:
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = (A.ok >> u) & 1u;
+            A.ok = AllMask<U>();
+            break;
+        case OP_WRAP:
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = WrapTo(A.v[u], fa);
+            break;
+        case OP_CAST:
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = CastValOutlined(A.v[u], fa, fb);
+            break;
+        case OP_CHECK:
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (((act & A.ok) >> u) & 1u) {
+                    if (!FitsTypeOutlined(A.v[u], fa, fb)) err |= SCAN_CAST_OVERFLOW;
+                }
+            }
+            break;
+        case OP_COALESCE: {
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = ((A.ok >> u) & 1u) ? A.v[u] : B.v[u];
+            A.ok |= B.ok;
+            break;
+        }
+        case OP_ROWIDX:
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.v[u] = uint64_t(Row(u));
+            break;
+        case OP_STRLEN: {
+            A.ok = ValidityOf(si);
+            const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, si));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint64_t len = 0;
+                if (((act & A.ok) >> u) & 1u) len = uint64_t(int64_t(offs[Row(u) + 1] - offs[Row(u)]));
+                A.v[u] = len;  // 0 under null slots (not-null kernel variant)
+            }
+            break;
+        }
+        case OP_STRMATCH: {
+            const uint64_t pat = ReadLane64(tConstBits, fa);
+            const uint8_t* pp = a.pattern + uint32_t(pat >> 32);
+            const int32_t pn = int32_t(uint32_t(pat));
+            A.ok = ValidityOf(si) & (ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint64_t m = 0;
+                if ((act >> u) & 1u) {
+                    const uint8_t* s;
+                    int32_t n;
+                    StringAt(si, Row(u), s, n);
+                    m = StrMatchOutlined(fb & 15, (fb & 16) != 0, s, n, pp, pn) ? 1 : 0;
+                }
+                A.v[u] = m;
+            }
+            break;
+        }
+        case OP_STRCMP: {
+            uint32_t ok = ValidityOf(si);
+            const bool rhsCol = (fb & 16) != 0;
+            const uint8_t* pp = nullptr;
+            int32_t pn = 0;
+            if (!rhsCol) {
+                const uint64_t pat = ReadLane64(tConstBits, fa);
+                pp = a.pattern + uint32_t(pat >> 32);
+                pn = int32_t(uint32_t(pat));
+                ok &= ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u;
+            } else {
+                ok &= ValidityOf(fa);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint64_t m = 0;
+                if ((act >> u) & 1u) {
+                    const uint8_t* s;
+                    int32_t n;
+                    StringAt(si, Row(u), s, n);
+                    if (rhsCol) StringAt(fa, Row(u), pp, pn);
+                    m = CmpFromOrder(fb & 15, StrCompareOutlined(s, n, pp, pn)) ? 1 : 0;
+                }
+                A.v[u] = m;
+            }
+            A.ok = ok;
+            break;
+        }
+        case OP_PRED: {
+            uint32_t t = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) t |= (A.v[u] != 0 ? 1u : 0u) << u;
+            P &= t;
+            break;
+        }
+        default:
+            break;
         }
     }
 

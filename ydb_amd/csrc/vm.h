@@ -132,7 +132,7 @@ SSA_HD int InsnB(uint32_t i) { return (i >> 24) & 0xFF; }
 constexpr int kMaxCols = 16;     // source columns referenced by one scan program
 constexpr int kMaxRegs = 16;     // R registers (outputs first, then temporaries); they live in LDS
 constexpr int kMaxConsts = 24;
-constexpr int kMaxCode = 128;
+constexpr int kMaxCode = 64;      // instructions per step (one per lane of a wave)
 constexpr int kMaxAggs = 12;
 constexpr int kMaxKeys = 6;
 constexpr int kMaxOuts = 12;
@@ -162,6 +162,36 @@ struct DevConst {
     int32_t type;
 };
 
+// Pre-decoded dispatch: how the operand of an instruction is fetched ...
+enum FetchKind : uint32_t {
+    FK_NONE = 0,
+    FK_LDS_64,    // staged 8-byte column (int64 / uint64 / double / timestamp / duration): raw bits
+    FK_LDS_I32, FK_LDS_U32, FK_LDS_I16, FK_LDS_U16, FK_LDS_I8, FK_LDS_U8,
+    FK_LDS_F32,
+    FK_REG,       // R register (LDS)
+    FK_CONST,
+    FK_SLOW,      // unstaged, bit-packed or string column: generic path
+    FK_HAS_VALIDITY = 0x80,  // flag: the column carries a validity bitmap
+};
+// ... and which handler runs it.  Everything not listed executes through the generic form.
+enum OpKind : uint32_t {
+    OK_GENERIC = 0,
+    OK_LD, OK_ST, OK_PREDCMP, OK_CMP, OK_PRED,
+    OK_ADD_F64, OK_SUB_F64, OK_RSUB_F64, OK_MUL_F64,
+    OK_ADD_I, OK_SUB_I, OK_MUL_I,
+};
+// Comparison as a mask over {lt = 1, eq = 2, gt = 4, unordered = 8}.
+SSA_HD uint32_t CmpMaskOf(int cmp) {
+    switch (cmp) {
+        case CMP_EQ: return 2;
+        case CMP_NE: return 1 | 4 | 8;
+        case CMP_LT: return 1;
+        case CMP_LE: return 1 | 2;
+        case CMP_GT: return 4;
+        default: return 4 | 2;
+    }
+}
+
 enum AggKind : int32_t {
     AGG_NONE = 0,
     AGG_COUNT,     // counts rows where the argument is valid (or all rows when reg < 0)
@@ -178,6 +208,8 @@ struct AggSpec {
     int32_t reg;        // >= 0: R register holding the argument; -1: none (COUNT of rows); <= -2: column slot (-2 - reg)
     int32_t arg_class;  // ValClass of the argument payload
     int32_t check_valid; // skip rows whose argument is null (0: the argument's validity is not consulted)
+    uint32_t fetch_kind;    // pre-decoded operand (FetchKind, payload) for `reg`
+    uint32_t fetch_payload;
 };
 
 struct KeySpec {
@@ -185,6 +217,8 @@ struct KeySpec {
     int32_t col;        // string keys: source column index
     int32_t type;       // TypeId
     int32_t nullable;   // key contributes a null flag
+    uint32_t fetch_kind;    // pre-decoded operand for `reg`
+    uint32_t fetch_payload;
 };
 
 enum SinkKind : int32_t {
@@ -202,7 +236,7 @@ struct ScanArgs {
     int32_t nullable;        // any nullable input / null-producing op: validity is tracked
     DevColumn cols[kMaxCols];
     DevConst consts[kMaxConsts];
-    uint32_t code[kMaxCode];
+    uint32_t code[kMaxCode * 3];   // pre-decoded: {dispatch word, operand payload, generic form} per instruction
     uint8_t pattern[kMaxPatternBytes];
     uint32_t* status;        // device word, OR-ed with ScanStatus bits
     // LDS plan of one workgroup (byte offsets into dynamic shared memory)
