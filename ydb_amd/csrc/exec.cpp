@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 
 #include "vm_ops.h"
@@ -129,7 +130,9 @@ Executor::Executor(int device) : Device(device) {
     (void)hipStreamCreateWithFlags(&StreamHandle, hipStreamNonBlocking);
     (void)hipEventCreate(&EvStart);
     (void)hipEventCreate(&EvStop);
-    (void)ConfigureScanKernels(160 * 1024);
+    // dynamic LDS the scan kernels may ask for: everything but 1 KiB kept for their static arrays
+    const hipError_t cfgErr = ConfigureScanKernels(160 * 1024 - 1024);
+    if (cfgErr != hipSuccess) std::fprintf(stderr, "ydb_ssa_hip: cannot raise the LDS limit of the scan kernels: %s\n", hipGetErrorString(cfgErr));
     StatusWord = Buffer::Alloc(256);
     if (StatusWord) (void)hipMemset(StatusWord->Ptr, 0, 256);
 }
@@ -162,14 +165,19 @@ void Executor::ProfileEnd(const char* kernel, int64_t algoBytes) {
     Profile.LastKernel = kernel;
 }
 
-Status Executor::CheckScanStatus() {
+Status Executor::CheckScanStatus(bool* tableFull) {
     uint32_t st = 0;
+    if (tableFull) *tableFull = false;
     SSA_HIP(hipMemcpyAsync(&st, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
     SSA_HIP(hipStreamSynchronize(StreamHandle));
     if (st == 0) return Status::OK();
     SSA_HIP(hipMemsetAsync(StatusWord->Ptr, 0, sizeof(st), StreamHandle));
     if (st & SCAN_DIV_BY_ZERO) return Status::Invalid("divide by zero");
     if (st & SCAN_CAST_OVERFLOW) return Status::Invalid("Integer value not in range");
+    if (st == SCAN_TABLE_FULL && tableFull) {
+        *tableFull = true;
+        return Status::OK();
+    }
     return Status::Invalid("scan kernel reported status " + std::to_string(st));
 }
 
@@ -661,7 +669,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     if (lds > kLdsPerCU - 1024) return Status::Unsupported("step needs more LDS than one CU has");
 
     const int64_t ntiles = (in.Rows + kTileRows - 1) / kTileRows;
-    int perCU = lds > 0 ? (kLdsPerCU - 8192) / lds : 8;
+    int perCU = kLdsPerCU / (lds + 1024);  // 1 KiB per workgroup for the kernels' static LDS and allocation granularity
     if (const char* pc = std::getenv("SSA_BLOCKS_PER_CU")) perCU = std::atoi(pc);
     perCU = std::max(1, std::min(perCU, 8));
     int64_t grid = std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU);
@@ -986,8 +994,273 @@ Status Executor::RunProject(const TProgramStep& step, const StepPlan& plan, cons
     return Status::OK();
 }
 
-Status Executor::RunKeyed(const StepPlan&, const Batch&, BatchPtr&) {
-    return Status::Unsupported("keyed GROUP BY");
+namespace {
+uint64_t NextPow2(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+}  // namespace
+
+// Rows of `src` at the given 64-bit row indices (~0 -> null).
+Status Executor::GatherRows(const Column& src, const BufferPtr& rowIdx, int64_t n, bool keepValidity, Column& dst) {
+    const uint64_t* rows = static_cast<const uint64_t*>(rowIdx->Ptr);
+    dst = Column();
+    dst.Field = src.Field;
+    dst.Field.Nullable = false;
+    dst.Length = n;
+    const int type = src.Field.Type;
+    BufferPtr validBytes;
+    if (keepValidity) {
+        validBytes = Buffer::Alloc(size_t(n) + 16);
+        if (!validBytes) return Status::Hip("out of device memory");
+    }
+    const uint8_t* srcValid = src.Validity ? static_cast<const uint8_t*>(src.Validity->Ptr) : nullptr;
+    uint8_t* dstValid = validBytes ? static_cast<uint8_t*>(validBytes->Ptr) : nullptr;
+    if (IsStringLike(type)) {
+        BufferPtr lens = Buffer::Alloc(size_t(n + 1) * 4 + 16);
+        dst.Values = Buffer::Alloc(size_t(n + 1) * 4 + 16);
+        const int64_t nblocks = (n + 4095) / 4096 + 2;
+        BufferPtr tmp = Buffer::Alloc(size_t(nblocks) * 8 + 16);
+        if (!lens || !dst.Values || !tmp) return Status::Hip("out of device memory");
+        const int32_t* offs = static_cast<const int32_t*>(src.ValuesPtr());
+        SSA_HIP(LaunchGatherStringLens(offs, rows, n, static_cast<int32_t*>(lens->Ptr), StreamHandle));
+        SSA_HIP(LaunchExclusiveScanI32(static_cast<const int32_t*>(lens->Ptr), static_cast<int32_t*>(dst.Values->Ptr), n,
+                                       static_cast<int64_t*>(tmp->Ptr), StreamHandle));
+        int32_t total = 0;
+        SSA_HIP(hipMemcpyAsync(&total, static_cast<const int32_t*>(dst.Values->Ptr) + n, 4, hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        dst.Chars = Buffer::Alloc(size_t(total) + 16);
+        if (!dst.Chars) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchGatherStringBytes(offs, static_cast<const uint8_t*>(src.Chars->Ptr), rows, n,
+                                        static_cast<const int32_t*>(dst.Values->Ptr), static_cast<uint8_t*>(dst.Chars->Ptr), StreamHandle));
+        if (dstValid) SSA_HIP(LaunchGatherValidity(srcValid, src.ValidBitOff, rows, n, dstValid, StreamHandle));
+    } else if (type == T_BOOL) {
+        return Status::Unsupported("gather of a boolean column");
+    } else {
+        const int w = TypeWidth(type);
+        dst.Values = Buffer::Alloc(size_t(n) * w + 16);
+        if (!dst.Values) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchGatherFixed(src.ValuesPtr(), srcValid, src.ValidBitOff, w, rows, n, dst.Values->Ptr, dstValid, StreamHandle));
+    }
+    if (validBytes) SSA_RETURN_NOT_OK(PackValidity(validBytes, n, dst));
+    return Status::OK();
+}
+
+// TProgramStep::ApplyAggregates with keys (ydb/core/formats/arrow/program.cpp:760-832): the step's
+// assigns and filters run fused with a two-level hash aggregation; the table is then turned into one
+// output row per group, aggregates first, keys after them.
+Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out) {
+    const int naggsUser = int(plan.Aggs.size());
+    const int nkeys = int(plan.Keys.size());
+    int keyBits = 0;
+    bool hashed = false;
+    for (const KeyPlan& kp : plan.Keys) {
+        if (IsStringLike(kp.Spec.type)) hashed = true;
+        else keyBits += 8 * TypeWidth(kp.Spec.type) + (kp.Spec.nullable ? 1 : 0);
+    }
+    if (keyBits > 119) hashed = true;
+    if (hashed) {
+        for (const KeyPlan& kp : plan.Keys) {
+            if (kp.InputColumn < 0) return Status::Unsupported("computed GROUP BY key next to string or wide keys");
+        }
+    }
+    const bool twoWords = hashed || keyBits > 63;
+    const int naggs = naggsUser + (hashed ? 1 : 0);
+
+    KeyedHint& hint = KeyedHints[&step];
+    const uint64_t maxCap = std::max<uint64_t>(1024, NextPow2(uint64_t(in.Rows) * 2 + 2));
+    uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(hint.TableCap, 1024), maxCap);
+
+    int L = hint.LdsCap, R = 1;
+    if (L == 16) {
+        R = 32;
+        while (R > 1 && L * R * naggs * 8 > 32 * 1024) R >>= 1;
+    }
+    if (const char* env = std::getenv("SSA_KEYED_LDS")) {
+        int l = 0, r = 1;
+        if (std::sscanf(env, "%d,%d", &l, &r) >= 1 && (l & (l - 1)) == 0 && r >= 1 && (r & (r - 1)) == 0) {
+            L = l;
+            R = l ? r : 1;
+        }
+    }
+    if (L == 0) R = 1;
+    const int sinkLds = L * 16 + naggs * L * R * 8 + L * 4;
+
+    ScanArgs args;
+    LaunchCfg cfg;
+    int64_t algoBytes = 0;
+    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, sinkLds, args, cfg, algoBytes));
+    KeyedSink sink{};
+    sink.naggs = naggs;
+    sink.nkeys = nkeys;
+    for (int k = 0; k < naggsUser; ++k) {
+        sink.aggs[k] = plan.Aggs[size_t(k)].Spec;
+        if (sink.aggs[k].reg != -1) EncodeOperand(args, sink.aggs[k].reg, sink.aggs[k].fetch_kind, sink.aggs[k].fetch_payload);
+    }
+    sink.rep_row_agg = -1;
+    if (hashed) {
+        sink.rep_row_agg = naggsUser;
+        sink.aggs[naggsUser] = AggSpec{};
+        sink.aggs[naggsUser].kind = AGG_MIN_U;
+        sink.aggs[naggsUser].reg = -1;
+        sink.aggs[naggsUser].arg_class = CLS_U;
+    }
+    for (int k = 0; k < nkeys; ++k) {
+        sink.keys[k] = plan.Keys[size_t(k)].Spec;
+        if (sink.keys[k].col < 0) EncodeOperand(args, sink.keys[k].reg, sink.keys[k].fetch_kind, sink.keys[k].fetch_payload);
+    }
+    sink.two_words = twoWords;
+    sink.hashed = hashed;
+    sink.lds_cap = L;
+    sink.lds_rep = R;
+
+    BufferPtr tLo, tHi, tAcc, tSeen;
+    for (;;) {
+        tLo = Buffer::Alloc(cap * 8);
+        tHi = Buffer::Alloc(twoWords ? cap * 8 : 64);
+        tAcc = Buffer::Alloc(size_t(naggs) * cap * 8);
+        tSeen = Buffer::Alloc(cap * 4);
+        if (!tLo || !tHi || !tAcc || !tSeen) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemsetAsync(tLo->Ptr, 0xFF, cap * 8, StreamHandle));
+        if (twoWords) SSA_HIP(hipMemsetAsync(tHi->Ptr, 0xFF, cap * 8, StreamHandle));
+        SSA_HIP(hipMemsetAsync(tSeen->Ptr, 0, cap * 4, StreamHandle));
+        for (int k = 0; k < naggs; ++k) {
+            uint64_t* base = static_cast<uint64_t*>(tAcc->Ptr) + size_t(k) * cap;
+            const uint64_t ident = KeyedTableIdentity(sink.aggs[k].kind);
+            if (ident == 0) SSA_HIP(hipMemsetAsync(base, 0, cap * 8, StreamHandle));
+            else SSA_HIP(LaunchFill(base, 8, ident, int64_t(cap), StreamHandle));
+        }
+        sink.table_mask = cap - 1;
+        sink.t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
+        sink.t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
+        sink.t_acc = static_cast<uint64_t*>(tAcc->Ptr);
+        sink.t_seen = static_cast<uint32_t*>(tSeen->Ptr);
+        if (in.Rows > 0) {
+            ProfileBegin();
+            SSA_HIP(LaunchScanKeyed(args, sink, cfg));
+            ProfileEnd("ScanKeyedKernel", algoBytes);
+        }
+        bool tableFull = false;
+        SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull));
+        if (!tableFull) break;
+        if (cap >= maxCap) return Status::Invalid("internal: group-by table overflow");
+        cap = std::min<uint64_t>(cap * 16, maxCap);
+    }
+
+    BufferPtr counter = Buffer::Alloc(256);
+    if (!counter) return Status::Hip("out of device memory");
+    SSA_HIP(hipMemsetAsync(counter->Ptr, 0, 8, StreamHandle));
+    SSA_HIP(LaunchKeyedCount(sink.t_key_lo, cap, static_cast<unsigned long long*>(counter->Ptr), StreamHandle));
+    unsigned long long ngroupsU = 0;
+    SSA_HIP(hipMemcpyAsync(&ngroupsU, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    const int64_t ngroups = int64_t(ngroupsU);
+    SSA_HIP(hipMemsetAsync(counter->Ptr, 0, 8, StreamHandle));
+
+    // next call on this step: size both table levels for what was seen
+    hint.TableCap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(ngroups) * 4), 1024), maxCap);
+    hint.LdsCap = ngroups <= 8 ? 16 : (ngroups <= 128 ? 256 : 0);
+
+    KeyedFinalizeArgs fa{};
+    fa.capacity = cap;
+    fa.t_key_lo = sink.t_key_lo;
+    fa.t_key_hi = sink.t_key_hi;
+    fa.t_acc = sink.t_acc;
+    fa.t_seen = sink.t_seen;
+    fa.counter = static_cast<unsigned long long*>(counter->Ptr);
+    fa.naggs = naggs;
+    fa.nkeys = nkeys;
+    fa.two_words = twoWords;
+    fa.hashed = hashed;
+    std::vector<Column> aggCols, keyCols;
+    aggCols.resize(size_t(naggsUser));
+    keyCols.resize(size_t(nkeys));
+    std::vector<BufferPtr> aggValid, aggRowIdx, keyValid;
+    aggValid.resize(size_t(naggsUser));
+    aggRowIdx.resize(size_t(naggsUser));
+    keyValid.resize(size_t(nkeys));
+    BufferPtr repRows;
+    for (int k = 0; k < naggs; ++k) {
+        fa.aggs[k] = sink.aggs[k];
+        if (k == naggsUser) {
+            repRows = Buffer::Alloc(size_t(ngroups) * 8 + 16);
+            if (!repRows) return Status::Hip("out of device memory");
+            fa.agg_row_index[k] = 1;
+            fa.agg_out_type[k] = T_U64;
+            fa.agg_vals[k] = repRows->Ptr;
+            continue;
+        }
+        const AggPlan& ap = plan.Aggs[size_t(k)];
+        Column& col = aggCols[size_t(k)];
+        col.Field.Type = ap.OutType;
+        col.Length = ngroups;
+        fa.agg_out_type[k] = ap.OutType;
+        if (ap.SomeInputColumn >= 0) {
+            aggRowIdx[size_t(k)] = Buffer::Alloc(size_t(ngroups) * 8 + 16);
+            if (!aggRowIdx[size_t(k)]) return Status::Hip("out of device memory");
+            fa.agg_row_index[k] = 1;
+            fa.agg_vals[k] = aggRowIdx[size_t(k)]->Ptr;
+            continue;
+        }
+        col.Values = Buffer::Alloc(size_t(ngroups) * TypeWidth(ap.OutType) + 16);
+        if (!col.Values) return Status::Hip("out of device memory");
+        fa.agg_vals[k] = col.Values->Ptr;
+        if (ap.Spec.kind != AGG_COUNT && ap.Spec.check_valid) {
+            aggValid[size_t(k)] = Buffer::Alloc(size_t(ngroups) + 16);
+            if (!aggValid[size_t(k)]) return Status::Hip("out of device memory");
+            fa.agg_valid_bytes[k] = static_cast<uint8_t*>(aggValid[size_t(k)]->Ptr);
+        }
+    }
+    for (int k = 0; k < nkeys; ++k) {
+        fa.keys[k] = sink.keys[k];
+        if (hashed) continue;
+        const KeyPlan& kp = plan.Keys[size_t(k)];
+        Column& col = keyCols[size_t(k)];
+        col.Field.Type = kp.Spec.type;
+        col.Length = ngroups;
+        col.Values = Buffer::Alloc(size_t(ngroups) * TypeWidth(kp.Spec.type) + 16);
+        if (!col.Values) return Status::Hip("out of device memory");
+        fa.key_vals[k] = col.Values->Ptr;
+        if (kp.Spec.nullable) {
+            keyValid[size_t(k)] = Buffer::Alloc(size_t(ngroups) + 16);
+            if (!keyValid[size_t(k)]) return Status::Hip("out of device memory");
+            fa.key_valid_bytes[k] = static_cast<uint8_t*>(keyValid[size_t(k)]->Ptr);
+        }
+    }
+    if (ngroups > 0) SSA_HIP(LaunchKeyedEmit(fa, StreamHandle));
+    for (int k = 0; k < naggsUser; ++k) {
+        const AggPlan& ap = plan.Aggs[size_t(k)];
+        if (ap.SomeInputColumn >= 0) {
+            SSA_RETURN_NOT_OK(GatherRows(in.Cols[size_t(ap.SomeInputColumn)], aggRowIdx[size_t(k)], ngroups, true, aggCols[size_t(k)]));
+        } else if (aggValid[size_t(k)]) {
+            SSA_RETURN_NOT_OK(PackValidity(aggValid[size_t(k)], ngroups, aggCols[size_t(k)]));
+        }
+    }
+    for (int k = 0; k < nkeys; ++k) {
+        const KeyPlan& kp = plan.Keys[size_t(k)];
+        if (hashed) {
+            SSA_RETURN_NOT_OK(GatherRows(in.Cols[size_t(kp.InputColumn)], repRows, ngroups, kp.Spec.nullable != 0, keyCols[size_t(k)]));
+        } else if (keyValid[size_t(k)]) {
+            SSA_RETURN_NOT_OK(PackValidity(keyValid[size_t(k)], ngroups, keyCols[size_t(k)]));
+        }
+    }
+
+    out = std::make_shared<Batch>();
+    out->Rows = ngroups;
+    for (const OutColumn& oc : plan.Outs) {
+        Column col = oc.Source == OutColumn::FROM_AGG ? aggCols[size_t(oc.Index)] : keyCols[size_t(oc.Index)];
+        const bool nullable = col.Field.Nullable;
+        if (oc.Source == OutColumn::FROM_KEY && plan.Keys[size_t(oc.Index)].InputColumn >= 0) {
+            col.Field = in.Cols[size_t(plan.Keys[size_t(oc.Index)].InputColumn)].Field;  // keeps decimal / timestamp parameters
+        }
+        col.Field.Name = oc.Name;
+        col.Field.Type = oc.Type;
+        col.Field.Nullable = nullable;
+        out->Cols.push_back(std::move(col));
+    }
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    return Status::OK();
 }
 
 Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out) {
@@ -1000,7 +1273,7 @@ Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPt
         case StepPlan::AGG_NOKEY:
             return RunNoKey(plan, *in, out);
         case StepPlan::AGG_KEYED:
-            return RunKeyed(plan, *in, out);
+            return RunKeyed(step, plan, *in, out);
         default:
             return Status::Invalid("internal: unexpected plan kind");
     }

@@ -99,18 +99,18 @@ public:
 private:
     Status ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
     Status RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out);
-    Status RunKeyed(const StepPlan& plan, const Batch& in, BatchPtr& out);
+    Status RunKeyed(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out);
     Status RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& in, BatchPtr& out);
     Status RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,
                            int64_t& selected);
     Status FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, ScanArgs& args, LaunchCfg& cfg,
                         int64_t& algoBytes);
-    Status CheckScanStatus();
+    Status CheckScanStatus(bool* tableFull = nullptr);
     Status CompactColumn(const Column& src, int64_t rows, const BufferPtr& bitmap, const BufferPtr& tileOffsets,
                          int64_t selected, Column& dst);
     Status MaterializeScalar(const OutColumn& oc, int64_t rows, Column& dst);
     Status PackValidity(const BufferPtr& validBytes, int64_t rows, Column& col);
-    Status GatherRows(const Column& src, const BufferPtr& rowIdx, int64_t n, Column& dst);
+    Status GatherRows(const Column& src, const BufferPtr& rowIdx, int64_t n, bool keepValidity, Column& dst);
     void ProfileBegin();
     void ProfileEnd(const char* kernel, int64_t algoBytes);
 
@@ -118,6 +118,12 @@ private:
     hipStream_t StreamHandle = nullptr;
     hipEvent_t EvStart = nullptr, EvStop = nullptr;
     BufferPtr StatusWord;   // device uint32
+    // Sizing of the two hash-table levels of a keyed step, learnt from its previous run (performance only).
+    struct KeyedHint {
+        int LdsCap = 16;
+        uint64_t TableCap = 4096;
+    };
+    std::map<const TProgramStep*, KeyedHint> KeyedHints;
 };
 
 }  // namespace ssa

@@ -1,4 +1,25 @@
-// Keyed aggregation kernels (placeholder translation unit while the scan path is brought up).
+// Keyed GROUP BY: the scan VM feeding a hash aggregation sink, and the kernels that turn the hash table
+// into output columns.
+//
+// The reference aggregates through a ClickHouse-derived hash aggregator, one batch at a time
+// (ydb/library/arrow_clickhouse/Aggregator.cpp:132-226 picks the hash method from the key columns,
+// Aggregator.cpp:228-330 executes a batch).  Here one fused pass evaluates the step's expressions and
+// feeds every passing row into a two-level table:
+//
+//   * level 1 lives in the workgroup's LDS and absorbs low-cardinality groupings entirely: each slot
+//     carries R replicas of every accumulator so that the lanes of a wave that hit the same group
+//     spread over R addresses instead of serialising on one;
+//   * level 2 is an open-addressing table in HBM.  Rows whose key does not fit level 1 go there
+//     directly; level 1 is merged into it once, when the workgroup has consumed its last tile.
+//
+// Keys are 128 bits (lo, hi).  Fixed-width keys of up to 119 bits in total are packed exactly (value
+// bits and, for the null-aware methods, one null flag per key), so the table compares keys, not
+// hashes, and the output key columns are decoded from the table.  Anything wider -- and every string
+// key -- is reduced to a 126-bit hash; those tables also keep the smallest row index of each group and
+// the output keys are gathered from that row of the input.
+//
+// HBM traffic of the scan is the referenced source columns once plus the table, which is tiny for the
+// groupings this path is for; the bound is HBM bandwidth.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -6,6 +27,541 @@
 
 namespace ssa {
 
-hipError_t ConfigureScanKernels(int) { return hipSuccess; }
+namespace {
+
+constexpr uint64_t kEmpty = ~0ull;        // lo word of a free slot (real keys keep bit 63 of lo clear)
+constexpr uint64_t kUnpublished = ~0ull;  // hi word of a slot whose owner has not stored it yet
+
+__device__ __forceinline__ uint64_t Mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xFF51AFD7ED558CCDull;
+    x ^= x >> 33;
+    x *= 0xC4CEB9FE1A85EC53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+// Order-preserving map double -> uint64 (so float min/max become integer atomics) and back.
+__device__ __forceinline__ uint64_t OrderedFromF64(uint64_t bits) {
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+}
+__device__ __forceinline__ uint64_t F64FromOrdered(uint64_t enc) {
+    return (enc >> 63) ? (enc & 0x7FFFFFFFFFFFFFFFull) : ~enc;
+}
+
+// What the tables hold for an untouched accumulator.
+__device__ __host__ inline uint64_t TableIdentity(int kind) {
+    switch (kind) {
+        case AGG_MIN_I: return uint64_t(INT64_MAX);
+        case AGG_MAX_I: return uint64_t(INT64_MIN);
+        case AGG_MIN_U: return ~0ull;
+        case AGG_MIN_F: return 0xFFF0000000000000ull;  // ordered(+inf)
+        case AGG_MAX_F: return 0x000FFFFFFFFFFFFFull;  // ordered(-inf)
+        default: return 0;
+    }
+}
+
+// Accumulator update.  The same code serves LDS and HBM accumulators: after inlining the compiler
+// knows the address space and picks ds_* or global_* atomics.
+__device__ __forceinline__ void AccUpdate(int kind, uint64_t* p, uint64_t v) {
+    switch (kind) {
+        case AGG_COUNT:
+        case AGG_SUM_I:
+            atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
+            break;
+        case AGG_SUM_F:
+            atomicAdd(reinterpret_cast<double*>(p), BitsToF64(v));
+            break;
+        case AGG_MIN_I:
+            atomicMin(reinterpret_cast<long long*>(p), static_cast<long long>(v));
+            break;
+        case AGG_MAX_I:
+            atomicMax(reinterpret_cast<long long*>(p), static_cast<long long>(v));
+            break;
+        case AGG_MIN_U:
+        case AGG_MIN_F:
+            atomicMin(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
+            break;
+        case AGG_MAX_U:
+        case AGG_MAX_F:
+            atomicMax(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
+            break;
+        default:
+            break;
+    }
+}
+
+// Merge of two table states of one aggregate (level-1 replicas; level 1 into level 2 goes through
+// AccUpdate because other workgroups update level 2 concurrently).
+__device__ __forceinline__ uint64_t TableCombine(int kind, uint64_t a, uint64_t b) {
+    switch (kind) {
+        case AGG_COUNT: case AGG_SUM_I: return a + b;
+        case AGG_SUM_F: return F64ToBits(BitsToF64(a) + BitsToF64(b));
+        case AGG_MIN_I: return int64_t(b) < int64_t(a) ? b : a;
+        case AGG_MAX_I: return int64_t(b) > int64_t(a) ? b : a;
+        case AGG_MIN_U: case AGG_MIN_F: return b < a ? b : a;
+        case AGG_MAX_U: case AGG_MAX_F: return b > a ? b : a;
+        default: return a;
+    }
+}
+
+// Find or claim the slot of key (lo, hi) in an open-addressing table of `mask + 1` slots, starting at
+// `start`.  A slot is claimed by a compare-and-swap on its lo word; the owner then publishes hi.  A
+// lane that finds its own lo with hi not yet published looks at the same slot again on the next trip
+// of the loop: the lanes of a wave take every trip together, so the owner's store has been issued by
+// then, and owners in other waves make progress on their own.  Returns -1 after `maxProbes` slots.
+__device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uint64_t mask, uint64_t start, uint64_t lo,
+                                               uint64_t hi, bool twoWords, uint32_t maxProbes) {
+    uint64_t s = start & mask;
+    uint32_t probes = 0;
+    while (probes < maxProbes) {
+        uint64_t cur = __hip_atomic_load(tLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmpty) {
+            cur = atomicCAS(reinterpret_cast<unsigned long long*>(tLo + s), static_cast<unsigned long long>(kEmpty),
+                            static_cast<unsigned long long>(lo));
+            if (cur == kEmpty) {
+                if (twoWords) __hip_atomic_store(tHi + s, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return int64_t(s);
+            }
+        }
+        if (cur == lo) {
+            if (!twoWords) return int64_t(s);
+            const uint64_t ch = __hip_atomic_load(tHi + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ch == hi) return int64_t(s);
+            if (ch == kUnpublished) continue;
+        }
+        s = (s + 1) & mask;
+        ++probes;
+    }
+    return -1;
+}
+
+// Hash of a string key: its length, then its bytes in 8-byte little-endian words.  Takes and returns
+// the two hash lanes by value so that the caller's key state stays in registers.
+struct HashPair {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ void AbsorbWord(HashPair& h, uint64_t w) {
+    h.lo = Mix64(h.lo ^ w);
+    h.hi = Mix64(h.hi + w * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull);
+}
+__device__ __noinline__ HashPair AbsorbString(HashPair h, const uint8_t* p, int32_t n) {
+    AbsorbWord(h, uint64_t(uint32_t(n)));
+    for (int32_t i = 0; i < n; i += 8) {
+        uint64_t w = 0;
+        const int32_t m = (n - i) < 8 ? (n - i) : 8;
+        for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[i + j]) << (8 * j);
+        AbsorbWord(h, w);
+    }
+    return h;
+}
+
+// ---- key construction ---------------------------------------------------------------------------------
+template <int U>
+struct KeyBuilder {
+    uint64_t lo[U], hi[U];
+    int pos;  // exact packing: bits used so far (wave-uniform)
+
+    __device__ __forceinline__ void Begin(bool hashed) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            lo[u] = hashed ? 0x243F6A8885A308D3ull : 0ull;
+            hi[u] = hashed ? 0x13198A2E03707344ull : 0ull;
+        }
+        pos = 0;
+    }
+    // exact: append the low `nbits` of `bits`
+    __device__ __forceinline__ void Append(int u, uint64_t bits, int nbits) {
+        (void)nbits;
+        if (pos < 64) {
+            lo[u] |= bits << pos;
+            if (pos > 0 && pos + nbits > 64) hi[u] |= bits >> (64 - pos);
+        } else {
+            hi[u] |= bits << (pos - 64);
+        }
+    }
+    // hashed: absorb one 64-bit word into both lanes of the hash
+    __device__ __forceinline__ void Absorb(int u, uint64_t w) {
+        HashPair h{lo[u], hi[u]};
+        AbsorbWord(h, w);
+        lo[u] = h.lo;
+        hi[u] = h.hi;
+    }
+    // Final table key: bit 63 of lo stays clear (so lo never equals the free marker) and hi never
+    // equals the unpublished marker: exact keys keep its top byte zero, hashed keys force 0b10 on top.
+    __device__ __forceinline__ void Finish(int u, bool hashed) {
+        if (hashed) {
+            lo[u] &= 0x7FFFFFFFFFFFFFFFull;
+            hi[u] = (hi[u] | 0x8000000000000000ull) & ~0x4000000000000000ull;
+        } else {
+            const uint64_t l = lo[u], h = hi[u];
+            lo[u] = l & 0x7FFFFFFFFFFFFFFFull;
+            hi[u] = (h << 1) | (l >> 63);
+        }
+    }
+};
+
+__device__ __forceinline__ uint64_t WidthMask(int nbits) { return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull); }
+
+}  // namespace
+
+// ---- sink: keyed aggregation ------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>) {
+    const ScanArgs& a = KernArgs<KeyedSink>().a;
+    const KeyedSink& s = KernArgs<KeyedSink>().s;
+    Machine<U> m(a);
+    const int naggs = s.naggs;
+    const int L = s.lds_cap, R = s.lds_rep;
+    const bool twoWords = s.two_words != 0, hashed = s.hashed != 0;
+    // level-1 table in the sink area of LDS: lo[L], hi[L], acc[naggs][L][R], seen[L]
+    uint64_t* lLo = reinterpret_cast<uint64_t*>(gLds + a.lds_sink_off);
+    uint64_t* lHi = lLo + L;
+    uint64_t* lAcc = lHi + L;
+    uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(naggs) * L * R);
+    for (int i = threadIdx.x; i < L; i += kBlock) {
+        lLo[i] = kEmpty;
+        lHi[i] = kUnpublished;
+        lSeen[i] = 0;
+    }
+    for (int k = 0; k < naggs; ++k) {
+        const uint64_t ident = TableIdentity(s.aggs[k].kind);
+        for (int i = threadIdx.x; i < L * R; i += kBlock) lAcc[size_t(k) * L * R + i] = ident;
+    }
+    // (the barriers of the first BeginTile order this initialisation before any use)
+    const int rep = threadIdx.x & (R - 1);
+    const uint32_t ldsProbes = L < 8 ? uint32_t(L) : 8u;
+
+    const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        m.BeginTile(tile * (kBlock * U));
+        m.Run();
+        if (m.P == 0) continue;
+
+        // keys of the lane's rows
+        KeyBuilder<U> kb;
+        kb.Begin(hashed);
+        for (int k = 0; k < s.nkeys; ++k) {
+            const KeySpec ks = s.keys[k];
+            if (ks.col >= 0) {
+                // string key (always hashed); the validity of the column is not part of these keys
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if ((m.P >> u) & 1u) {
+                        const uint8_t* p;
+                        int32_t n;
+                        m.StringAt(ks.col, m.Row(u), p, n);
+                        const HashPair h = AbsorbString(HashPair{kb.lo[u], kb.hi[u]}, p, n);
+                        kb.lo[u] = h.lo;
+                        kb.hi[u] = h.hi;
+                    }
+                }
+                continue;
+            }
+            Val<U> x;
+            m.FetchOperand(ks.fetch_kind, ks.fetch_payload, x);
+            const int nbits = 8 * TypeWidth(ks.type);
+            const uint64_t wmask = WidthMask(nbits);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool isNull = ks.nullable && !((x.ok >> u) & 1u);
+                const uint64_t bits = isNull ? 0ull : (PayloadToStored(x.v[u], ks.type) & wmask);
+                if (hashed) {
+                    kb.Absorb(u, bits);
+                    if (ks.nullable) kb.Absorb(u, isNull ? 1ull : 0ull);
+                } else {
+                    kb.Append(u, bits, nbits);
+                }
+            }
+            if (!hashed) {
+                kb.pos += nbits;
+                if (ks.nullable) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) kb.Append(u, ((x.ok >> u) & 1u) ? 0ull : 1ull, 1);
+                    kb.pos += 1;
+                }
+            }
+        }
+
+        // slots: >= 0 level 1, <= -2 level 2 (slot g as -2 - g), -1 no row
+        int64_t slot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            slot[u] = -1;
+            if (!((m.P >> u) & 1u)) continue;
+            kb.Finish(u, hashed);
+            const uint64_t h = Mix64(kb.lo[u] ^ Mix64(kb.hi[u]));
+            int64_t sl = -1;
+            if (L > 0) sl = TableUpsert(lLo, lHi, uint64_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords, ldsProbes);
+            if (sl < 0) {
+                const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, h >> 20, kb.lo[u], kb.hi[u], twoWords, 4096u);
+                if (g < 0) {
+                    m.err |= SCAN_TABLE_FULL;
+                    m.P &= ~(1u << u);
+                } else {
+                    sl = -2 - g;
+                }
+            }
+            slot[u] = sl;
+        }
+
+        for (int k = 0; k < naggs; ++k) {
+            const AggSpec spec = s.aggs[k];
+            uint32_t live = m.P;
+            Val<U> x;
+            if (k == s.rep_row_agg) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) x.v[u] = uint64_t(m.Row(u));
+            } else if (spec.reg != -1) {
+                m.FetchOperand(spec.fetch_kind, spec.fetch_payload, x);
+                if (spec.check_valid) live &= x.ok;
+            }
+            if (live == 0) continue;
+            const int kind = spec.kind;
+            if (kind == AGG_COUNT) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) x.v[u] = 1;
+            } else if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
+                // fmin / fmax semantics: a NaN never replaces a number (and the identity is an infinity)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double d = BitsToF64(x.v[u]);
+                    if (d != d) live &= ~(1u << u);
+                    x.v[u] = OrderedFromF64(x.v[u]);
+                }
+            }
+            uint64_t* accK = lAcc + size_t(k) * L * R;
+            uint64_t* tabK = s.t_acc + size_t(k) * (s.table_mask + 1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!((live >> u) & 1u)) continue;
+                if (slot[u] >= 0) {
+                    AccUpdate(kind, accK + slot[u] * R + rep, x.v[u]);
+                } else {
+                    AccUpdate(kind, tabK + (-2 - slot[u]), x.v[u]);
+                }
+            }
+            if (spec.check_valid) {
+                // a nullable argument was seen for the group: set once
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!((m.P & x.ok) >> u & 1u)) continue;
+                    if (slot[u] >= 0) {
+                        if (!((lSeen[slot[u]] >> k) & 1u)) atomicOr(lSeen + slot[u], 1u << k);
+                    } else {
+                        uint32_t* g = s.t_seen + (-2 - slot[u]);
+                        if (!((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> k) & 1u)) atomicOr(g, 1u << k);
+                    }
+                }
+            }
+        }
+    }
+
+    // merge level 1 into level 2
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += kBlock) {
+        const uint64_t lo = lLo[i];
+        if (lo == kEmpty) continue;
+        const uint64_t hi = twoWords ? lHi[i] : 0ull;
+        const uint64_t h = Mix64(lo ^ Mix64(twoWords ? hi : 0ull));
+        const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, h >> 20, lo, hi, twoWords, 4096u);
+        if (g < 0) {
+            m.err |= SCAN_TABLE_FULL;
+            continue;
+        }
+        for (int k = 0; k < naggs; ++k) {
+            const int kind = s.aggs[k].kind;
+            const uint64_t* src = lAcc + (size_t(k) * L + i) * R;
+            uint64_t v = src[0];
+            for (int r = 1; r < R; ++r) v = TableCombine(kind, v, src[r]);
+            if (v != TableIdentity(kind)) AccUpdate(kind, s.t_acc + size_t(k) * (s.table_mask + 1) + g, v);
+        }
+        const uint32_t seen = lSeen[i];
+        if (seen) atomicOr(s.t_seen + g, seen);
+    }
+    m.ReportErrors();
+}
+
+namespace {
+
+// ---- table -> output columns -------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void KeyedCountKernel(const uint64_t* tLo, uint64_t capacity, unsigned long long* count) {
+    unsigned long long c = 0;
+    for (uint64_t i = uint64_t(blockIdx.x) * kBlock + threadIdx.x; i < capacity; i += uint64_t(gridDim.x) * kBlock) {
+        c += tLo[i] != kEmpty ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+__global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArgs) {
+    const KeyedFinalizeArgs& f = KernArgsAs<KeyedFinalizeArgs>();
+    for (uint64_t i = uint64_t(blockIdx.x) * kBlock + threadIdx.x; i < f.capacity; i += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t klo = f.t_key_lo[i];
+        if (klo == kEmpty) continue;
+        const int64_t g = int64_t(atomicAdd(f.counter, 1ull));  // output order is unspecified
+        const uint32_t seen = f.t_seen[i];
+        for (int k = 0; k < f.naggs; ++k) {
+            const int kind = f.aggs[k].kind;
+            uint64_t v = f.t_acc[size_t(k) * f.capacity + i];
+            bool valid = true;
+            if (f.agg_row_index[k]) {
+                valid = v != ~0ull;  // smallest row with a non-null argument, none -> null
+            } else {
+                if (kind == AGG_MIN_F || kind == AGG_MAX_F) v = F64FromOrdered(v);
+                if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> k) & 1u;
+                if (!valid) v = 0;
+                v = PayloadToStored(v, f.agg_out_type[k]);
+            }
+            if (f.agg_vals[k] != nullptr) {
+                StoreTyped(f.agg_vals[k], f.agg_row_index[k] ? 8 : TypeWidth(f.agg_out_type[k]), g, v);
+                if (f.agg_valid_bytes[k] != nullptr) f.agg_valid_bytes[k][g] = valid ? 1 : 0;
+            }
+        }
+        if (!f.hashed) {
+            // undo Finish(): 127 packed bits
+            const uint64_t khi = f.two_words ? f.t_key_hi[i] : 0ull;
+            const uint64_t lo = klo | (khi << 63), hi = khi >> 1;
+            int pos = 0;
+            for (int k = 0; k < f.nkeys; ++k) {
+                const int type = f.keys[k].type;
+                const int nbits = 8 * TypeWidth(type);
+                uint64_t bits;
+                if (pos < 64) {
+                    bits = lo >> pos;
+                    if (pos > 0 && pos + nbits > 64) bits |= hi << (64 - pos);
+                } else {
+                    bits = hi >> (pos - 64);
+                }
+                bits &= WidthMask(nbits);
+                pos += nbits;
+                StoreTyped(f.key_vals[k], TypeWidth(type), g, bits);
+                if (f.keys[k].nullable) {
+                    const uint64_t isNull = pos < 64 ? (lo >> pos) & 1ull : (hi >> (pos - 64)) & 1ull;
+                    pos += 1;
+                    if (f.key_valid_bytes[k] != nullptr) f.key_valid_bytes[k][g] = isNull ? 0 : 1;
+                }
+            }
+        }
+    }
+}
+
+// ---- gathers (representative rows -> key columns, row indices -> some() values) --------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void GatherFixedKernel(const T* src, const uint8_t* srcValid, int64_t srcValidOff,
+                                                          const uint64_t* rows, int64_t n, T* dst, uint8_t* dstValidBytes) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) {
+        const uint64_t r = rows[i];
+        if (r == ~0ull) {
+            dst[i] = T{};
+            if (dstValidBytes != nullptr) dstValidBytes[i] = 0;
+        } else {
+            dst[i] = src[r];
+            if (dstValidBytes != nullptr) dstValidBytes[i] = srcValid ? uint8_t(LoadBit(srcValid, int64_t(r) + srcValidOff)) : 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void GatherValidityKernel(const uint8_t* srcValid, int64_t srcValidOff, const uint64_t* rows,
+                                                             int64_t n, uint8_t* dstValidBytes) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) {
+        const uint64_t r = rows[i];
+        dstValidBytes[i] = r == ~0ull ? 0 : (srcValid ? uint8_t(LoadBit(srcValid, int64_t(r) + srcValidOff)) : 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void GatherStringLensKernel(const int32_t* offsets, const uint64_t* rows, int64_t n,
+                                                               int32_t* outLens) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) {
+        const uint64_t r = rows[i];
+        outLens[i] = r == ~0ull ? 0 : offsets[r + 1] - offsets[r];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void GatherStringBytesKernel(const int32_t* offsets, const uint8_t* chars,
+                                                                const uint64_t* rows, int64_t n, const int32_t* newOffsets,
+                                                                uint8_t* outChars) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) {
+        const uint64_t r = rows[i];
+        if (r == ~0ull) continue;
+        const int32_t b = offsets[r], len = offsets[r + 1] - b, o = newOffsets[i];
+        for (int32_t j = 0; j < len; ++j) outChars[o + j] = chars[b + j];
+    }
+}
+
+struct G128 {
+    uint64_t lo, hi;
+};
+
+int GridFor(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return int(g);
+}
+
+}  // namespace
+
+uint64_t KeyedTableIdentity(int aggKind) { return TableIdentity(aggKind); }
+
+hipError_t LaunchScanKeyed(const ScanArgs& a, const KeyedSink& s, LaunchCfg cfg) {
+    KArgs<KeyedSink> k{a, s};
+    hipLaunchKernelGGL((ScanKeyedKernel<kRowsPerThread>), dim3(cfg.grid), dim3(kBlock), cfg.lds_bytes, cfg.stream, k);
+    return hipGetLastError();
+}
+
+hipError_t ConfigureKeyedKernels(int maxLdsBytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanKeyedKernel<kRowsPerThread>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+}
+
+hipError_t LaunchKeyedCount(const uint64_t* tKeyLo, uint64_t capacity, unsigned long long* count, hipStream_t st) {
+    hipLaunchKernelGGL(KeyedCountKernel, dim3(GridFor(int64_t(capacity))), dim3(kBlock), 0, st, tKeyLo, capacity, count);
+    return hipGetLastError();
+}
+
+hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(KeyedEmitKernel, dim3(GridFor(int64_t(a.capacity))), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t LaunchGatherFixed(const void* src, const uint8_t* srcValid, int64_t srcValidOff, int width, const uint64_t* rows,
+                             int64_t n, void* dst, uint8_t* dstValidBytes, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int grid = GridFor(n);
+#define SSA_GATHER(T) \
+    hipLaunchKernelGGL((GatherFixedKernel<T>), dim3(grid), dim3(kBlock), 0, st, (const T*)src, srcValid, srcValidOff, rows, n, (T*)dst, dstValidBytes)
+    switch (width) {
+        case 1: SSA_GATHER(uint8_t); break;
+        case 2: SSA_GATHER(uint16_t); break;
+        case 4: SSA_GATHER(uint32_t); break;
+        case 8: SSA_GATHER(uint64_t); break;
+        case 16: SSA_GATHER(G128); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef SSA_GATHER
+    return hipGetLastError();
+}
+
+hipError_t LaunchGatherValidity(const uint8_t* srcValid, int64_t srcValidOff, const uint64_t* rows, int64_t n,
+                                uint8_t* dstValidBytes, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(GatherValidityKernel, dim3(GridFor(n)), dim3(kBlock), 0, st, srcValid, srcValidOff, rows, n, dstValidBytes);
+    return hipGetLastError();
+}
+
+hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, int64_t n, int32_t* outLens, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(GatherStringLensKernel, dim3(GridFor(n)), dim3(kBlock), 0, st, offsets, rows, n, outLens);
+    return hipGetLastError();
+}
+
+hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
+                                   const int32_t* newOffsets, uint8_t* outChars, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(GatherStringBytesKernel, dim3(GridFor(n)), dim3(kBlock), 0, st, offsets, chars, rows, n, newOffsets, outChars);
+    return hipGetLastError();
+}
 
 }  // namespace ssa

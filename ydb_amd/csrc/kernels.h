@@ -44,18 +44,18 @@ struct ProjectSink {
 // Group-by: open-addressing table in global memory (the "spill table"), fronted by a small
 // per-workgroup table in LDS that absorbs the hot groups.
 struct KeyedSink {
-    int32_t naggs;
+    int32_t naggs;           // including the representative-row aggregate of hashed keys
     int32_t nkeys;
-    AggSpec aggs[kMaxAggs];
+    AggSpec aggs[kMaxAggs + 1];
     KeySpec keys[kMaxKeys];
-    int32_t key_words;       // 1: 64-bit key, 2: 128-bit key
-    int32_t hashed;          // keys may exceed 15 bytes: rows carry a representative row index
-    int32_t lds_cap;         // LDS table capacity (power of two, 0 = bypass LDS)
-    int32_t lds_rep;         // accumulator replication factor inside LDS (power of two)
-    uint64_t table_mask;     // global capacity - 1
-    uint64_t* t_key_lo;      // [cap] ~0 = empty
-    uint64_t* t_key_hi;      // [cap] (key_words == 2)
-    uint64_t* t_rep_row;     // [cap] min row index of the group (hashed keys)
+    int32_t two_words;       // keys use the hi word
+    int32_t hashed;          // keys are 126-bit hashes (strings / more than 119 key bits)
+    int32_t rep_row_agg;     // index of the MIN(row index) aggregate kept for hashed keys, else -1
+    int32_t lds_cap;         // level-1 (LDS) table slots, power of two, 0 = none
+    int32_t lds_rep;         // accumulator replicas per level-1 slot, power of two
+    uint64_t table_mask;     // level-2 capacity - 1
+    uint64_t* t_key_lo;      // [cap] ~0 = free
+    uint64_t* t_key_hi;      // [cap] ~0 = not yet published
     uint64_t* t_acc;         // [naggs][cap]
     uint32_t* t_seen;        // [cap] bit k: aggregate k saw a non-null argument
 };
@@ -104,30 +104,33 @@ struct KeyedFinalizeArgs {
     uint64_t capacity;
     const uint64_t* t_key_lo;
     const uint64_t* t_key_hi;
-    const uint64_t* t_rep_row;
     const uint64_t* t_acc;
     const uint32_t* t_seen;
+    unsigned long long* counter;      // zeroed; ends as the number of groups
     int32_t naggs;
     int32_t nkeys;
-    int32_t key_words;
+    int32_t two_words;
     int32_t hashed;
-    AggSpec aggs[kMaxAggs];
-    int32_t agg_out_type[kMaxAggs];
+    AggSpec aggs[kMaxAggs + 1];
+    int32_t agg_out_type[kMaxAggs + 1];
+    int32_t agg_row_index[kMaxAggs + 1];  // the accumulator is a row index (some(), representative row): raw uint64 out
     KeySpec keys[kMaxKeys];
-    // outputs (ngroups rows)
-    void* agg_vals[kMaxAggs];
-    uint8_t* agg_valid_bytes[kMaxAggs];
-    void* key_vals[kMaxKeys];         // fixed-width keys decoded from the packed key
+    // outputs (one row per group)
+    void* agg_vals[kMaxAggs + 1];
+    uint8_t* agg_valid_bytes[kMaxAggs + 1];
+    void* key_vals[kMaxKeys];         // exact keys only: decoded from the table
     uint8_t* key_valid_bytes[kMaxKeys];
-    uint64_t* group_rep_row;          // hashed keys: representative row per output group
-    uint64_t* group_slot;             // table slot per output group
 };
-// Pass 1: count occupied slots per block; pass 2 (after the scan) writes group rows in slot order.
-hipError_t LaunchKeyedCount(const uint64_t* t_key_lo, uint64_t capacity, uint32_t* block_counts, int nblocks, hipStream_t st);
-hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, const int64_t* block_offsets, int nblocks, hipStream_t st);
+uint64_t KeyedTableIdentity(int aggKind);  // initial value of a level-2 accumulator
+hipError_t ConfigureKeyedKernels(int maxLdsBytes);
+hipError_t LaunchKeyedCount(const uint64_t* t_key_lo, uint64_t capacity, unsigned long long* count, hipStream_t st);
+hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st);
 // Gather rows of a fixed-width column by 64-bit row index (idx == ~0 -> zero + invalid).
 hipError_t LaunchGatherFixed(const void* src, const uint8_t* src_valid, int64_t src_valid_off, int width,
                              const uint64_t* rows, int64_t n, void* dst, uint8_t* dst_valid_bytes, hipStream_t st);
+// Validity bits of the gathered rows as one byte per row (no bitmap: all valid).
+hipError_t LaunchGatherValidity(const uint8_t* src_valid, int64_t src_valid_off, const uint64_t* rows, int64_t n,
+                                uint8_t* dst_valid_bytes, hipStream_t st);
 hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, int64_t n, int32_t* out_lens, hipStream_t st);
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);

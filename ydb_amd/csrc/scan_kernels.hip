@@ -466,6 +466,17 @@ hipError_t LaunchScanProject(const ScanArgs& a, const ProjectSink& s, LaunchCfg 
     SSA_LAUNCH_SCAN(ScanProjectKernel, ProjectSink, a, s, cfg);
 }
 
+hipError_t ConfigureScanKernels(int maxLdsBytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanNoKeyKernel<kRowsPerThread>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanFilterKernel<kRowsPerThread>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanProjectKernel<kRowsPerThread>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    if (e == hipSuccess) e = ConfigureKeyedKernels(maxLdsBytes);
+    return e;
+}
+
 hipError_t LaunchNoKeyFinalize(const NoKeySink& s, int grid, uint64_t* outVals, uint8_t* outValid, hipStream_t st) {
     FinalizeArgs fa{s, grid, outVals, outValid};
     hipLaunchKernelGGL(NoKeyFinalizeKernel, dim3(1), dim3(kBlock), 0, st, fa);
