@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Scan-pushdown benchmark: rows/s of the SSA program executor over an HBM-resident lineitem.
+
+    python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q6] [--rows R]
+
+One step = one pass of the program (TPC-H Q1 by default: filter, two computed columns, nine aggregates
+grouped by (l_returnflag, l_linestatus)) over this rank's SF100 lineitem shard, result on the host.  With
+N > 1 (one process per GPU, launched by torch.distributed.run) every rank scans its own SF100-sized
+row range and the partial aggregates are merged through one RCCL all-gather plus a merge program, all
+inside the timed region; `value` is the rows all ranks scanned divided by the slowest rank's time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+
+
+def cpu_baseline(workload: str, seconds_target: float = 15.0):
+    """Times the CPU oracle (a port of the reference's op-at-a-time execution) on a bounded sample."""
+    try:
+        from oracle import ssa_oracle
+    except Exception as e:  # oracle library not built
+        return {"value": None, "unit": "rows/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    from ydb_amd import tpch
+    import numpy as np
+
+    codes = workload == "q1_codes"
+    if workload == "q6":
+        prog, cols = tpch.q6_program(), tpch.Q6_COLUMNS
+    else:
+        prog, cols = tpch.q1_program(codes), (tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8)
+    batch_rows = 1_000_000  # the reference hands the program batches of about this size
+    li = tpch.lineitem_host(0, batch_rows)
+    batch = {c: li[c] for c in cols}
+    orc = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog)
+    hb = orc.import_batch(batch)
+    orc.apply_imported(hb)  # warm
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        orc.apply_imported(hb)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or n >= 400:
+            break
+    return {"value": n * batch_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{n} x {batch_rows}-row batches of the same synthetic lineitem, {dt:.1f} s, one thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6"])
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: TPC-H SF100 lineitem)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ydb_amd import tpch
+    from ydb_amd.shard import ShardedScan
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the scan kernels have no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rows = args.rows or tpch.SF100_ROWS
+    codes = args.workload == "q1_codes"
+    if args.workload == "q6":
+        prog, cols, bpr = tpch.q6_program(), tpch.Q6_COLUMNS, tpch.Q6_BYTES_PER_ROW
+        name = "TPC-H Q6"
+    else:
+        prog = tpch.q1_program(codes)
+        cols = tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8
+        bpr = tpch.Q1_BYTES_PER_ROW_CODES if codes else tpch.Q1_BYTES_PER_ROW_UTF8
+        name = "TPC-H Q1" + (" (1-byte flag codes)" if codes else " (utf8 flags)")
+    li = tpch.DeviceLineitem(rows, device=local_rank, row0=rank * rows,
+                             utf8_flags=(args.workload == "q1"), code_flags=codes)
+    scan = ShardedScan(prog, tpch.LINEITEM_RESOLVER, device=local_rank)
+    batch = li.batch(cols)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    result = None
+    for _ in range(args.warmup):
+        result = scan.run(batch, gather_device=dev)
+    scan.local.EnableProfile(True)
+    scan.local.ReadProfile()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = scan.run(batch, gather_device=dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches, algo_bytes = scan.local.ReadProfile()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_rows = rows * world * args.steps
+        avg_kernel_s = (kernel_ms / 1e3) / max(1, launches)
+        achieved = (algo_bytes / max(1, launches)) / avg_kernel_s / 1e9 if launches else 0.0
+        out = {
+            "metric": "rows/sec scanned + % HBM roofline, TPC-H Q1/Q6 SF100 at 1/2/4/8 MI355X",
+            "value": total_rows / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{name}, SF100-sized lineitem shard per GPU ({rows} rows), whole shard as one HBM-resident batch",
+                       "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr,
+                       "groups": len(next(iter(result.values())).valid) if result else 0,
+                       "parallelism": f"row-range shards x{world}, partial aggregates merged by RCCL all-gather + merge program"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "ScanKeyedKernel" if args.workload != "q6" else "ScanNoKeyKernel",
+                         "avg_kernel_ms": 1e3 * avg_kernel_s, "launches": launches,
+                         "algorithmic_bytes_per_launch": algo_bytes // max(1, launches)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+"""Row-range sharding of a scan across the GPUs of one node and the merge of per-shard partial aggregates.
+
+A column table is already split into shards that scan independently
+(ydb/core/tx/columnshard/columnshard__scan.cpp:300-340 runs the program per batch and ships the
+partial aggregates to the compute actor, which merges them).  With one process per GPU each rank runs the
+program over its own rows; the only exchange is the small table of partial aggregates:
+
+  * every rank serialises its result batch into one byte tensor,
+  * one all-gather (RCCL over xGMI on GPUs, gloo on CPU) replicates the partial tables,
+  * the partial tables are concatenated and reduced by a *merge program* -- an SSA GroupBy over the
+    partial columns (SUM of sums and counts, MIN of mins, MAX of maxes, SOME of somes) with the same keys
+    -- which runs through the same GPU executor as any other program.
+
+High-cardinality groupings would instead hash-partition the partial tables with an all-to-all so that
+each rank merges 1/N of the groups; `partition_of_keys` provides the rank assignment for that path.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .arrow_c import Col, ResultColumn
+from .ssa_pb import AGG, Aggregate, Column, GroupBy, Program, Projection
+
+Resolver = Sequence[Tuple[int, str]]
+
+_PARTIAL_PREFIX = "partial:"
+_MERGE_ID_BASE = 1_000_000
+
+
+def _column_name(c, names: Dict[int, str]) -> str:
+    """Name of a program column the way TProgramBuilder derives it (ydb/core/tx/program/program.cpp:60-90):
+    the resolver's name for a table column, the explicit name, else the decimal id."""
+    if isinstance(c, Column):
+        if c.name is not None:
+            return c.name
+        c = c.id
+    if isinstance(c, str):
+        return c
+    return names.get(int(c), str(int(c)))
+
+
+def last_group_by(program: Program) -> Optional[GroupBy]:
+    gb = None
+    for cmd in program.commands:
+        if isinstance(cmd, GroupBy):
+            gb = cmd
+    return gb
+
+
+def merge_program(program: Program, resolver: Resolver) -> Tuple[Program, List[Tuple[int, str]]]:
+    """Program + resolver that reduce concatenated partial results of `program` to its final result.
+
+    Partial aggregate columns are fed in under the name "partial:<name>" so that the merged aggregate can
+    carry the original name; key columns keep their names."""
+    names = {i: n for i, n in resolver}
+    gb = last_group_by(program)
+    if gb is None:
+        raise ValueError("program has no GroupBy: shards are concatenated, not merged")
+    merge_of = {AGG.SUM: AGG.SUM, AGG.COUNT: AGG.SUM, AGG.MIN: AGG.MIN, AGG.MAX: AGG.MAX, AGG.SOME: AGG.SOME}
+    out_resolver: List[Tuple[int, str]] = []
+    aggs = []
+    next_id = _MERGE_ID_BASE
+    for a in gb.aggregates:
+        name = _column_name(a.column, names)
+        out_resolver.append((next_id, _PARTIAL_PREFIX + name))
+        out_col = a.column if isinstance(a.column, Column) else Column(id=a.column) if isinstance(a.column, int) else Column(name=a.column)
+        aggs.append(Aggregate(out_col, merge_of[a.id], [next_id]))
+        next_id += 1
+    keys = []
+    for k in gb.keys:
+        name = _column_name(k, names)
+        out_resolver.append((next_id, name))
+        keys.append(next_id)
+        next_id += 1
+    merged = Program(version=program.version).group_by(aggs, keys=keys)
+    # a trailing projection of the original program applies to the merged result as well
+    tail = program.commands[-1]
+    if isinstance(tail, Projection):
+        merged.project([_column_name(c, names) for c in tail.columns])
+    return merged, out_resolver
+
+
+def partial_batch(parts: Sequence[Dict[str, ResultColumn]], program: Program, resolver: Resolver) -> Dict[str, Col]:
+    """Concatenates per-shard results column-wise into the input batch of the merge program."""
+    names = {i: n for i, n in resolver}
+    gb = last_group_by(program)
+    agg_names = [_column_name(a.column, names) for a in gb.aggregates]
+    key_names = [_column_name(k, names) for k in gb.keys]
+    out: Dict[str, Col] = {}
+    for name in agg_names + key_names:
+        cols = [p[name] for p in parts]
+        valid = np.concatenate([np.asarray(c.valid, dtype=np.bool_) for c in cols]) if cols else np.zeros(0, np.bool_)
+        if isinstance(cols[0].values, list):
+            vals: List[Optional[bytes]] = []
+            for c in cols:
+                vals.extend(v if ok else None for v, ok in zip(c.values, c.valid))
+            col = Col(vals, type=cols[0].type)
+        else:
+            vals_np = np.concatenate([np.asarray(c.values) for c in cols])
+            col = Col(vals_np, valid=None if valid.all() else valid, type=cols[0].type)
+        out[(_PARTIAL_PREFIX + name) if name in agg_names else name] = col
+    return out
+
+
+# ---- wire format of a result batch (all-gather payload) --------------------------------------------------
+def pack_result(result: Dict[str, ResultColumn]) -> bytes:
+    out = [struct.pack("<I", len(result))]
+    for key, c in result.items():
+        name = c.name.encode()
+        typ = c.type.encode()
+        n = len(c.valid)
+        out.append(struct.pack("<HHq", len(name), len(typ), n))
+        out.append(name)
+        out.append(typ)
+        out.append(np.asarray(c.valid, dtype=np.uint8).tobytes())
+        if isinstance(c.values, list):
+            lens = np.array([len(v) for v in c.values], dtype=np.int32)
+            out.append(lens.tobytes())
+            out.append(b"".join(bytes(v) for v in c.values))
+        else:
+            out.append(np.ascontiguousarray(c.values).tobytes())
+    return b"".join(out)
+
+
+def unpack_result(data: bytes) -> Dict[str, ResultColumn]:
+    from .arrow_c import _TYPES
+    pos = 0
+    (ncols,) = struct.unpack_from("<I", data, pos)
+    pos += 4
+    out: Dict[str, ResultColumn] = {}
+    for _ in range(ncols):
+        ln, lt, n = struct.unpack_from("<HHq", data, pos)
+        pos += 12
+        name = data[pos:pos + ln].decode()
+        pos += ln
+        typ = data[pos:pos + lt].decode()
+        pos += lt
+        valid = np.frombuffer(data, dtype=np.uint8, count=n, offset=pos).astype(np.bool_)
+        pos += n
+        if typ in ("string", "binary"):
+            lens = np.frombuffer(data, dtype=np.int32, count=n, offset=pos)
+            pos += 4 * n
+            vals = []
+            for l in lens:
+                vals.append(data[pos:pos + int(l)])
+                pos += int(l)
+            col = ResultColumn(name, typ, vals, valid)
+        else:
+            dt = np.dtype(_TYPES[typ][1])
+            vals_np = np.frombuffer(data, dtype=dt, count=n, offset=pos).copy()
+            pos += n * dt.itemsize
+            col = ResultColumn(name, typ, vals_np, valid)
+        key = name
+        while key in out:
+            key += "'"
+        out[key] = col
+    return out
+
+
+def all_gather_results(result: Dict[str, ResultColumn], device=None) -> List[Dict[str, ResultColumn]]:
+    """Replicates every rank's partial table on every rank: one size all-gather, one payload all-gather."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    payload = pack_result(result)
+    dev = device if device is not None else torch.device("cpu")
+    size = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    cap = max(int(s.item()) for s in sizes)
+    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    return [unpack_result(b[:int(s.item())].cpu().numpy().tobytes()) for b, s in zip(bufs, sizes)]
+
+
+def partition_of_keys(key_hashes: np.ndarray, world: int) -> np.ndarray:
+    """Rank that owns each group in the hash-partitioned (all-to-all) merge of high-cardinality groupings."""
+    h = np.asarray(key_hashes, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = (h ^ (h >> np.uint64(33))) * np.uint64(0xFF51AFD7ED558CCD)
+        h = h ^ (h >> np.uint64(33))
+    return (h % np.uint64(world)).astype(np.int64)
+
+
+class ShardedScan:
+    """One rank of a row-range sharded scan: run the program on the local shard, merge across ranks."""
+
+    def __init__(self, program: Program, resolver: Resolver, device: int = 0):
+        from .program import ProgramContainer
+
+        self.program = program
+        self.resolver = list(resolver)
+        self.local = ProgramContainer(device)
+        ok, err = self.local.Init(self.resolver, program)
+        if not ok:
+            raise ValueError(err)
+        self.merge = None
+        if last_group_by(program) is not None:
+            mp, mr = merge_program(program, resolver)
+            self.merge_resolver = mr
+            self.merge = ProgramContainer(device)
+            ok, err = self.merge.Init(mr, mp)
+            if not ok:
+                raise ValueError(err)
+
+    def run(self, batch, gather_device=None) -> Dict[str, ResultColumn]:
+        """Local scan (HBM-resident `batch`), then -- when torch.distributed is initialised with more than one
+        rank -- the all-gather of the partial tables and the merge program."""
+        import torch.distributed as dist
+
+        partial = self.local.Export(self.local.ApplyDevice(batch))
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return partial
+        parts = all_gather_results(partial, gather_device)
+        if self.merge is None:
+            raise ValueError("sharded scan without aggregation: results stay on their shards")
+        return self.merge.ApplyProgram(partial_batch(parts, self.program, self.resolver))
