@@ -1,0 +1,318 @@
+"""ctypes front end of the CPU oracle (libssa_oracle.so).  TEST INFRASTRUCTURE -- the GPU product never imports this.
+
+Inputs are the same dictionaries the product's host batches are built from: name -> numpy array, list of
+str / bytes / None, or any object with the attributes `values, valid, type, offset, dictionary, decimal`
+(ydb_amd.arrow_c.Col has them).  A sliced column (offset != 0) is cut here and a dictionary column is decoded
+here, because the reference's executor only ever sees plain arrays of the slice
+(ydb/core/formats/arrow/arrow_helpers.cpp:987-1016, ydb/core/formats/arrow/dictionary/conversion.h:13-15).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libssa_oracle.so")
+
+TYPE_IDS = {"bool": 1, "int8": 2, "int16": 3, "int32": 4, "int64": 5, "uint8": 6, "uint16": 7, "uint32": 8, "uint64": 9,
+            "float": 10, "double": 11, "timestamp": 12, "duration": 13, "string": 14, "binary": 15, "decimal128": 16}
+TYPE_NAMES = {v: k for k, v in TYPE_IDS.items()}
+_NP = {"bool": np.uint8, "int8": np.int8, "int16": np.int16, "int32": np.int32, "int64": np.int64, "uint8": np.uint8,
+       "uint16": np.uint16, "uint32": np.uint32, "uint64": np.uint64, "float": np.float32, "double": np.float64,
+       "timestamp": np.int64, "duration": np.int64}
+_NUMPY_TO_TYPE = {np.dtype(np.bool_): "bool", np.dtype(np.int8): "int8", np.dtype(np.uint8): "uint8",
+                  np.dtype(np.int16): "int16", np.dtype(np.uint16): "uint16", np.dtype(np.int32): "int32",
+                  np.dtype(np.uint32): "uint32", np.dtype(np.int64): "int64", np.dtype(np.uint64): "uint64",
+                  np.dtype(np.float32): "float", np.dtype(np.float64): "double"}
+
+
+class OrcCol(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("type", ctypes.c_int32), ("n", ctypes.c_int64), ("values", ctypes.c_void_p),
+                ("valid", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("chars", ctypes.c_void_p)]
+
+
+def build(force: bool = False) -> str:
+    """Compiles the oracle with g++ (seconds).  Returns the library path."""
+    src = os.path.join(_HERE, "ssa_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        lib = ctypes.CDLL(_LIB_PATH)
+        lib.orc_program_create.restype = ctypes.c_void_p
+        lib.orc_program_create.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        lib.orc_program_free.argtypes = [ctypes.c_void_p]
+        lib.orc_program_steps.argtypes = [ctypes.c_void_p]
+        lib.orc_program_sources.restype = ctypes.c_void_p
+        lib.orc_program_sources.argtypes = [ctypes.c_void_p]
+        lib.orc_batch_import.restype = ctypes.c_void_p
+        lib.orc_batch_import.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
+        lib.orc_batch_free.argtypes = [ctypes.c_void_p]
+        lib.orc_apply.restype = ctypes.c_void_p
+        lib.orc_apply.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.orc_build_filter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.orc_batch_rows.restype = ctypes.c_int64
+        lib.orc_batch_rows.argtypes = [ctypes.c_void_p]
+        lib.orc_batch_ncols.argtypes = [ctypes.c_void_p]
+        lib.orc_batch_col_name.restype = ctypes.c_char_p
+        lib.orc_batch_col_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.orc_batch_col_type.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.orc_batch_col_has_nulls.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.orc_batch_col_chars.restype = ctypes.c_int64
+        lib.orc_batch_col_chars.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.orc_batch_col_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.orc_free_string.argtypes = [ctypes.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _take(lib, p) -> str:
+    if not p:
+        return ""
+    s = ctypes.string_at(p).decode(errors="replace")
+    lib.orc_free_string(p)
+    return s
+
+
+@dataclass
+class OracleColumn:
+    name: str
+    type: str
+    values: object          # numpy array, list of bytes (strings), or (n, 2) uint64 for decimal128
+    valid: np.ndarray       # bool mask
+
+    def to_pylist(self):
+        out = []
+        for i in range(len(self.valid)):
+            if not self.valid[i]:
+                out.append(None)
+            else:
+                v = self.values[i]
+                if isinstance(v, (bytes, bytearray)):
+                    out.append(v.decode() if self.type == "string" else bytes(v))
+                elif isinstance(v, np.generic):
+                    out.append(v.item())
+                else:
+                    out.append(v)
+        return out
+
+
+def _plain_column(name: str, c) -> Tuple[OrcCol, list]:
+    """One input column -> OrcCol + the numpy buffers that back it."""
+    values = getattr(c, "values", c)
+    valid = getattr(c, "valid", None)
+    tname = getattr(c, "type", None)
+    off = getattr(c, "offset", 0) or 0
+    dictionary = getattr(c, "dictionary", None)
+    decimal = getattr(c, "decimal", None)
+    keep: list = []
+    oc = OrcCol()
+    keep.append(name.encode())
+    oc.name = keep[-1]
+    if valid is not None:
+        valid = np.asarray(valid, dtype=np.bool_)[off:]
+    if dictionary is not None:  # decode: the executor of the reference never sees a dictionary array
+        codes = np.asarray(values)[off:]
+        d = list(dictionary)
+        values = [d[int(k)] if (valid is None or valid[i]) else None for i, k in enumerate(codes)]
+        off = 0
+        tname = tname or "string"
+    if decimal is not None:
+        vals = np.ascontiguousarray(np.asarray(values, dtype=np.uint64)[off:]).reshape(-1, 2)
+        n = vals.shape[0]
+        oc.type = TYPE_IDS["decimal128"]
+        keep.append(vals)
+        oc.values = vals.ctypes.data
+    elif isinstance(values, np.ndarray) and values.dtype.kind in "biufMm":
+        if values.dtype.kind in "Mm":
+            tname = tname or ("timestamp" if values.dtype.kind == "M" else "duration")
+            values = values.astype("datetime64[us]" if values.dtype.kind == "M" else "timedelta64[us]").astype(np.int64)
+        if tname is None:
+            tname = _NUMPY_TO_TYPE[values.dtype]
+        vals = np.ascontiguousarray(values[off:].astype(_NP[tname]))
+        n = len(vals)
+        oc.type = TYPE_IDS[tname]
+        keep.append(vals)
+        oc.values = vals.ctypes.data
+    else:
+        seq = list(values)[off:]
+        if tname is None:
+            first = next((v for v in seq if v is not None), "")
+            tname = "string" if isinstance(first, str) else "binary"
+        offs = np.zeros(len(seq) + 1, dtype=np.int32)
+        chunks = []
+        nulls = np.ones(len(seq), dtype=np.bool_)
+        pos = 0
+        for i, v in enumerate(seq):
+            if v is None:
+                nulls[i] = False
+                b = b""
+            else:
+                b = v.encode() if isinstance(v, str) else bytes(v)
+            chunks.append(b)
+            pos += len(b)
+            offs[i + 1] = pos
+        data = np.frombuffer(b"".join(chunks) + b"\0", dtype=np.uint8).copy()
+        valid = nulls if valid is None else (valid & nulls)
+        n = len(seq)
+        oc.type = TYPE_IDS[tname]
+        keep += [offs, data]
+        oc.offsets = offs.ctypes.data
+        oc.chars = data.ctypes.data
+    oc.n = n
+    if valid is not None and not valid.all():  # null_count == 0 -> the array "may not have nulls"
+        vb = np.ascontiguousarray(valid.astype(np.uint8))
+        keep.append(vb)
+        oc.valid = vb.ctypes.data
+    return oc, keep
+
+
+class OracleBatch:
+    def __init__(self, lib, handle):
+        self._lib = lib
+        self._h = handle
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.orc_batch_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Oracle:
+    def __init__(self, resolver: Sequence[Tuple[int, str]], program, parameters: Optional[Dict[str, object]] = None,
+                 olap_wrapper: Optional[bool] = None):
+        self._lib = load()
+        if hasattr(program, "encode") and not isinstance(program, (bytes, bytearray)):
+            body = program.encode()
+            n = len(body)
+            varint = bytearray()
+            while True:
+                b = n & 0x7F
+                n >>= 7
+                varint.append(b | 0x80 if n else b)
+                if not n:
+                    break
+            data = b"\x0a" + bytes(varint) + body  # TOlapProgram { bytes Program = 1 }
+            wrapper = True
+        else:
+            data = bytes(program)
+            wrapper = True if olap_wrapper is None else olap_wrapper
+        ids = (ctypes.c_uint32 * max(1, len(resolver)))(*[i for i, _ in resolver])
+        names_b = [n.encode() for _, n in resolver]
+        names = (ctypes.c_char_p * max(1, len(resolver)))(*names_b)
+        pcols, keep = self._columns(parameters or {})
+        err = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(data, len(data))
+        self._h = self._lib.orc_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), 1 if wrapper else 0, ids, names,
+                                               len(resolver), pcols, len(parameters or {}), ctypes.byref(err))
+        if not self._h:
+            raise OracleError(_take(self._lib, err.value))
+
+    @staticmethod
+    def _columns(batch: Dict[str, object]):
+        arr = (OrcCol * max(1, len(batch)))()
+        keep = []
+        for i, (name, c) in enumerate(batch.items()):
+            oc, k = _plain_column(name, c)
+            arr[i] = oc
+            keep.append(k)
+        return arr, keep
+
+    def step_count(self) -> int:
+        return self._lib.orc_program_steps(self._h)
+
+    def source_columns(self) -> List[str]:
+        return [x for x in _take(self._lib, self._lib.orc_program_sources(self._h)).split("\n") if x]
+
+    def import_batch(self, batch: Dict[str, object], rows: Optional[int] = None) -> OracleBatch:
+        arr, keep = self._columns(batch)
+        n = rows if rows is not None else (arr[0].n if batch else 0)
+        err = ctypes.c_void_p()
+        h = self._lib.orc_batch_import(arr, len(batch), n, ctypes.byref(err))
+        if not h:
+            raise OracleError(_take(self._lib, err.value))
+        return OracleBatch(self._lib, h)
+
+    def apply_imported(self, batch: OracleBatch, read: bool = True):
+        err = ctypes.c_void_p()
+        h = self._lib.orc_apply(self._h, batch._h, ctypes.byref(err))
+        if not h:
+            raise OracleError(_take(self._lib, err.value))
+        out = OracleBatch(self._lib, h)
+        return self._read(out) if read else out
+
+    def apply(self, batch: Dict[str, object], rows: Optional[int] = None) -> Dict[str, OracleColumn]:
+        return self.apply_imported(self.import_batch(batch, rows))
+
+    def build_filter(self, batch: Dict[str, object], step: int = 0) -> np.ndarray:
+        b = self.import_batch(batch)
+        n = self._lib.orc_batch_rows(b._h)
+        mask = np.zeros(max(1, n), dtype=np.uint8)
+        err = ctypes.c_void_p()
+        if self._lib.orc_build_filter(self._h, step, b._h, mask.ctypes.data, ctypes.byref(err)) != 0:
+            raise OracleError(_take(self._lib, err.value))
+        return mask[:n].astype(np.bool_)
+
+    def _read(self, b: OracleBatch) -> Dict[str, OracleColumn]:
+        lib = self._lib
+        n = lib.orc_batch_rows(b._h)
+        out: Dict[str, OracleColumn] = {}
+        for i in range(lib.orc_batch_ncols(b._h)):
+            name = lib.orc_batch_col_name(b._h, i).decode()
+            tname = TYPE_NAMES[lib.orc_batch_col_type(b._h, i)]
+            valid = np.ones(max(1, n), dtype=np.uint8)
+            if tname in ("string", "binary"):
+                total = lib.orc_batch_col_chars(b._h, i)
+                offs = np.zeros(n + 1, dtype=np.int32)
+                chars = np.zeros(max(1, total), dtype=np.uint8)
+                lib.orc_batch_col_read(b._h, i, None, valid.ctypes.data, offs.ctypes.data, chars.ctypes.data)
+                data = chars.tobytes()
+                vals = [data[offs[j]:offs[j + 1]] for j in range(n)]
+            elif tname == "decimal128":
+                vals = np.zeros((max(1, n), 2), dtype=np.uint64)
+                lib.orc_batch_col_read(b._h, i, vals.ctypes.data, valid.ctypes.data, None, None)
+                vals = vals[:n]
+            else:
+                vals = np.zeros(max(1, n), dtype=_NP[tname])
+                lib.orc_batch_col_read(b._h, i, vals.ctypes.data, valid.ctypes.data, None, None)
+                vals = vals[:n]
+                if tname == "bool":
+                    vals = vals.astype(np.bool_)
+            key = name
+            while key in out:
+                key += "'"
+            out[key] = OracleColumn(name, tname, vals, valid[:n].astype(np.bool_))
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.orc_program_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,383 @@
+"""GPU executor (through the C-ABI) vs the CPU oracle on the same seeded inputs: bit-exact for integers, keys,
+counts, min/max and element-wise results; floating-point SUMs within FLOAT_SUM_RTOL (cases.py)."""
+import numpy as np
+import pytest
+
+from cases import compare_batches
+from ydb_amd.arrow_c import Col
+from ydb_amd.ssa_pb import AGG, F, YQL, Aggregate, Column, Program
+
+pytestmark = pytest.mark.gpu
+
+
+def both(resolver, program, batch):
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    pc = ProgramContainer()
+    ok, err = pc.Init(resolver, program)
+    assert ok, err
+    got = pc.ApplyProgram(batch)
+    exp = ssa_oracle.Oracle(resolver, program).apply(batch)
+    return got, exp
+
+
+def both_fail(resolver, program, batch):
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer, SsaError
+    pc = ProgramContainer()
+    ok, err = pc.Init(resolver, program)
+    assert ok, err
+    with pytest.raises(SsaError) as gi:
+        pc.ApplyProgram(batch)
+    with pytest.raises(ssa_oracle.OracleError) as oi:
+        ssa_oracle.Oracle(resolver, program).apply(batch)
+    return str(gi.value), str(oi.value)
+
+
+def both_chunked(resolver, ops, batch, chunk=8):
+    """ops: (kind, function id, argument ids) with kind 'f' (SIMPLE_ARROW) or 'y' (YQL kernel); one computed output
+    column each, at most `chunk` per program (a scan step has a bounded number of output registers)."""
+    for lo in range(0, len(ops), chunk):
+        p = Program()
+        outs = []
+        for i, (kind, fid, args) in enumerate(ops[lo:lo + chunk]):
+            if kind == "f":
+                p.assign_func(100 + i, fid, args)
+            else:
+                p.assign_yql(100 + i, fid, args)
+            outs.append(100 + i)
+        p.project(outs)
+        got, exp = both(resolver, p, batch)
+        compare_batches(got, exp)
+
+
+SIZES = [0, 1, 63, 64, 65, 1023, 1024, 1025, 4097, 100_003]
+
+
+def lineitem_like(rng, n, nulls=0.0):
+    def maybe(a):
+        if nulls <= 0:
+            return a
+        return Col(a, valid=rng.random(n) >= nulls)
+    return {
+        "ship": maybe(rng.integers(8036, 10562, n).astype(np.int32)),
+        "disc": maybe(rng.integers(0, 11, n) / 100.0),
+        "qty": maybe(rng.integers(1, 51, n).astype(np.float64)),
+        "price": maybe(rng.integers(90000, 200000, n) / 100.0),
+        "flag": maybe(rng.integers(0, 3, n).astype(np.int8)),
+        "status": maybe(rng.integers(0, 2, n).astype(np.uint8)),
+    }
+
+
+LI = [(1, "ship"), (2, "disc"), (3, "qty"), (4, "price"), (5, "flag"), (6, "status")]
+
+
+def q6_like():
+    return (Program()
+            .assign_const(100, "Int32", 9131).assign_const(101, "Int32", 9496)
+            .assign_const(102, "Double", 0.07 - 0.01).assign_const(103, "Double", 0.07 + 0.01).assign_const(104, "Double", 25.0)
+            .assign_func(110, F.CMP_GREATER_EQUAL, [1, 100]).assign_func(111, F.CMP_LESS, [1, 101])
+            .assign_func(112, F.CMP_GREATER_EQUAL, [2, 102]).assign_func(113, F.CMP_LESS_EQUAL, [2, 103])
+            .assign_func(114, F.CMP_LESS, [3, 104])
+            .filter(110).filter(111).filter(112).filter(113).filter(114)
+            .assign_func(120, F.MATH_MULTIPLY, [4, 2])
+            .group_by([Aggregate(130, AGG.SUM, [120]), Aggregate(131, AGG.COUNT, []), Aggregate(132, AGG.MIN, [1]),
+                       Aggregate(133, AGG.MAX, [4]), Aggregate(134, AGG.SOME, [3])])
+            .project([130, 131, 132, 133, 134]))
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("nulls", [0.0, 0.1])
+def test_filter_sum_nokeys(n, nulls):
+    rng = np.random.default_rng(1000 + n)
+    got, exp = both(LI, q6_like(), lineitem_like(rng, n, nulls))
+    compare_batches(got, exp, float_sum_names=["130"])
+
+
+def q1_like(keys):
+    return (Program()
+            .assign_const(100, "Int32", 10461).assign_const(101, "Double", 1.0)
+            .assign_func(110, F.CMP_LESS_EQUAL, [1, 100]).filter(110)
+            .assign_func(120, F.MATH_SUBTRACT, [101, 2]).assign_func(121, F.MATH_MULTIPLY, [4, 120])
+            .assign_func(122, F.MATH_ADD, [101, 2]).assign_func(123, F.MATH_MULTIPLY, [121, 122])
+            .group_by([Aggregate(130, AGG.SUM, [3]), Aggregate(131, AGG.SUM, [4]), Aggregate(132, AGG.SUM, [121]),
+                       Aggregate(133, AGG.SUM, [123]), Aggregate(134, AGG.COUNT, [3]), Aggregate(135, AGG.COUNT, []),
+                       Aggregate(136, AGG.MIN, [2]), Aggregate(137, AGG.MAX, [1]), Aggregate(138, AGG.SOME, [4])], keys=keys))
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("nulls", [0.0, 0.1])
+def test_filter_group_by_small_keys(n, nulls):
+    rng = np.random.default_rng(2000 + n)
+    got, exp = both(LI, q1_like([5, 6]), lineitem_like(rng, n, nulls))
+    compare_batches(got, exp, key_names=["flag", "status"], float_sum_names=["130", "131", "132", "133"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 1000, 50_000])
+def test_group_by_single_byte_key_ignores_argument_nulls(n):
+    # one 1-byte non-null key: the reference's lookup-table path does not look at argument validity
+    rng = np.random.default_rng(2500 + n)
+    b = lineitem_like(rng, n, 0.2)
+    b["flag"] = rng.integers(0, 3, n).astype(np.int8)
+    p = Program().group_by([Aggregate(130, AGG.SUM, [1]), Aggregate(131, AGG.COUNT, [1]), Aggregate(132, AGG.MIN, [1])], keys=[5])
+    got, exp = both(LI, p, b)
+    compare_batches(got, exp, key_names=["flag"])
+
+
+@pytest.mark.parametrize("n", [0, 5, 70_000])
+def test_group_by_string_keys(n):
+    rng = np.random.default_rng(3000 + n)
+    flags = [("A", "N", "R")[i] for i in rng.integers(0, 3, n)]
+    status = [("F", "O", "")[i] for i in rng.integers(0, 3, n)]
+    v = rng.integers(-1000, 1000, n).astype(np.int32)
+    p = Program().group_by([Aggregate(10, AGG.SUM, [3]), Aggregate(11, AGG.COUNT, []), Aggregate(12, AGG.MAX, [3])], keys=[1, 2])
+    got, exp = both([(1, "rf"), (2, "ls"), (3, "v")], p, {"rf": flags, "ls": status, "v": v})
+    compare_batches(got, exp, key_names=["rf", "ls"])
+
+
+def test_group_by_long_and_null_strings():
+    rng = np.random.default_rng(3100)
+    n = 20_000
+    words = ["", "a", "ab", "x" * 7, "x" * 8, "x" * 9, "y" * 31, "prefix-" + "z" * 100]
+    s = [words[i] for i in rng.integers(0, len(words), n)]
+    sv = rng.random(n) > 0.1
+    k = rng.integers(0, 4, n).astype(np.int64)
+    p = Program().group_by([Aggregate(10, AGG.COUNT, [2]), Aggregate(11, AGG.SUM, [2])], keys=[1, 2])
+    got, exp = both([(1, "s"), (2, "k")], p, {"s": Col(s, valid=sv), "k": k})
+    # a null string key groups with whatever bytes its slot holds (here: the string itself), validity is dropped
+    compare_batches(got, exp, key_names=["s", "k"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 3000, 200_000])
+def test_group_by_high_cardinality(n):
+    rng = np.random.default_rng(4000 + n)
+    key = rng.integers(-40_000, 40_000, n).astype(np.int64)
+    val = rng.integers(-1000, 1000, n).astype(np.int32)
+    valid = rng.random(n) > 0.3
+    f = rng.normal(size=n)
+    p = Program().group_by([Aggregate(10, AGG.SUM, [2]), Aggregate(11, AGG.MIN, [2]), Aggregate(12, AGG.MAX, [2]),
+                            Aggregate(13, AGG.COUNT, [2]), Aggregate(14, AGG.COUNT, []), Aggregate(15, AGG.MIN, [3]),
+                            Aggregate(16, AGG.MAX, [3]), Aggregate(17, AGG.SUM, [3]), Aggregate(18, AGG.SOME, [2])], keys=[1])
+    got, exp = both([(1, "k"), (2, "v"), (3, "f")], p, {"k": key, "v": Col(val, valid=valid), "f": f})
+    # groups here hold a handful of rows: 1e-12 is relative to the group's sum, which can cancel to ~0
+    compare_batches(got, exp, key_names=["k"], float_sum_names=["17"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("widths", [("int32", "int16"), ("int64", "int64"), ("uint8", "float"), ("int64", "uint64", "int32")])
+def test_group_by_nullable_and_wide_keys(widths):
+    rng = np.random.default_rng(5000 + len(widths) + sum(map(len, widths)))
+    n = 30_000
+    res, batch = [], {}
+    np_types = {"int32": np.int32, "int16": np.int16, "int64": np.int64, "uint8": np.uint8, "uint64": np.uint64, "float": np.float32}
+    for i, w in enumerate(widths):
+        vals = rng.integers(0, 4, n).astype(np_types[w])
+        batch[f"k{i}"] = Col(vals, valid=rng.random(n) > 0.2, type=w)
+        res.append((i + 1, f"k{i}"))
+    batch["v"] = rng.integers(0, 100, n).astype(np.uint32)
+    res.append((10, "v"))
+    keys = [i + 1 for i in range(len(widths))]
+    p = Program().group_by([Aggregate(20, AGG.SUM, [10]), Aggregate(21, AGG.COUNT, []), Aggregate(22, AGG.MAX, [10])], keys=keys)
+    got, exp = both(res, p, batch)
+    compare_batches(got, exp, key_names=[f"k{i}" for i in range(len(widths))])
+
+
+@pytest.mark.parametrize("n", [0, 1, 1025, 70_001])
+def test_projection_with_filter_and_strings(n):
+    rng = np.random.default_rng(6000 + n)
+    strs = [("ab" if i % 3 == 0 else "xyz") + str(i % 7) for i in range(n)]
+    sv = rng.random(n) > 0.15
+    a = rng.integers(-100, 100, n).astype(np.int16)
+    b = rng.integers(0, 1 << 40, n).astype(np.uint64)
+    bv = rng.random(n) > 0.15
+    flt = rng.random(n) > 0.4
+    p = (Program().assign_const(100, "Bytes", b"ab").assign_func(110, F.STR_STARTS_WITH, [1, 100])
+         .assign_func(111, F.STR_LENGTH, [1]).assign_func(112, F.MATH_ADD, [2, 3]).assign_func(113, F.CMP_GREATER, [2, 111])
+         .assign_func(114, F.IS_NULL, [3]).filter(110).filter(4)
+         .project([1, 111, 112, 113, 114, 2, 3, 4, 100]))
+    res = [(1, "s"), (2, "a"), (3, "b"), (4, "flt")]
+    got, exp = both(res, p, {"s": Col(strs, valid=sv), "a": a, "b": Col(b, valid=bv), "flt": flt})
+    compare_batches(got, exp)
+
+
+def test_sliced_inputs_and_bit_offsets():
+    rng = np.random.default_rng(7000)
+    total, off = 5000, 37
+    a = rng.integers(-1000, 1000, total).astype(np.int32)
+    av = rng.random(total) > 0.2
+    flag = rng.random(total) > 0.5
+    s = ["s%d" % (i % 11) for i in range(total)]
+    p = (Program().assign_const(100, "Int32", 0).assign_func(110, F.CMP_GREATER, [1, 100]).filter(110).filter(2)
+         .group_by([Aggregate(120, AGG.SUM, [1]), Aggregate(121, AGG.COUNT, [])], keys=[3]))
+    batch = {"a": Col(a, valid=av, offset=off), "flag": Col(flag, offset=off), "s": Col(s, offset=off)}
+    got, exp = both([(1, "a"), (2, "flag"), (3, "s")], p, batch)
+    compare_batches(got, exp, key_names=["s"])
+
+
+def test_dictionary_column_equals_decoded_column():
+    rng = np.random.default_rng(7100)
+    n = 10_000
+    d = ["google", "yandex", "", "bing.com/search"]
+    codes = rng.integers(0, len(d), n).astype(np.int8)
+    v = rng.integers(0, 10, n).astype(np.int64)
+    p = (Program().assign_const(100, "Bytes", b"g").assign_yql(110, YQL.StringContains, [1, 100]).filter(110)
+         .group_by([Aggregate(120, AGG.COUNT, []), Aggregate(121, AGG.SUM, [2])], keys=[1]))
+    got, exp = both([(1, "phrase"), (2, "v")], p, {"phrase": Col(codes, dictionary=d), "v": v})
+    compare_batches(got, exp, key_names=["phrase"])
+
+
+ARITH_TYPES = ["int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float", "double"]
+NPT = {"int8": np.int8, "int16": np.int16, "int32": np.int32, "int64": np.int64, "uint8": np.uint8, "uint16": np.uint16,
+       "uint32": np.uint32, "uint64": np.uint64, "float": np.float32, "double": np.float64}
+
+
+def small_values(rng, t, n):
+    if t in ("float", "double"):
+        return (rng.integers(-50, 50, n) / 4.0).astype(NPT[t])
+    lo = 0 if t.startswith("u") else -60
+    return rng.integers(lo, 60, n).astype(NPT[t])
+
+
+@pytest.mark.parametrize("ta", ARITH_TYPES)
+@pytest.mark.parametrize("tb", ARITH_TYPES)
+def test_arrow_binary_ops_all_type_pairs(ta, tb):
+    rng = np.random.default_rng(abs(hash((ta, tb))) % (1 << 31))
+    n = 700
+    a = Col(small_values(rng, ta, n), valid=rng.random(n) > 0.1, type=ta)
+    bvals = small_values(rng, tb, n)
+    bvals[bvals == 0] = 1  # integer division by zero is an error (checked separately)
+    b = Col(bvals, valid=rng.random(n) > 0.1, type=tb)
+    p = Program()
+    outs = []
+    for i, fid in enumerate([F.MATH_ADD, F.MATH_SUBTRACT, F.MATH_MULTIPLY, F.MATH_DIVIDE, F.CMP_EQUAL, F.CMP_NOT_EQUAL, F.CMP_LESS,
+                             F.CMP_LESS_EQUAL, F.CMP_GREATER, F.CMP_GREATER_EQUAL]):
+        p.assign_func(100 + i, fid, [1, 2])
+        outs.append(100 + i)
+    p.project(outs)
+    got, exp = both([(1, "a"), (2, "b")], p, {"a": a, "b": b})
+    compare_batches(got, exp)
+
+
+@pytest.mark.parametrize("ta", ARITH_TYPES)
+@pytest.mark.parametrize("tb", ARITH_TYPES)
+def test_yql_binary_kernels_all_type_pairs(ta, tb):
+    rng = np.random.default_rng(abs(hash((tb, ta, 1))) % (1 << 31))
+    n = 700
+    a = Col(small_values(rng, ta, n), valid=rng.random(n) > 0.1, type=ta)
+    b = Col(small_values(rng, tb, n), valid=rng.random(n) > 0.1, type=tb)  # zeros included: Div/Mod yield NULL
+    p = Program()
+    outs = []
+    for i, op in enumerate([YQL.Add, YQL.Sub, YQL.Mul, YQL.Div, YQL.Mod, YQL.Equals, YQL.NotEquals, YQL.Less, YQL.LessOrEqual,
+                            YQL.Greater, YQL.GreaterOrEqual]):
+        p.assign_yql(100 + i, op, [1, 2])
+        outs.append(100 + i)
+    p.project(outs)
+    got, exp = both([(1, "a"), (2, "b")], p, {"a": a, "b": b})
+    compare_batches(got, exp)
+
+
+def test_integer_wraparound_and_extremes():
+    a64 = np.array([np.iinfo(np.int64).max, np.iinfo(np.int64).min, -1, 0, 1, 1 << 62], dtype=np.int64)
+    b64 = np.array([1, -1, np.iinfo(np.int64).min, 5, -1, 4], dtype=np.int64)
+    a8 = np.array([127, -128, -1, 0, 1, 100], dtype=np.int8)
+    b8 = np.array([1, -1, -128, 5, -1, 100], dtype=np.int8)
+    u = np.array([0, 1, (1 << 64) - 1, 1 << 63, 5, 7], dtype=np.uint64)
+    ops = []
+    for x, y in ((1, 2), (3, 4), (5, 5)):
+        for fid in (F.MATH_ADD, F.MATH_SUBTRACT, F.MATH_MULTIPLY):
+            ops.append(("f", fid, [x, y]))
+    ops.append(("f", F.MATH_DIVIDE, [1, 2]))   # INT64_MIN / -1 -> 0
+    ops.append(("f", F.MATH_DIVIDE, [3, 4]))   # -128 / -1 -> 0
+    for op in (YQL.Div, YQL.Mod):
+        ops.append(("y", op, [1, 2]))          # MIN / -1 -> NULL
+        ops.append(("y", op, [3, 4]))
+    both_chunked([(1, "a64"), (2, "b64"), (3, "a8"), (4, "b8"), (5, "u")], ops, {"a64": a64, "b64": b64, "a8": a8, "b8": b8, "u": u})
+
+
+def test_kleene_logic_and_filters_ignore_validity():
+    rng = np.random.default_rng(8000)
+    n = 3000
+    x = Col(rng.integers(0, 2, n).astype(np.uint8), valid=rng.random(n) > 0.3)
+    y = Col(rng.integers(0, 2, n).astype(np.uint8), valid=rng.random(n) > 0.3)
+    bx = Col(rng.random(n) > 0.5, valid=rng.random(n) > 0.3)
+    by = Col(rng.random(n) > 0.5, valid=rng.random(n) > 0.3)
+    v = rng.integers(0, 100, n).astype(np.int32)
+    p = (Program().assign_yql(100, YQL.And, [1, 2]).assign_yql(101, YQL.Or, [1, 2]).assign_yql(102, YQL.Xor, [1, 2])
+         .assign_func(103, F.BINARY_AND, [3, 4]).assign_func(104, F.BINARY_OR, [3, 4]).assign_func(105, F.BINARY_XOR, [3, 4])
+         .assign_func(106, F.BINARY_NOT, [3]).assign_yql(107, YQL.Coalesce, [1, 2])
+         .project([100, 101, 102, 103, 104, 105, 106, 107]))
+    res = [(1, "x"), (2, "y"), (3, "bx"), (4, "by"), (5, "v")]
+    batch = {"x": x, "y": y, "bx": bx, "by": by, "v": v}
+    got, exp = both(res, p, batch)
+    compare_batches(got, exp)
+    # a NULL predicate row is kept or dropped by the value its slot holds
+    for pred in (1, 3):
+        p2 = Program().filter(pred).group_by([Aggregate(110, AGG.COUNT, [5]), Aggregate(111, AGG.SUM, [5])])
+        got, exp = both(res, p2, batch)
+        compare_batches(got, exp)
+
+
+def test_casts():
+    rng = np.random.default_rng(8100)
+    n = 2000
+    cols = {"i": rng.integers(-70000, 70000, n).astype(np.int32), "u": rng.integers(0, 1 << 33, n).astype(np.uint64),
+            "f": (rng.normal(size=n) * 300).astype(np.float64), "g": (rng.normal(size=n) * 100).astype(np.float32),
+            "s": rng.integers(0, 2_000_000_000, n).astype(np.uint32)}
+    res = [(1, "i"), (2, "u"), (3, "f"), (4, "g"), (5, "s")]
+    casts = [F.CAST_TO_BOOLEAN, F.CAST_TO_INT8, F.CAST_TO_INT16, F.CAST_TO_INT32, F.CAST_TO_INT64, F.CAST_TO_UINT8, F.CAST_TO_UINT16,
+             F.CAST_TO_UINT32, F.CAST_TO_UINT64, F.CAST_TO_FLOAT, F.CAST_TO_DOUBLE]
+    ops = []
+    for src in (1, 2, 3, 4):
+        for c in casts:
+            if src in (3, 4) and c not in (F.CAST_TO_FLOAT, F.CAST_TO_DOUBLE, F.CAST_TO_INT64, F.CAST_TO_INT32):
+                continue  # out-of-range float -> narrow int is undefined behaviour in the reference's C++ cast
+            ops.append(("f", c, [src]))
+    ops.append(("f", F.CAST_TO_TIMESTAMP, [5]))
+    both_chunked(res, ops, cols)
+
+
+def test_errors_match():
+    a = np.array([1, 2, 3], dtype=np.int32)
+    z = np.array([1, 0, 3], dtype=np.int32)
+    g, o = both_fail([(1, "a"), (2, "z")], Program().assign_func(10, F.MATH_DIVIDE, [1, 2]).project([10]), {"a": a, "z": z})
+    assert "divide by zero" in g and "divide by zero" in o
+    # a division by zero under a null slot is not evaluated
+    got, exp = both([(1, "a"), (2, "z")], Program().assign_func(10, F.MATH_DIVIDE, [1, 2]).project([10]),
+                    {"a": a, "z": Col(z, valid=np.array([True, False, True]))})
+    compare_batches(got, exp)
+    # implicit casts are checked: uint64 beyond int64 compared with a signed column
+    big = np.array([1, (1 << 63) + 5], dtype=np.uint64)
+    s = np.array([-1, 2], dtype=np.int64)
+    g, o = both_fail([(1, "u"), (2, "s")], Program().assign_func(10, F.CMP_LESS, [1, 2]).project([10]), {"u": big, "s": s})
+    assert "not in range" in g and "not in range" in o
+    # filter over a non-boolean column, projection of a missing column
+    both_fail([(1, "a"), (2, "z")], Program().filter(1).project([1]), {"a": a, "z": z})
+    both_fail([(1, "a"), (2, "z")], Program().project([1, 7]), {"a": a, "z": z})
+
+
+def test_build_filter_matches_oracle():
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    rng = np.random.default_rng(8200)
+    for n in (0, 1, 64, 1000, 4097):
+        b = lineitem_like(rng, n, 0.1)
+        p = q6_like()
+        pc = ProgramContainer()
+        ok, err = pc.Init(LI, p)
+        assert ok, err
+        mask, selected = pc.BuildFilter(b)
+        exp = ssa_oracle.Oracle(LI, p).build_filter(b)
+        assert selected == int(exp.sum())
+        assert (mask == exp).all()
+
+
+def test_multi_step_program():
+    rng = np.random.default_rng(8300)
+    n = 20_000
+    b = lineitem_like(rng, n)
+    p = (Program().assign_const(100, "Int32", 9000).assign_func(110, F.CMP_GREATER, [1, 100]).filter(110)
+         .assign_func(120, F.MATH_MULTIPLY, [4, 2]).project([120, 5, 6, 3])
+         .assign_const(200, "Double", 20.0).assign_func(210, F.CMP_LESS, [3, 200]).filter(210)
+         .group_by([Aggregate(220, AGG.SUM, [120]), Aggregate(221, AGG.COUNT, [])], keys=[5, 6])
+         .project([220, 221, 6, 5]))
+    got, exp = both(LI, p, b)
+    compare_batches(got, exp, key_names=["flag", "status"], float_sum_names=["220"])
