@@ -1,0 +1,83 @@
+"""The N > 1 path on CPU: two gloo ranks scan their own row ranges (with the oracle standing in for the GPU scan, which
+this box cannot run), exchange partial aggregates with shard.all_gather_results, and merge them with the derived merge
+program.  The merged result must equal the program applied to the whole table."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, codes, rows_per_rank, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from cases import compare_batches
+    from oracle import ssa_oracle
+    from ydb_amd import shard, tpch
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        prog = tpch.q1_program(codes)
+        cols = tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8
+        li = tpch.lineitem_host(rank * rows_per_rank, rows_per_rank)
+        local = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply({c: li[c] for c in cols})
+        parts = shard.all_gather_results(local)
+        assert len(parts) == world
+        mine = parts[rank]
+        assert list(mine.keys()) == list(local.keys())
+        for k in local:
+            assert mine[k].to_pylist() == local[k].to_pylist(), k  # the wire format round-trips
+        mp_, mr = shard.merge_program(prog, tpch.LINEITEM_RESOLVER)
+        merged = ssa_oracle.Oracle(mr, mp_).apply(shard.partial_batch(parts, prog, tpch.LINEITEM_RESOLVER))
+        full = tpch.lineitem_host(0, world * rows_per_rank)
+        exp = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply({c: full[c] for c in cols})
+        compare_batches(merged, exp, key_names=cols[-2:], float_sum_names=["130", "131", "132", "133", "136"])
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("codes", [True, False])
+def test_two_rank_partial_aggregate_merge(tmp_path, codes):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, codes, 20_000, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_merge_program_shape():
+    sys.path.insert(0, ROOT)
+    from ydb_amd import shard, tpch
+    from ydb_amd.ssa_pb import AGG, GroupBy
+    mp_, mr = shard.merge_program(tpch.q1_program(True), tpch.LINEITEM_RESOLVER)
+    gb = [c for c in mp_.commands if isinstance(c, GroupBy)][0]
+    assert [a.id for a in gb.aggregates] == [AGG.SUM] * 9  # SUM of sums and of counts
+    names = dict(mr)
+    assert names[gb.keys[0]] == "l_returnflag_code" and names[gb.keys[1]] == "l_linestatus_code"
+    assert all(names[a.args[0]].startswith("partial:") for a in gb.aggregates)
+
+
+def test_partition_of_keys_is_balanced_and_stable():
+    sys.path.insert(0, ROOT)
+    from ydb_amd import shard
+    h = np.arange(100_000, dtype=np.uint64) * np.uint64(2654435761)
+    r = shard.partition_of_keys(h, 8)
+    assert r.min() == 0 and r.max() == 7
+    counts = np.bincount(r, minlength=8)
+    assert counts.min() > 0.9 * 12_500 and counts.max() < 1.1 * 12_500
+    assert (shard.partition_of_keys(h, 8) == r).all()

@@ -1,4 +1,4 @@
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 """Bring-up checks of keyed GROUP BY against pandas (run by hand on the GPU box)."""
 import numpy as np
 import pandas as pd

@@ -1,4 +1,4 @@
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 """Bring-up checks of the scan path against numpy (run by hand on the GPU box)."""
 import numpy as np
 from ydb_amd.program import ProgramContainer
