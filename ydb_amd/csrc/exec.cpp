@@ -1066,7 +1066,49 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         }
     }
     const bool twoWords = hashed || keyBits > 63;
-    const int naggs = naggsUser + (hashed ? 1 : 0);
+
+    // Aggregates that read the same operand the same way share one accumulator (COUNT(a), COUNT(b) and COUNT(*) over
+    // non-null columns are one counter).
+    std::vector<AggSpec> phys;
+    std::vector<int> aggSrc;
+    aggSrc.resize(size_t(naggsUser));
+    for (int k = 0; k < naggsUser; ++k) {
+        AggSpec spec = plan.Aggs[size_t(k)].Spec;
+        if (spec.kind == AGG_COUNT && !spec.check_valid) spec.reg = -1;  // counts rows
+        int found = -1;
+        for (size_t j = 0; j < phys.size(); ++j) {
+            if (phys[j].kind == spec.kind && phys[j].reg == spec.reg && phys[j].check_valid == spec.check_valid &&
+                phys[j].arg_class == spec.arg_class) found = int(j);
+        }
+        if (found < 0) {
+            found = int(phys.size());
+            phys.push_back(spec);
+        }
+        aggSrc[size_t(k)] = found;
+    }
+    const int naggs = int(phys.size());
+    // Accumulators the sink can keep in registers go first: row counters and SUMs without a validity check (their
+    // operand layout is checked once the LDS plan is known).
+    {
+        std::vector<int> order;
+        auto simple = [](const AggSpec& a) {
+            return !a.check_valid && ((a.kind == AGG_COUNT && a.reg == -1) || a.kind == AGG_SUM_F || a.kind == AGG_SUM_I);
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int j = 0; j < naggs; ++j) {
+                if (simple(phys[size_t(j)]) == (pass == 0)) order.push_back(j);
+            }
+        }
+        std::vector<AggSpec> sorted;
+        std::vector<int> newIndex;
+        newIndex.resize(size_t(naggs));
+        for (int j = 0; j < naggs; ++j) {
+            sorted.push_back(phys[size_t(order[size_t(j)])]);
+            newIndex[size_t(order[size_t(j)])] = j;
+        }
+        phys = sorted;
+        for (int& src : aggSrc) src = newIndex[size_t(src)];
+    }
 
     KeyedHint& hint = KeyedHints[&step];
     const uint64_t maxCap = std::max<uint64_t>(1024, NextPow2(uint64_t(in.Rows) * 2 + 2));
@@ -1074,8 +1116,8 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
 
     int L = hint.LdsCap, R = 1;
     if (L == 16) {
-        R = 32;
-        while (R > 1 && L * R * naggs * 8 > 32 * 1024) R >>= 1;
+        R = 8;
+        while (R > 1 && L * R * naggs * 8 > 16 * 1024) R >>= 1;
     }
     if (const char* env = std::getenv("SSA_KEYED_LDS")) {
         int l = 0, r = 1;
@@ -1085,7 +1127,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         }
     }
     if (L == 0) R = 1;
-    const int sinkLds = L * 16 + naggs * L * R * 8 + L * 4;
+    const int sinkLds = L * 24 + naggs * L * R * 8 + L * 8 + 16;
 
     ScanArgs args;
     LaunchCfg cfg;
@@ -1094,17 +1136,9 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     KeyedSink sink{};
     sink.naggs = naggs;
     sink.nkeys = nkeys;
-    for (int k = 0; k < naggsUser; ++k) {
-        sink.aggs[k] = plan.Aggs[size_t(k)].Spec;
+    for (int k = 0; k < naggs; ++k) {
+        sink.aggs[k] = phys[size_t(k)];
         if (sink.aggs[k].reg != -1) EncodeOperand(args, sink.aggs[k].reg, sink.aggs[k].fetch_kind, sink.aggs[k].fetch_payload);
-    }
-    sink.rep_row_agg = -1;
-    if (hashed) {
-        sink.rep_row_agg = naggsUser;
-        sink.aggs[naggsUser] = AggSpec{};
-        sink.aggs[naggsUser].kind = AGG_MIN_U;
-        sink.aggs[naggsUser].reg = -1;
-        sink.aggs[naggsUser].arg_class = CLS_U;
     }
     for (int k = 0; k < nkeys; ++k) {
         sink.keys[k] = plan.Keys[size_t(k)].Spec;
@@ -1114,14 +1148,35 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     sink.hashed = hashed;
     sink.lds_cap = L;
     sink.lds_rep = R;
+    for (int k = 0; k < kHotAggs && k < naggs; ++k) {
+        const AggSpec& a = sink.aggs[k];
+        if (a.check_valid) continue;
+        if (a.kind == AGG_COUNT && a.reg == -1) {
+            sink.hot_kind[k] = HOT_ROWS;
+            continue;
+        }
+        if (a.kind != AGG_SUM_F && a.kind != AGG_SUM_I) continue;
+        int off = -1;
+        if (a.reg >= 0) {
+            off = args.lds_reg_off + a.reg * kTileRows * 8;  // R registers hold 64-bit payloads
+        } else if (a.reg <= -2 && (a.fetch_kind & 0x7F) == FK_LDS_64) {
+            const int t = args.cols[-2 - a.reg].type;
+            if ((a.kind == AGG_SUM_F) == (t == T_F64)) off = int(a.fetch_payload & 0xFFFFFFu);
+        }
+        if (off < 0) continue;
+        sink.hot_kind[k] = a.kind == AGG_SUM_F ? HOT_SUM_F64 : HOT_SUM_I64;
+        sink.hot_off[k] = off;
+    }
 
-    BufferPtr tLo, tHi, tAcc, tSeen;
+    BufferPtr tLo, tHi, tAcc, tSeen, tRep;
     for (;;) {
         tLo = Buffer::Alloc(cap * 8);
         tHi = Buffer::Alloc(twoWords ? cap * 8 : 64);
         tAcc = Buffer::Alloc(size_t(naggs) * cap * 8);
         tSeen = Buffer::Alloc(cap * 4);
-        if (!tLo || !tHi || !tAcc || !tSeen) return Status::Hip("out of device memory");
+        tRep = Buffer::Alloc(hashed ? cap * 8 : 64);
+        if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
+        if (hashed) SSA_HIP(hipMemsetAsync(tRep->Ptr, 0xFF, cap * 8, StreamHandle));
         SSA_HIP(hipMemsetAsync(tLo->Ptr, 0xFF, cap * 8, StreamHandle));
         if (twoWords) SSA_HIP(hipMemsetAsync(tHi->Ptr, 0xFF, cap * 8, StreamHandle));
         SSA_HIP(hipMemsetAsync(tSeen->Ptr, 0, cap * 4, StreamHandle));
@@ -1136,6 +1191,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         sink.t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
         sink.t_acc = static_cast<uint64_t*>(tAcc->Ptr);
         sink.t_seen = static_cast<uint32_t*>(tSeen->Ptr);
+        sink.t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
         if (in.Rows > 0) {
             ProfileBegin();
             SSA_HIP(LaunchScanKeyed(args, sink, cfg));
@@ -1169,7 +1225,8 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     fa.t_acc = sink.t_acc;
     fa.t_seen = sink.t_seen;
     fa.counter = static_cast<unsigned long long*>(counter->Ptr);
-    fa.naggs = naggs;
+    fa.t_rep_row = sink.t_rep_row;
+    fa.naggs = naggsUser;
     fa.nkeys = nkeys;
     fa.two_words = twoWords;
     fa.hashed = hashed;
@@ -1181,17 +1238,15 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     aggRowIdx.resize(size_t(naggsUser));
     keyValid.resize(size_t(nkeys));
     BufferPtr repRows;
-    for (int k = 0; k < naggs; ++k) {
-        fa.aggs[k] = sink.aggs[k];
-        if (k == naggsUser) {
-            repRows = Buffer::Alloc(size_t(ngroups) * 8 + 16);
-            if (!repRows) return Status::Hip("out of device memory");
-            fa.agg_row_index[k] = 1;
-            fa.agg_out_type[k] = T_U64;
-            fa.agg_vals[k] = repRows->Ptr;
-            continue;
-        }
+    if (hashed) {
+        repRows = Buffer::Alloc(size_t(ngroups) * 8 + 16);
+        if (!repRows) return Status::Hip("out of device memory");
+        fa.group_rep_row = static_cast<uint64_t*>(repRows->Ptr);
+    }
+    for (int k = 0; k < naggsUser; ++k) {
         const AggPlan& ap = plan.Aggs[size_t(k)];
+        fa.aggs[k] = ap.Spec;
+        fa.agg_src[k] = aggSrc[size_t(k)];
         Column& col = aggCols[size_t(k)];
         col.Field.Type = ap.OutType;
         col.Length = ngroups;

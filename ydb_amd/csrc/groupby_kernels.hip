@@ -206,6 +206,53 @@ __device__ __forceinline__ uint64_t WidthMask(int nbits) { return nbits >= 64 ? 
 }  // namespace
 
 // ---- sink: keyed aggregation ------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kNoDense = 0xFFFFFFFFu;  // dense id of a level-1 slot not yet published by its owner
+constexpr int kHotGroups = 4;               // groups whose SUM / COUNT accumulators live in registers
+
+// Level-1 upsert.  Hash positions are claimed like level 2; the owner then numbers the group with the next dense id
+// (order of first appearance in this workgroup), records a representative row and publishes the id.  Accumulators are
+// indexed by dense id, so the first kHotGroups groups of a workgroup are the ones kept in registers.
+__device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint64_t* lRep, uint32_t* lDense, uint32_t* lCount,
+                                              uint32_t mask, uint64_t start, uint64_t lo, uint64_t hi, bool twoWords,
+                                              uint64_t row, uint32_t maxProbes) {
+    uint32_t s = uint32_t(start) & mask;
+    uint32_t probes = 0;
+    while (probes < maxProbes) {
+        uint64_t cur = __hip_atomic_load(lLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == kEmpty) {
+            cur = atomicCAS(reinterpret_cast<unsigned long long*>(lLo + s), static_cast<unsigned long long>(kEmpty),
+                            static_cast<unsigned long long>(lo));
+            if (cur == kEmpty) {
+                const uint32_t id = atomicAdd(lCount, 1u);
+                lRep[s] = row;
+                if (twoWords) __hip_atomic_store(lHi + s, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(lDense + s, id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return int(id);
+            }
+        }
+        if (cur == lo) {
+            bool same = true;
+            if (twoWords) {
+                const uint64_t ch = __hip_atomic_load(lHi + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ch == kUnpublished) continue;  // owner is between its two stores: look again next trip
+                same = ch == hi;
+            }
+            if (same) {
+                const uint32_t id = __hip_atomic_load(lDense + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (id == kNoDense) continue;
+                return int(id);
+            }
+        }
+        s = (s + 1) & mask;
+        ++probes;
+    }
+    return -1;
+}
+
+}  // namespace
+
 template <int U>
 __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>) {
     const ScanArgs& a = KernArgs<KeyedSink>().a;
@@ -214,16 +261,23 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
     const int naggs = s.naggs;
     const int L = s.lds_cap, R = s.lds_rep;
     const bool twoWords = s.two_words != 0, hashed = s.hashed != 0;
-    // level-1 table in the sink area of LDS: lo[L], hi[L], acc[naggs][L][R], seen[L]
+    // level-1 table in the sink area of LDS:
+    //   by hash position: lo[L], hi[L], rep[L], dense[L];  by dense id: acc[naggs][L][R], seen[L];  count
     uint64_t* lLo = reinterpret_cast<uint64_t*>(gLds + a.lds_sink_off);
     uint64_t* lHi = lLo + L;
-    uint64_t* lAcc = lHi + L;
+    uint64_t* lRep = lHi + L;
+    uint64_t* lAcc = lRep + L;
     uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(naggs) * L * R);
+    uint32_t* lDense = lSeen + L;
+    uint32_t* lCount = lDense + L;
     for (int i = threadIdx.x; i < L; i += kBlock) {
         lLo[i] = kEmpty;
         lHi[i] = kUnpublished;
+        lRep[i] = ~0ull;
         lSeen[i] = 0;
+        lDense[i] = kNoDense;
     }
+    if (threadIdx.x == 0) *lCount = 0;
     for (int k = 0; k < naggs; ++k) {
         const uint64_t ident = TableIdentity(s.aggs[k].kind);
         for (int i = threadIdx.x; i < L * R; i += kBlock) lAcc[size_t(k) * L * R + i] = ident;
@@ -231,6 +285,30 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
     // (the barriers of the first BeginTile order this initialisation before any use)
     const int rep = threadIdx.x & (R - 1);
     const uint32_t ldsProbes = L < 8 ? uint32_t(L) : 8u;
+
+    // Register accumulators of the first kHotGroups groups x first kHotAggs aggregates (SUM / COUNT only; their
+    // identity is 0 in every representation).  Lane-private for the whole kernel, folded into level 1 at the end.
+    uint64_t hot[kHotGroups][kHotAggs];
+#pragma unroll
+    for (int g = 0; g < kHotGroups; ++g) {
+#pragma unroll
+        for (int k = 0; k < kHotAggs; ++k) hot[g][k] = 0;
+    }
+    const bool useHot = L >= kHotGroups && !(a.debug_flags & 8);
+
+    // Sink description in VGPR lanes (lane i: key i / accumulator i), decoded with v_readlane inside the tile loop:
+    // re-reading the kernel-argument segment there costs a scalar-memory round trip per field and tile.
+    const int lane = threadIdx.x & 63;
+    const int ki = lane < kMaxKeys ? lane : 0;
+    const uint32_t tKeyCol = uint32_t(s.keys[ki].col), tKeyType = uint32_t(s.keys[ki].type), tKeyNullable = uint32_t(s.keys[ki].nullable);
+    const uint32_t tKeyFk = s.keys[ki].fetch_kind, tKeyPayload = s.keys[ki].fetch_payload;
+    const int ai = lane < kMaxAggs ? lane : 0;
+    const uint32_t tAggKind = uint32_t(s.aggs[ai].kind), tAggReg = uint32_t(s.aggs[ai].reg), tAggCheck = uint32_t(s.aggs[ai].check_valid);
+    const uint32_t tAggFk = s.aggs[ai].fetch_kind, tAggPayload = s.aggs[ai].fetch_payload;
+    const int hi_ = lane < kHotAggs ? lane : 0;
+    const uint32_t tHotKind = (lane < kHotAggs && !(a.debug_flags & 32)) ? uint32_t(s.hot_kind[hi_]) : 0u;
+    const uint32_t tHotOff = uint32_t(s.hot_off[hi_]);
+    const int nkeys = s.nkeys;
 
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -241,8 +319,13 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         // keys of the lane's rows
         KeyBuilder<U> kb;
         kb.Begin(hashed);
-        for (int k = 0; k < s.nkeys; ++k) {
-            const KeySpec ks = s.keys[k];
+        for (int k = 0; k < nkeys; ++k) {
+            KeySpec ks;
+            ks.col = int32_t(ReadLane32(tKeyCol, k));
+            ks.type = int32_t(ReadLane32(tKeyType, k));
+            ks.nullable = int32_t(ReadLane32(tKeyNullable, k));
+            ks.fetch_kind = ReadLane32(tKeyFk, k);
+            ks.fetch_payload = ReadLane32(tKeyPayload, k);
             if (ks.col >= 0) {
                 // string key (always hashed); the validity of the column is not part of these keys
 #pragma unroll
@@ -283,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             }
         }
 
-        // slots: >= 0 level 1, <= -2 level 2 (slot g as -2 - g), -1 no row
+        // group of each row: >= 0 dense id in level 1, <= -2 level-2 slot g as -2 - g, -1 no row
         int64_t slot[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -292,7 +375,8 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             kb.Finish(u, hashed);
             const uint64_t h = Mix64(kb.lo[u] ^ Mix64(kb.hi[u]));
             int64_t sl = -1;
-            if (L > 0) sl = TableUpsert(lLo, lHi, uint64_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords, ldsProbes);
+            if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
+                                           uint64_t(m.Row(u)), ldsProbes);
             if (sl < 0) {
                 const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, h >> 20, kb.lo[u], kb.hi[u], twoWords, 4096u);
                 if (g < 0) {
@@ -300,24 +384,104 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
                     m.P &= ~(1u << u);
                 } else {
                     sl = -2 - g;
+                    if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(s.t_rep_row + g), static_cast<unsigned long long>(m.Row(u)));
                 }
             }
             slot[u] = sl;
         }
 
-        for (int k = 0; k < naggs; ++k) {
-            const AggSpec spec = s.aggs[k];
-            uint32_t live = m.P;
-            Val<U> x;
-            if (k == s.rep_row_agg) {
+        // membership of the lane's rows in the register-held groups: bit u of hit[g]; as 0.0 / 1.0 factors for the
+        // floating-point sums (one FMA per row and group)
+        uint32_t hit[kHotGroups];
+        double one[kHotGroups][U];
+        uint32_t hotRows = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) x.v[u] = uint64_t(m.Row(u));
-            } else if (spec.reg != -1) {
+        for (int g = 0; g < kHotGroups; ++g) {
+            hit[g] = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = useHot && slot[u] == g;
+                hit[g] |= (in ? 1u : 0u) << u;
+                one[g][u] = in ? 1.0 : 0.0;
+            }
+            hotRows |= hit[g];
+        }
+
+        // Register path: aggregates the host marked as plain 64-bit SUMs over an LDS-resident operand (a staged
+        // column or an R register) and the row counter.  Kept tiny on purpose: it is unrolled per aggregate.
+        uint32_t hotDone = 0;
+        if (useHot && !(a.debug_flags & 2)) {
+#pragma unroll
+            for (int k = 0; k < kHotAggs; ++k) {
+                const int hk = int(ReadLane32(tHotKind, k));
+                if (hk == HOT_SUM_F64) {
+                    const double* src = reinterpret_cast<const double*>(gLds + ReadLane32(tHotOff, k));
+                    double x[U];
+                    bool finite = true;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        x[u] = src[u * kBlock + threadIdx.x];
+                        finite = finite && (x[u] - x[u] == 0.0);
+                    }
+                    // x * 0.0 must be 0: an infinity / NaN anywhere in the wave's rows sends this aggregate through
+                    // the tables for this tile
+                    if (__all(finite)) {
+#pragma unroll
+                        for (int g = 0; g < kHotGroups; ++g) {
+                            double acc = BitsToF64(hot[g][k]);
+#pragma unroll
+                            for (int u = 0; u < U; ++u) acc = __builtin_fma(x[u], one[g][u], acc);
+                            hot[g][k] = F64ToBits(acc);
+                        }
+                        hotDone |= 1u << k;
+                    }
+                } else if (hk == HOT_SUM_I64) {
+                    const uint64_t* src = reinterpret_cast<const uint64_t*>(gLds + ReadLane32(tHotOff, k));
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint64_t x = src[u * kBlock + threadIdx.x];
+#pragma unroll
+                        for (int g = 0; g < kHotGroups; ++g) hot[g][k] += ((hit[g] >> u) & 1u) ? x : 0ull;
+                    }
+                    hotDone |= 1u << k;
+                } else if (hk == HOT_ROWS) {
+#pragma unroll
+                    for (int g = 0; g < kHotGroups; ++g) hot[g][k] += uint64_t(__popc(hit[g]));
+                    hotDone |= 1u << k;
+                }
+            }
+        }
+
+        // Table path: everything else, and the rows of groups that are not register-held.
+        for (int k = 0; k < naggs && !(a.debug_flags & (2 | 16)); ++k) {
+            uint32_t live = m.P & (((hotDone >> k) & 1u) ? ~hotRows : ~0u);
+            if (!__any(live != 0)) continue;
+            AggSpec spec;
+            spec.kind = int32_t(ReadLane32(tAggKind, k));
+            spec.reg = int32_t(ReadLane32(tAggReg, k));
+            spec.check_valid = int32_t(ReadLane32(tAggCheck, k));
+            spec.fetch_kind = ReadLane32(tAggFk, k);
+            spec.fetch_payload = ReadLane32(tAggPayload, k);
+            Val<U> x;
+            if (spec.reg != -1) {
                 m.FetchOperand(spec.fetch_kind, spec.fetch_payload, x);
                 if (spec.check_valid) live &= x.ok;
             }
             if (live == 0) continue;
             const int kind = spec.kind;
+            if (spec.check_valid) {
+                // a nullable argument was seen for the group: set once
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!((live >> u) & 1u)) continue;
+                    if (slot[u] >= 0) {
+                        if (!((lSeen[slot[u]] >> k) & 1u)) atomicOr(lSeen + slot[u], 1u << k);
+                    } else {
+                        uint32_t* g = s.t_seen + (-2 - slot[u]);
+                        if (!((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> k) & 1u)) atomicOr(g, 1u << k);
+                    }
+                }
+            }
             if (kind == AGG_COUNT) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) x.v[u] = 1;
@@ -341,18 +505,24 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
                     AccUpdate(kind, tabK + (-2 - slot[u]), x.v[u]);
                 }
             }
-            if (spec.check_valid) {
-                // a nullable argument was seen for the group: set once
+        }
+    }
+
+    // fold the register accumulators into level 1 (dense ids 0 .. kHotGroups-1): wave butterfly, then one lane adds
+    if (useHot) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!((m.P & x.ok) >> u & 1u)) continue;
-                    if (slot[u] >= 0) {
-                        if (!((lSeen[slot[u]] >> k) & 1u)) atomicOr(lSeen + slot[u], 1u << k);
-                    } else {
-                        uint32_t* g = s.t_seen + (-2 - slot[u]);
-                        if (!((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> k) & 1u)) atomicOr(g, 1u << k);
-                    }
+        for (int k = 0; k < kHotAggs; ++k) {
+            const int hk = int(ReadLane32(tHotKind, k));
+            if (hk == HOT_NONE) continue;
+#pragma unroll
+            for (int g = 0; g < kHotGroups; ++g) {
+                uint64_t v = hot[g][k];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const uint64_t o = uint64_t(__shfl_xor(static_cast<unsigned long long>(v), off, 64));
+                    v = hk == HOT_SUM_F64 ? F64ToBits(BitsToF64(v) + BitsToF64(o)) : v + o;
                 }
+                if ((threadIdx.x & 63) == 0 && v != 0) AccUpdate(hk == HOT_SUM_F64 ? AGG_SUM_F : AGG_SUM_I, lAcc + (size_t(k) * L + g) * R, v);
             }
         }
     }
@@ -363,20 +533,22 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         const uint64_t lo = lLo[i];
         if (lo == kEmpty) continue;
         const uint64_t hi = twoWords ? lHi[i] : 0ull;
+        const uint32_t d = lDense[i];
         const uint64_t h = Mix64(lo ^ Mix64(twoWords ? hi : 0ull));
         const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, h >> 20, lo, hi, twoWords, 4096u);
         if (g < 0) {
             m.err |= SCAN_TABLE_FULL;
             continue;
         }
+        if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(s.t_rep_row + g), static_cast<unsigned long long>(lRep[i]));
         for (int k = 0; k < naggs; ++k) {
             const int kind = s.aggs[k].kind;
-            const uint64_t* src = lAcc + (size_t(k) * L + i) * R;
+            const uint64_t* src = lAcc + (size_t(k) * L + d) * R;
             uint64_t v = src[0];
             for (int r = 1; r < R; ++r) v = TableCombine(kind, v, src[r]);
             if (v != TableIdentity(kind)) AccUpdate(kind, s.t_acc + size_t(k) * (s.table_mask + 1) + g, v);
         }
-        const uint32_t seen = lSeen[i];
+        const uint32_t seen = lSeen[d];
         if (seen) atomicOr(s.t_seen + g, seen);
     }
     m.ReportErrors();
@@ -402,15 +574,16 @@ __global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArg
         if (klo == kEmpty) continue;
         const int64_t g = int64_t(atomicAdd(f.counter, 1ull));  // output order is unspecified
         const uint32_t seen = f.t_seen[i];
+        if (f.group_rep_row != nullptr) f.group_rep_row[g] = f.t_rep_row[i];
         for (int k = 0; k < f.naggs; ++k) {
             const int kind = f.aggs[k].kind;
-            uint64_t v = f.t_acc[size_t(k) * f.capacity + i];
+            uint64_t v = f.t_acc[size_t(f.agg_src[k]) * f.capacity + i];
             bool valid = true;
             if (f.agg_row_index[k]) {
                 valid = v != ~0ull;  // smallest row with a non-null argument, none -> null
             } else {
                 if (kind == AGG_MIN_F || kind == AGG_MAX_F) v = F64FromOrdered(v);
-                if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> k) & 1u;
+                if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> f.agg_src[k]) & 1u;
                 if (!valid) v = 0;
                 v = PayloadToStored(v, f.agg_out_type[k]);
             }

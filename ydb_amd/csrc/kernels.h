@@ -43,21 +43,27 @@ struct ProjectSink {
 
 // Group-by: open-addressing table in global memory (the "spill table"), fronted by a small
 // per-workgroup table in LDS that absorbs the hot groups.
+// Aggregates the keyed sink keeps in registers for the first groups of a workgroup.
+constexpr int kHotAggs = 6;
+enum HotKind : int32_t { HOT_NONE = 0, HOT_SUM_F64 = 1, HOT_SUM_I64 = 2, HOT_ROWS = 3 };
+
 struct KeyedSink {
-    int32_t naggs;           // including the representative-row aggregate of hashed keys
+    int32_t naggs;           // distinct accumulators (identical aggregates of the step share one)
     int32_t nkeys;
-    AggSpec aggs[kMaxAggs + 1];
+    AggSpec aggs[kMaxAggs];
     KeySpec keys[kMaxKeys];
     int32_t two_words;       // keys use the hi word
     int32_t hashed;          // keys are 126-bit hashes (strings / more than 119 key bits)
-    int32_t rep_row_agg;     // index of the MIN(row index) aggregate kept for hashed keys, else -1
     int32_t lds_cap;         // level-1 (LDS) table slots, power of two, 0 = none
     int32_t lds_rep;         // accumulator replicas per level-1 slot, power of two
     uint64_t table_mask;     // level-2 capacity - 1
     uint64_t* t_key_lo;      // [cap] ~0 = free
     uint64_t* t_key_hi;      // [cap] ~0 = not yet published
     uint64_t* t_acc;         // [naggs][cap]
-    uint32_t* t_seen;        // [cap] bit k: aggregate k saw a non-null argument
+    uint32_t* t_seen;        // [cap] bit k: accumulator k saw a non-null argument
+    uint64_t* t_rep_row;     // [cap] hashed keys: smallest representative row index seen for the group (~0 = none)
+    int32_t hot_kind[kHotAggs];  // register path of accumulator k (HotKind)
+    int32_t hot_off[kHotAggs];   // LDS byte offset of its 64-bit operand tile
 };
 
 struct LaunchCfg {
@@ -106,18 +112,21 @@ struct KeyedFinalizeArgs {
     const uint64_t* t_key_hi;
     const uint64_t* t_acc;
     const uint32_t* t_seen;
+    const uint64_t* t_rep_row;
     unsigned long long* counter;      // zeroed; ends as the number of groups
-    int32_t naggs;
+    int32_t naggs;                    // output aggregates (the step's GroupBy list)
     int32_t nkeys;
     int32_t two_words;
     int32_t hashed;
-    AggSpec aggs[kMaxAggs + 1];
-    int32_t agg_out_type[kMaxAggs + 1];
-    int32_t agg_row_index[kMaxAggs + 1];  // the accumulator is a row index (some(), representative row): raw uint64 out
+    AggSpec aggs[kMaxAggs];
+    int32_t agg_src[kMaxAggs];        // accumulator each output aggregate reads
+    int32_t agg_out_type[kMaxAggs];
+    int32_t agg_row_index[kMaxAggs];  // the accumulator is a row index (some()): raw uint64 out
     KeySpec keys[kMaxKeys];
     // outputs (one row per group)
-    void* agg_vals[kMaxAggs + 1];
-    uint8_t* agg_valid_bytes[kMaxAggs + 1];
+    uint64_t* group_rep_row;          // hashed keys: representative input row of each group
+    void* agg_vals[kMaxAggs];
+    uint8_t* agg_valid_bytes[kMaxAggs];
     void* key_vals[kMaxKeys];         // exact keys only: decoded from the table
     uint8_t* key_valid_bytes[kMaxKeys];
 };
