@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: TPC-H SF100 lineitem)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank uses cuda:0 and the exchange runs over gloo (checks the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -80,11 +82,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the scan kernels have no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    gather_dev = dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            gather_dev = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     rows = args.rows or tpch.SF100_ROWS
     codes = args.workload == "q1_codes"
@@ -109,18 +118,18 @@ def main():
 
     result = None
     for _ in range(args.warmup):
-        result = scan.run(batch, gather_device=dev)
+        result = scan.run(batch, gather_device=gather_dev)
     scan.local.EnableProfile(True)
     scan.local.ReadProfile()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        result = scan.run(batch, gather_device=dev)
+        result = scan.run(batch, gather_device=gather_dev)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches, algo_bytes = scan.local.ReadProfile()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -614,10 +614,10 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
         d.valid_bit_off = col.ValidBitOff;
         args.lds_col_off[c] = -1;
         const int w = TypeWidth(col.Field.Type);
-        if (w >= 1 && w <= 8 && (reinterpret_cast<uintptr_t>(d.values) & 15) == 0 &&
-            lds + kTileRows * w <= kLdsStageBudget) {
+        const int sw = StageWidth(col.Field.Type);  // strings: their int32 offsets
+        if (sw >= 1 && (reinterpret_cast<uintptr_t>(d.values) & 15) == 0 && lds + kTileRows * sw <= kLdsStageBudget) {
             args.lds_col_off[c] = lds;
-            lds += kTileRows * w;
+            lds += kTileRows * sw;
         }
         // algorithmic bytes: every referenced source column once
         if (IsStringLike(col.Field.Type)) {

@@ -41,6 +41,18 @@ __device__ __forceinline__ uint64_t Mix64(uint64_t x) {
     return x;
 }
 
+// Table position of a key.  Only the spread matters (equality is decided on the key words), so 32 bits of
+// multiply-xorshift are enough; both table levels take their index from it.
+__device__ __forceinline__ uint32_t Fold32(uint64_t lo, uint64_t hi) {
+    uint32_t x = uint32_t(lo) ^ (uint32_t(lo >> 32) * 0x9E3779B1u) ^ (uint32_t(hi) * 0x85EBCA6Bu) ^ (uint32_t(hi >> 32) * 0xC2B2AE35u);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
 // Order-preserving map double -> uint64 (so float min/max become integer atomics) and back.
 __device__ __forceinline__ uint64_t OrderedFromF64(uint64_t bits) {
     return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
@@ -142,8 +154,10 @@ struct HashPair {
     uint64_t lo, hi;
 };
 __device__ __forceinline__ void AbsorbWord(HashPair& h, uint64_t w) {
-    h.lo = Mix64(h.lo ^ w);
-    h.hi = Mix64(h.hi + w * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull);
+    h.lo = (h.lo ^ w) * 0x9E3779B97F4A7C15ull;
+    h.lo ^= h.lo >> 29;
+    h.hi = (h.hi + w) * 0xC2B2AE3D27D4EB4Full;
+    h.hi ^= h.hi >> 31;
 }
 __device__ __noinline__ HashPair AbsorbString(HashPair h, const uint8_t* p, int32_t n) {
     AbsorbWord(h, uint64_t(uint32_t(n)));
@@ -180,6 +194,16 @@ struct KeyBuilder {
             hi[u] |= bits << (pos - 64);
         }
     }
+    // exact packing at a per-row position (rows of a batch with string keys differ in length)
+    __device__ __forceinline__ void AppendAt(int u, uint64_t bits, uint32_t nbits, uint32_t& at) {
+        if (at < 64) {
+            lo[u] |= bits << at;
+            if (at > 0 && at + nbits > 64) hi[u] |= bits >> (64 - at);
+        } else if (at < 128) {
+            hi[u] |= bits << (at - 64);
+        }
+        at += nbits;
+    }
     // hashed: absorb one 64-bit word into both lanes of the hash
     __device__ __forceinline__ void Absorb(int u, uint64_t w) {
         HashPair h{lo[u], hi[u]};
@@ -191,8 +215,8 @@ struct KeyBuilder {
     // equals the unpublished marker: exact keys keep its top byte zero, hashed keys force 0b10 on top.
     __device__ __forceinline__ void Finish(int u, bool hashed) {
         if (hashed) {
-            lo[u] &= 0x7FFFFFFFFFFFFFFFull;
-            hi[u] = (hi[u] | 0x8000000000000000ull) & ~0x4000000000000000ull;
+            lo[u] = Mix64(lo[u]) & 0x7FFFFFFFFFFFFFFFull;
+            hi[u] = (Mix64(hi[u]) | 0x8000000000000000ull) & ~0x4000000000000000ull;
         } else {
             const uint64_t l = lo[u], h = hi[u];
             lo[u] = l & 0x7FFFFFFFFFFFFFFFull;
@@ -253,14 +277,17 @@ __device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint
 
 }  // namespace
 
-template <int U>
+// kHashed: the batch has string keys or more than 119 key bits (per-row packing with a hash for rows that do not fit);
+// otherwise all keys pack exactly at wave-uniform positions.
+template <int U, bool kHashed>
 __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>) {
     const ScanArgs& a = KernArgs<KeyedSink>().a;
     const KeyedSink& s = KernArgs<KeyedSink>().s;
     Machine<U> m(a);
     const int naggs = s.naggs;
     const int L = s.lds_cap, R = s.lds_rep;
-    const bool twoWords = s.two_words != 0, hashed = s.hashed != 0;
+    const bool twoWords = kHashed || s.two_words != 0;
+    constexpr bool hashed = kHashed;
     // level-1 table in the sink area of LDS:
     //   by hash position: lo[L], hi[L], rep[L], dense[L];  by dense id: acc[naggs][L][R], seen[L];  count
     uint64_t* lLo = reinterpret_cast<uint64_t*>(gLds + a.lds_sink_off);
@@ -316,9 +343,16 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         m.Run();
         if (m.P == 0) continue;
 
-        // keys of the lane's rows
+        // Keys of the lane's rows.  Batches whose keys all have a fixed width of at most 119 bits pack them at
+        // wave-uniform positions.  Otherwise every row first tries the same exact packing at its own positions, a
+        // string of up to 8 bytes as (length byte, bytes); rows that do not fit in 119 bits -- and only those -- are
+        // reduced to a 126-bit hash.  Exact and hashed keys cannot meet: they differ in the top bits of `hi`.
         KeyBuilder<U> kb;
-        kb.Begin(hashed);
+        kb.Begin(false);
+        uint32_t at[U];
+        uint32_t toHash = 0;  // bit u: row u needs the hash
+#pragma unroll
+        for (int u = 0; u < U; ++u) at[u] = 0;
         for (int k = 0; k < nkeys; ++k) {
             KeySpec ks;
             ks.col = int32_t(ReadLane32(tKeyCol, k));
@@ -326,18 +360,22 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             ks.nullable = int32_t(ReadLane32(tKeyNullable, k));
             ks.fetch_kind = ReadLane32(tKeyFk, k);
             ks.fetch_payload = ReadLane32(tKeyPayload, k);
-            if (ks.col >= 0) {
-                // string key (always hashed); the validity of the column is not part of these keys
+            if (kHashed && ks.col >= 0) {
+                // string key; the validity of the column is not part of these keys
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if ((m.P >> u) & 1u) {
-                        const uint8_t* p;
-                        int32_t n;
-                        m.StringAt(ks.col, m.Row(u), p, n);
-                        const HashPair h = AbsorbString(HashPair{kb.lo[u], kb.hi[u]}, p, n);
-                        kb.lo[u] = h.lo;
-                        kb.hi[u] = h.hi;
+                    if (!((m.P >> u) & 1u)) continue;
+                    const uint8_t* p;
+                    int32_t n;
+                    m.StringAt(ks.col, u, p, n);
+                    if (n > 8) {
+                        toHash |= 1u << u;
+                        continue;
                     }
+                    uint64_t w = 0;
+                    for (int32_t j = 0; j < n; ++j) w |= uint64_t(p[j]) << (8 * j);
+                    kb.AppendAt(u, uint64_t(uint32_t(n)), 8, at[u]);
+                    kb.AppendAt(u, w, uint32_t(8 * n), at[u]);
                 }
                 continue;
             }
@@ -349,19 +387,53 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             for (int u = 0; u < U; ++u) {
                 const bool isNull = ks.nullable && !((x.ok >> u) & 1u);
                 const uint64_t bits = isNull ? 0ull : (PayloadToStored(x.v[u], ks.type) & wmask);
-                if (hashed) {
-                    kb.Absorb(u, bits);
-                    if (ks.nullable) kb.Absorb(u, isNull ? 1ull : 0ull);
+                if constexpr (hashed) {
+                    kb.AppendAt(u, bits, uint32_t(nbits), at[u]);
+                    if (ks.nullable) kb.AppendAt(u, isNull ? 1ull : 0ull, 1, at[u]);
                 } else {
                     kb.Append(u, bits, nbits);
                 }
             }
-            if (!hashed) {
+            if constexpr (!hashed) {
                 kb.pos += nbits;
                 if (ks.nullable) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) kb.Append(u, ((x.ok >> u) & 1u) ? 0ull : 1ull, 1);
                     kb.pos += 1;
+                }
+            }
+        }
+        if constexpr (hashed) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (at[u] > 119) toHash |= 1u << u;
+            }
+            toHash &= m.P;
+            if (__any(toHash != 0)) {
+                // the rare rows: long strings or more than 119 key bits
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!((toHash >> u) & 1u)) continue;
+                    HashPair h{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+                    for (int k = 0; k < nkeys; ++k) {
+                        const int col = int32_t(ReadLane32(tKeyCol, k));
+                        if (col >= 0) {
+                            const uint8_t* p;
+                            int32_t n;
+                            m.StringAt(col, u, p, n);
+                            h = AbsorbString(h, p, n);
+                        } else {
+                            Val<U> x;
+                            m.FetchOperand(ReadLane32(tKeyFk, k), ReadLane32(tKeyPayload, k), x);
+                            const int type = int32_t(ReadLane32(tKeyType, k));
+                            const bool nullable = ReadLane32(tKeyNullable, k) != 0;
+                            const bool isNull = nullable && !((x.ok >> u) & 1u);
+                            AbsorbWord(h, isNull ? 0ull : (PayloadToStored(x.v[u], type) & WidthMask(8 * TypeWidth(type))));
+                            if (nullable) AbsorbWord(h, isNull ? 1ull : 0ull);
+                        }
+                    }
+                    kb.lo[u] = h.lo;
+                    kb.hi[u] = h.hi;
                 }
             }
         }
@@ -372,13 +444,13 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         for (int u = 0; u < U; ++u) {
             slot[u] = -1;
             if (!((m.P >> u) & 1u)) continue;
-            kb.Finish(u, hashed);
-            const uint64_t h = Mix64(kb.lo[u] ^ Mix64(kb.hi[u]));
+            kb.Finish(u, ((toHash >> u) & 1u) != 0);
+            const uint32_t h = Fold32(kb.lo[u], kb.hi[u]);
             int64_t sl = -1;
             if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
                                            uint64_t(m.Row(u)), ldsProbes);
             if (sl < 0) {
-                const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, h >> 20, kb.lo[u], kb.hi[u], twoWords, 4096u);
+                const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, kb.lo[u], kb.hi[u], twoWords, 4096u);
                 if (g < 0) {
                     m.err |= SCAN_TABLE_FULL;
                     m.P &= ~(1u << u);
@@ -534,8 +606,8 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         if (lo == kEmpty) continue;
         const uint64_t hi = twoWords ? lHi[i] : 0ull;
         const uint32_t d = lDense[i];
-        const uint64_t h = Mix64(lo ^ Mix64(twoWords ? hi : 0ull));
-        const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, h >> 20, lo, hi, twoWords, 4096u);
+        const uint32_t h = Fold32(lo, twoWords ? hi : 0ull);
+        const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, lo, hi, twoWords, 4096u);
         if (g < 0) {
             m.err |= SCAN_TABLE_FULL;
             continue;
@@ -680,13 +752,20 @@ uint64_t KeyedTableIdentity(int aggKind) { return TableIdentity(aggKind); }
 
 hipError_t LaunchScanKeyed(const ScanArgs& a, const KeyedSink& s, LaunchCfg cfg) {
     KArgs<KeyedSink> k{a, s};
-    hipLaunchKernelGGL((ScanKeyedKernel<kRowsPerThread>), dim3(cfg.grid), dim3(kBlock), cfg.lds_bytes, cfg.stream, k);
+    if (s.hashed) {
+        hipLaunchKernelGGL((ScanKeyedKernel<kRowsPerThread, true>), dim3(cfg.grid), dim3(kBlock), cfg.lds_bytes, cfg.stream, k);
+    } else {
+        hipLaunchKernelGGL((ScanKeyedKernel<kRowsPerThread, false>), dim3(cfg.grid), dim3(kBlock), cfg.lds_bytes, cfg.stream, k);
+    }
     return hipGetLastError();
 }
 
 hipError_t ConfigureKeyedKernels(int maxLdsBytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanKeyedKernel<kRowsPerThread>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanKeyedKernel<kRowsPerThread, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanKeyedKernel<kRowsPerThread, false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    return e;
 }
 
 hipError_t LaunchKeyedCount(const uint64_t* tKeyLo, uint64_t capacity, unsigned long long* count, hipStream_t st) {

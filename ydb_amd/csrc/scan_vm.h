@@ -221,7 +221,7 @@ struct Machine {
         for (int col = 0; col < a.ncols; ++col) {
             const int off = a.lds_col_off[col];
             if (off < 0) continue;
-            const int w = TypeWidth(a.cols[col].type);
+            const int w = StageWidth(a.cols[col].type);
             const int np = (kTile * w) >> 10;
             if (lane >= acc && lane < acc + np) {
                 tPieceSrc = reinterpret_cast<uint64_t>(a.cols[col].values) + uint64_t(lane - acc) * 1024u;
@@ -338,10 +338,24 @@ struct Machine {
         }
     }
 
-    __device__ __forceinline__ void StringAt(int c, int64_t row, const uint8_t*& p, int32_t& n) const {
+    // Bytes of the string in row u of the lane.  Offsets come from the staged tile when the column's offsets are in
+    // LDS.  Only the offsets of the tile's own rows are staged (and in the last tile only those below `nrows`), so
+    // the end offset of the tile's last row and of the batch's last row is read from memory.
+    __device__ __forceinline__ void StringAt(int c, int u, const uint8_t*& p, int32_t& n) const {
         const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, c));
         const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
-        const int32_t b = offs[row], e = offs[row + 1];
+        const int off = int(ReadLane32(tColOff, c));
+        const int64_t row = Row(u);
+        int32_t b, e;
+        if (off >= 0) {
+            const int32_t* l = reinterpret_cast<const int32_t*>(gLds + off);
+            const int idx = u * kBlock + int(threadIdx.x);
+            b = l[idx];
+            e = (idx + 1 < kTile && row + 1 < nrows) ? l[idx + 1] : offs[row + 1];
+        } else {
+            b = offs[row];
+            e = offs[row + 1];
+        }
         p = chars + b;
         n = e - b;
     }
@@ -645,7 +659,7 @@ struct Machine {
                 if ((act >> u) & 1u) {
                     const uint8_t* s;
                     int32_t n;
-                    StringAt(si, Row(u), s, n);
+                    StringAt(si, u, s, n);
                     m = StrMatchOutlined(fb & 15, (fb & 16) != 0, s, n, pp, pn) ? 1 : 0;
                 }
                 A.v[u] = m;
@@ -671,8 +685,8 @@ struct Machine {
                 if ((act >> u) & 1u) {
                     const uint8_t* s;
                     int32_t n;
-                    StringAt(si, Row(u), s, n);
-                    if (rhsCol) StringAt(fa, Row(u), pp, pn);
+                    StringAt(si, u, s, n);
+                    if (rhsCol) StringAt(fa, u, pp, pn);
                     m = CmpFromOrder(fb & 15, StrCompareOutlined(s, n, pp, pn)) ? 1 : 0;
                 }
                 A.v[u] = m;

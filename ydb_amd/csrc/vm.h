@@ -58,6 +58,14 @@ SSA_HD int TypeWidth(int t) {  // bytes of one fixed-width value, 0 for bit-pack
     }
 }
 
+// Bytes per row of the buffer a scan stages into LDS: the values of a fixed-width column, the int32 offsets of a
+// string column (0: nothing to stage).
+SSA_HD int StageWidth(int t) {
+    const int w = TypeWidth(t);
+    if (w >= 1 && w <= 8) return w;
+    return (t == T_STRING || t == T_BINARY) ? 4 : 0;
+}
+
 // Value classes: how a 64-bit VM payload is interpreted by an instruction.
 enum ValClass : int32_t {
     CLS_I = 0,    // signed integer, sign-extended to 64 bits
