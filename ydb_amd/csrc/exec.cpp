@@ -591,8 +591,8 @@ void EncodeOperand(const ScanArgs& args, int reg, uint32_t& fk, uint32_t& payloa
     }
 }
 
-Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, ScanArgs& args, LaunchCfg& cfg,
-                              int64_t& algoBytes) {
+Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, int kernelId, ScanArgs& args,
+                              LaunchCfg& cfg, int64_t& algoBytes) {
     std::memset(&args, 0, sizeof(args));
     args.nrows = in.Rows;
     args.ncols = int32_t(plan.SourceColumns.size());
@@ -632,6 +632,104 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     }
     for (size_t i = 0; i < plan.Consts.size(); ++i) args.consts[i] = plan.Consts[i];
     if (plan.Code.size() > size_t(kMaxCode)) return Status::Unsupported("step too long for one scan program");
+    std::memcpy(args.pattern, plan.PatternBytes.data(), plan.PatternBytes.size());
+    args.nregs = plan.NumRegsUsed;
+
+    // Liveness of the staged columns inside the step program: the instruction that reads a column last, and the
+    // first store into every register.  Columns the sink reads (aggregate arguments, keys) live to the end.
+    const int kLiveToEnd = 1 << 30;
+    int lastUse[kMaxCols], useCount[kMaxCols], firstStore[kMaxRegs];
+    for (int c = 0; c < kMaxCols; ++c) lastUse[c] = -1, useCount[c] = 0;
+    for (int r = 0; r < kMaxRegs; ++r) firstStore[r] = kLiveToEnd;
+    for (size_t i = 0; i < plan.Code.size(); ++i) {
+        const uint32_t ins = plan.Code[i];
+        const int op = InsnOp(ins), sk = InsnSk(ins), si = InsnSi(ins);
+        if (sk == SRC_COL) {
+            lastUse[si] = int(i);
+            ++useCount[si];
+        }
+        if (op == OP_STRLEN || op == OP_STRMATCH || op == OP_STRCMP) {
+            lastUse[si] = kLiveToEnd;
+            if (op == OP_STRCMP && (InsnB(ins) & 16)) lastUse[InsnA(ins)] = kLiveToEnd;
+        }
+        if (op == OP_ST) firstStore[si] = std::min(firstStore[si], int(i));
+    }
+    auto sinkUses = [&](int reg) {
+        if (reg <= -2) lastUse[-2 - reg] = kLiveToEnd;
+    };
+    for (const AggPlan& ap : plan.Aggs) sinkUses(ap.Spec.reg);
+    for (const KeyPlan& kp : plan.Keys) {
+        sinkUses(kp.Spec.reg);
+        if (kp.Spec.col >= 0) lastUse[kp.Spec.col] = kLiveToEnd;
+    }
+    const bool noTuning = std::getenv("SSA_NO_LDS_TUNING") != nullptr;
+
+    // A register whose first store comes after the last read of an 8-byte staged column takes over that column's tile
+    // (every lane reads and writes only its own rows, so overwriting in place is race-free).
+    bool taken[kMaxCols] = {false};
+    int regAlias[kMaxRegs];
+    int freshRegs = 0;
+    for (int r = 0; r < plan.NumRegsUsed; ++r) {
+        regAlias[r] = -1;
+        for (int c = 0; c < args.ncols && !noTuning; ++c) {
+            if (taken[c] || args.lds_col_off[c] < 0 || TypeWidth(args.cols[c].type) != 8) continue;
+            if (lastUse[c] >= 0 && lastUse[c] < firstStore[r]) {
+                regAlias[r] = c;
+                taken[c] = true;
+                break;
+            }
+        }
+        if (regAlias[r] < 0) ++freshRegs;
+    }
+    auto totalLds = [&](int stagedBytes) {
+        int t = stagedBytes + freshRegs * kTileRows * 8 + plan.NumRegsUsed * kBlock;
+        t = (t + 15) & ~15;
+        return t + sinkLdsBytes;
+    };
+    auto blocksPerCU = [&](int total) { return std::max(1, std::min(8, kLdsPerCU / (total + 1024))); };
+    // Narrow columns the program reads exactly once gain little from staging: give their tiles up when that lets one
+    // more workgroup fit on a CU.
+    if (!noTuning && std::getenv("SSA_UNSTAGE") != nullptr) {
+        std::vector<int> cand;
+        for (int c = 0; c < args.ncols; ++c) {
+            if (args.lds_col_off[c] >= 0 && !taken[c] && lastUse[c] != kLiveToEnd && useCount[c] == 1 &&
+                StageWidth(args.cols[c].type) <= 4 && TypeWidth(args.cols[c].type) > 0) cand.push_back(c);
+        }
+        std::sort(cand.begin(), cand.end(), [&](int x, int y) { return StageWidth(args.cols[x].type) < StageWidth(args.cols[y].type); });
+        const int base = blocksPerCU(totalLds(lds));
+        int dropped = 0;
+        for (size_t n = 1; n <= cand.size(); ++n) {
+            dropped += kTileRows * StageWidth(args.cols[cand[n - 1]].type);
+            if (blocksPerCU(totalLds(lds - dropped)) > base) {
+                for (size_t j = 0; j < n; ++j) args.lds_col_off[cand[j]] = -1;
+                break;
+            }
+        }
+        // re-pack the staged tiles
+        lds = 0;
+        for (int c = 0; c < args.ncols; ++c) {
+            if (args.lds_col_off[c] < 0) continue;
+            args.lds_col_off[c] = lds;
+            lds += kTileRows * StageWidth(args.cols[c].type);
+        }
+    }
+    for (int r = 0; r < kMaxRegs; ++r) args.lds_reg_offs[r] = 0;
+    for (int r = 0; r < plan.NumRegsUsed; ++r) {
+        if (regAlias[r] >= 0) {
+            args.lds_reg_offs[r] = args.lds_col_off[regAlias[r]];
+        } else {
+            args.lds_reg_offs[r] = lds;
+            lds += kTileRows * 8;
+        }
+    }
+    args.lds_regok_off = lds;
+    lds += plan.NumRegsUsed * kBlock;
+    lds = (lds + 15) & ~15;
+    args.lds_sink_off = lds;
+    lds += sinkLdsBytes;
+    if (lds > kLdsPerCU - 1024) return Status::Unsupported("step needs more LDS than one CU has");
+
+    // pre-decode the step program against the final LDS plan
     for (size_t i = 0; i < plan.Code.size(); ++i) {
         const uint32_t ins = plan.Code[i];
         const int op = InsnOp(ins), sk = InsnSk(ins), si = InsnSi(ins), fa = InsnA(ins), fb = InsnB(ins);
@@ -657,19 +755,9 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
         args.code[3 * i + 2] = ins;
     }
 
-    std::memcpy(args.pattern, plan.PatternBytes.data(), plan.PatternBytes.size());
-    args.nregs = plan.NumRegsUsed;
-    args.lds_reg_off = lds;
-    lds += plan.NumRegsUsed * kTileRows * 8;
-    args.lds_regok_off = lds;
-    lds += plan.NumRegsUsed * kBlock;
-    lds = (lds + 15) & ~15;
-    args.lds_sink_off = lds;
-    lds += sinkLdsBytes;
-    if (lds > kLdsPerCU - 1024) return Status::Unsupported("step needs more LDS than one CU has");
-
     const int64_t ntiles = (in.Rows + kTileRows - 1) / kTileRows;
-    int perCU = kLdsPerCU / (lds + 1024);  // 1 KiB per workgroup for the kernels' static LDS and allocation granularity
+    // Resident workgroups per CU as the runtime computes them (LDS and registers); more than 4 has measured slower.
+    int perCU = std::min(4, ScanKernelBlocksPerCU(kernelId, uint32_t(lds)));
     if (const char* pc = std::getenv("SSA_BLOCKS_PER_CU")) perCU = std::atoi(pc);
     perCU = std::max(1, std::min(perCU, 8));
     int64_t grid = std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU);
@@ -814,7 +902,7 @@ Status Executor::RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, Bu
     ScanArgs args;
     LaunchCfg cfg;
     int64_t algoBytes;
-    SSA_RETURN_NOT_OK(FillScanArgs(filterPlan, in, 0, args, cfg, algoBytes));
+    SSA_RETURN_NOT_OK(FillScanArgs(filterPlan, in, 0, SCAN_FILTER, args, cfg, algoBytes));
     FilterSink sink{static_cast<uint64_t*>(bitmap->Ptr), static_cast<uint32_t*>(tileCounts->Ptr)};
     if (rows > 0) {
         ProfileBegin();
@@ -835,7 +923,7 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
     LaunchCfg cfg;
     int64_t algoBytes;
     const int naggs = int(plan.Aggs.size());
-    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, naggs * kBlock * 8, args, cfg, algoBytes));
+    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, naggs * kBlock * 8, SCAN_NOKEY, args, cfg, algoBytes));
     BufferPtr partial = Buffer::Alloc(size_t(cfg.grid) * kMaxAggs * 8);
     BufferPtr seen = Buffer::Alloc(size_t(cfg.grid) * 4);
     BufferPtr outVals = Buffer::Alloc(kMaxAggs * 8 + kMaxAggs);
@@ -930,7 +1018,7 @@ Status Executor::RunProject(const TProgramStep& step, const StepPlan& plan, cons
         ScanArgs args;
         LaunchCfg cfg;
         int64_t algoBytes;
-        SSA_RETURN_NOT_OK(FillScanArgs(outPlan, in, 0, args, cfg, algoBytes));
+        SSA_RETURN_NOT_OK(FillScanArgs(outPlan, in, 0, SCAN_PROJECT, args, cfg, algoBytes));
         ProjectSink sink{};
         sink.bitmap = filtered ? static_cast<const uint64_t*>(bitmap->Ptr) : nullptr;
         sink.tile_offsets = filtered ? static_cast<const int64_t*>(tileOffsets->Ptr) : nullptr;
@@ -1114,8 +1202,14 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     const uint64_t maxCap = std::max<uint64_t>(1024, NextPow2(uint64_t(in.Rows) * 2 + 2));
     uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(hint.TableCap, 1024), maxCap);
 
+    // Level-1 accumulators are replicated only when the table path carries the bulk of the updates: steps whose
+    // aggregates all run on the register path touch LDS accumulators just for their fifth and later groups.
+    bool allSimple = true;
+    for (const AggSpec& a : phys) {
+        allSimple = allSimple && !a.check_valid && ((a.kind == AGG_COUNT && a.reg == -1) || a.kind == AGG_SUM_F || a.kind == AGG_SUM_I);
+    }
     int L = hint.LdsCap, R = 1;
-    if (L == 16) {
+    if (L == 16 && !(allSimple && naggs <= kHotAggs)) {
         R = 8;
         while (R > 1 && L * R * naggs * 8 > 16 * 1024) R >>= 1;
     }
@@ -1132,7 +1226,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     ScanArgs args;
     LaunchCfg cfg;
     int64_t algoBytes = 0;
-    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, sinkLds, args, cfg, algoBytes));
+    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, sinkLds, hashed ? SCAN_KEYED_HASHED : SCAN_KEYED_EXACT, args, cfg, algoBytes));
     KeyedSink sink{};
     sink.naggs = naggs;
     sink.nkeys = nkeys;
@@ -1158,7 +1252,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         if (a.kind != AGG_SUM_F && a.kind != AGG_SUM_I) continue;
         int off = -1;
         if (a.reg >= 0) {
-            off = args.lds_reg_off + a.reg * kTileRows * 8;  // R registers hold 64-bit payloads
+            off = args.lds_reg_offs[a.reg];  // R registers hold 64-bit payloads
         } else if (a.reg <= -2 && (a.fetch_kind & 0x7F) == FK_LDS_64) {
             const int t = args.cols[-2 - a.reg].type;
             if ((a.kind == AGG_SUM_F) == (t == T_F64)) off = int(a.fetch_payload & 0xFFFFFFu);

@@ -103,8 +103,8 @@ private:
     Status RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& in, BatchPtr& out);
     Status RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,
                            int64_t& selected);
-    Status FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, ScanArgs& args, LaunchCfg& cfg,
-                        int64_t& algoBytes);
+    Status FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, int kernelId, ScanArgs& args,
+                        LaunchCfg& cfg, int64_t& algoBytes);
     Status CheckScanStatus(bool* tableFull = nullptr);
     Status CompactColumn(const Column& src, int64_t rows, const BufferPtr& bitmap, const BufferPtr& tileOffsets,
                          int64_t selected, Column& dst);

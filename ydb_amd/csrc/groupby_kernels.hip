@@ -760,6 +760,13 @@ hipError_t LaunchScanKeyed(const ScanArgs& a, const KeyedSink& s, LaunchCfg cfg)
     return hipGetLastError();
 }
 
+int KeyedKernelBlocksPerCU(bool hashed, uint32_t ldsBytes) {
+    int n = 0;
+    const hipError_t e = hashed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ScanKeyedKernel<kRowsPerThread, true>, kBlock, ldsBytes)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ScanKeyedKernel<kRowsPerThread, false>, kBlock, ldsBytes);
+    return (e == hipSuccess && n > 0) ? n : 1;
+}
+
 hipError_t ConfigureKeyedKernels(int maxLdsBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanKeyedKernel<kRowsPerThread, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);

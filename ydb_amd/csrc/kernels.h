@@ -76,6 +76,10 @@ hipError_t LaunchScanNoKey(const ScanArgs& a, const NoKeySink& s, LaunchCfg cfg)
 hipError_t LaunchScanFilter(const ScanArgs& a, const FilterSink& s, LaunchCfg cfg);
 hipError_t LaunchScanProject(const ScanArgs& a, const ProjectSink& s, LaunchCfg cfg);
 hipError_t LaunchScanKeyed(const ScanArgs& a, const KeyedSink& s, LaunchCfg cfg);
+// Workgroups of a scan kernel that fit on one CU with `ldsBytes` of dynamic LDS (registers and LDS both count).
+enum ScanKernelId : int { SCAN_NOKEY = 0, SCAN_FILTER = 1, SCAN_PROJECT = 2, SCAN_KEYED_EXACT = 3, SCAN_KEYED_HASHED = 4 };
+int ScanKernelBlocksPerCU(int kernelId, uint32_t ldsBytes);
+int KeyedKernelBlocksPerCU(bool hashed, uint32_t ldsBytes);
 // Raise the dynamic-LDS limit of the scan kernels (call once per device).
 hipError_t ConfigureScanKernels(int maxLdsBytes);
 

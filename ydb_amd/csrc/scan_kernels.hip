@@ -466,6 +466,19 @@ hipError_t LaunchScanProject(const ScanArgs& a, const ProjectSink& s, LaunchCfg 
     SSA_LAUNCH_SCAN(ScanProjectKernel, ProjectSink, a, s, cfg);
 }
 
+int ScanKernelBlocksPerCU(int kernelId, uint32_t ldsBytes) {
+    int n = 0;
+    hipError_t e = hipSuccess;
+    switch (kernelId) {
+        case SCAN_NOKEY: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ScanNoKeyKernel<kRowsPerThread>, kBlock, ldsBytes); break;
+        case SCAN_FILTER: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ScanFilterKernel<kRowsPerThread>, kBlock, ldsBytes); break;
+        case SCAN_PROJECT: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ScanProjectKernel<kRowsPerThread>, kBlock, ldsBytes); break;
+        case SCAN_KEYED_EXACT: return KeyedKernelBlocksPerCU(false, ldsBytes);
+        default: return KeyedKernelBlocksPerCU(true, ldsBytes);
+    }
+    return (e == hipSuccess && n > 0) ? n : 1;
+}
+
 hipError_t ConfigureScanKernels(int maxLdsBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanNoKeyKernel<kRowsPerThread>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);

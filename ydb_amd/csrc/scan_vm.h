@@ -185,6 +185,7 @@ struct Machine {
     uint32_t tColOff, tColType, tColW;       // column slot (lane & 15): LDS offset (or -1), TypeId, width
     uint32_t tColValBit, tColValidBit;
     uint64_t tColVal, tColValid, tColChars;
+    uint32_t tRegOff;                        // R register (lane): LDS offset of its value tile
     uint64_t tConstBits;                     // constant (lane)
     uint32_t tConstValid;
     uint64_t tPieceSrc;                      // staging piece (lane): column base + piece offset
@@ -209,6 +210,7 @@ struct Machine {
         tColVal = reinterpret_cast<uint64_t>(a.cols[c].values);
         tColValid = reinterpret_cast<uint64_t>(a.cols[c].validity);
         tColChars = reinterpret_cast<uint64_t>(a.cols[c].chars);
+        tRegOff = uint32_t(a.lds_reg_offs[lane & (kMaxRegs - 1)]);
         const int k = lane < kMaxConsts ? lane : 0;
         tConstBits = a.consts[k].bits;
         tConstValid = uint32_t(a.consts[k].valid);
@@ -308,14 +310,14 @@ struct Machine {
     // R registers live in LDS: lane t owns elements [u * kBlock + t] of every register, so no
     // barrier is needed between a store and a later fetch.
     __device__ __forceinline__ void FetchReg(int r, Val<U>& out) {
-        const uint64_t* vals = reinterpret_cast<const uint64_t*>(gLds + a.lds_reg_off) + size_t(r) * kTile;
+        const uint64_t* vals = reinterpret_cast<const uint64_t*>(gLds + ReadLane32(tRegOff, r));
 #pragma unroll
         for (int u = 0; u < U; ++u) out.v[u] = vals[u * kBlock + threadIdx.x];
         out.ok = (gLds + a.lds_regok_off)[r * kBlock + threadIdx.x];
     }
 
     __device__ __forceinline__ void StoreReg(int r, const Val<U>& in) {
-        uint64_t* vals = reinterpret_cast<uint64_t*>(gLds + a.lds_reg_off) + size_t(r) * kTile;
+        uint64_t* vals = reinterpret_cast<uint64_t*>(gLds + ReadLane32(tRegOff, r));
 #pragma unroll
         for (int u = 0; u < U; ++u) vals[u * kBlock + threadIdx.x] = in.v[u];
         (gLds + a.lds_regok_off)[r * kBlock + threadIdx.x] = uint8_t(in.ok);

@@ -249,7 +249,7 @@ struct ScanArgs {
     uint32_t* status;        // device word, OR-ed with ScanStatus bits
     // LDS plan of one workgroup (byte offsets into dynamic shared memory)
     int32_t lds_col_off[kMaxCols];  // staged tile of column c, or -1: read from global memory on demand
-    int32_t lds_reg_off;            // R register values: nregs x tile rows x 8 bytes
+    int32_t lds_reg_offs[kMaxRegs]; // R register r: tile rows x 8 bytes at this offset (may reuse a dead staged column)
     int32_t lds_regok_off;          // R register validity: nregs x lanes bytes
     int32_t nregs;
     int32_t lds_sink_off;           // first byte available to the sink (group-by table)
