@@ -134,6 +134,16 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        # HBM traffic of the scan kernel: measured in a separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), kept as
+        # a ratio to the algorithmic bytes of the same launch; null when no such measurement is committed.
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_b_pmc_traffic.json")) as f:
+                pmc = json.load(f).get(args.workload)
+            if pmc and "note" not in pmc and launches:
+                traffic = pmc["ratio_to_algorithmic"] * (algo_bytes / launches)
+        except OSError:
+            pass
         total_rows = rows * world * args.steps
         avg_kernel_s = (kernel_ms / 1e3) / max(1, launches)
         achieved = (algo_bytes / max(1, launches)) / avg_kernel_s / 1e9 if launches else 0.0
@@ -155,7 +165,7 @@ def main():
                        "groups": len(next(iter(result.values())).valid) if result else 0,
                        "parallelism": f"row-range shards x{world}, partial aggregates merged by RCCL all-gather + merge program"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "ScanKeyedKernel" if args.workload != "q6" else "ScanNoKeyKernel",
                          "avg_kernel_ms": 1e3 * avg_kernel_s, "launches": launches,
                          "algorithmic_bytes_per_launch": algo_bytes // max(1, launches)},
