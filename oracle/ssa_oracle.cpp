@@ -960,7 +960,8 @@ static DatumPtr Materialize(const DatumPtr& d, int64_t rows) {
     auto out = NewArray(d->ty, rows);
     const Store st = StoreOf(d->ty);
     for (int64_t r = 0; r < rows; ++r) {
-        if (st == S_I) out->i[r] = d->i[0]; else if (st == S_U) out->u[r] = d->u[0]; else if (st == S_F) out->f[r] = d->f[0]; else out->s[r] = d->s[0];
+        if (d->ty == DEC) { out->u[r] = d->u[0]; out->hi[r] = d->hi[0]; }
+        else if (st == S_I) out->i[r] = d->i[0]; else if (st == S_U) out->u[r] = d->u[0]; else if (st == S_F) out->f[r] = d->f[0]; else out->s[r] = d->s[0];
     }
     if (!d->ok.empty() && !d->ok[0]) out->ok.assign(rows, 0);
     return out;
@@ -1171,8 +1172,8 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
         if (g.fn != AG_COUNT) {
             const int t = a ? a->ty : NONE;
             if (g.fn == AG_SUM && SumOutType(t) == NONE) throw Error(std::string("Function 'sum' has no kernel matching input types (") + TyName(t) + ")");
-            if (g.fn == AG_SUM && t == DEC) throw Error("Unsupported: decimal128 SUM with keys");
             if (g.fn != AG_SUM && !(IsNum(t) || IsTemporal(t))) throw Error("Unsupported aggregate argument type");
+            if (g.fn == AG_SUM && t == DEC && key8) throw Error("Unsupported: decimal128 SUM on the lookup-table path");
         }
         args.push_back(a);
     }
@@ -1214,7 +1215,8 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
             const Store s = StoreOf(a->ty);
             switch (fn) {
                 case AG_SUM:  // AggregateFunctionSum.h:31-47: sequential adds in row order, integers wrap
-                    if (s == S_I) st.i[k] = int64_t(uint64_t(st.i[k]) + uint64_t(a->i[r]));
+                    if (a->ty == DEC) AddDec(st.u[k], st.hi[k], a->u[r], a->hi[r]);  // extension: wrapping 128-bit sum
+                    else if (s == S_I) st.i[k] = int64_t(uint64_t(st.i[k]) + uint64_t(a->i[r]));
                     else if (s == S_U) st.u[k] += a->u[r];
                     else st.f[k] += a->f[r];
                     break;
@@ -1249,6 +1251,7 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
             const GroupState& st = groups[size_t(g)];
             const bool valid = fn == AG_COUNT || st.has[k];
             if (!valid) { anyNull = true; continue; }
+            if (ot == DEC) { col->u[g] = st.u[k]; col->hi[g] = st.hi[k]; continue; }
             switch (StoreOf(ot)) {
                 case S_I: col->i[g] = st.i[k]; break;
                 case S_U: col->u[g] = st.u[k]; break;

@@ -107,6 +107,10 @@ class OracleColumn:
                 out.append(None)
             else:
                 v = self.values[i]
+                if self.type == "decimal128":  # two's-complement 128-bit integer from its (lo, hi) words
+                    x = int(v[0]) | (int(v[1]) << 64)
+                    out.append(x - (1 << 128) if x >> 127 else x)
+                    continue
                 if isinstance(v, (bytes, bytearray)):
                     out.append(v.decode() if self.type == "string" else bytes(v))
                 elif isinstance(v, np.generic):

@@ -381,3 +381,42 @@ def test_multi_step_program():
          .project([220, 221, 6, 5]))
     got, exp = both(LI, p, b)
     compare_batches(got, exp, key_names=["flag", "status"], float_sum_names=["220"])
+
+
+def _decimal_column(rng, n, nulls=0.0):
+    """(n, 2) uint64 [lo, hi] words of signed 128-bit values around +-2^70 (carries out of the low word are common)."""
+    vals = [int(rng.integers(-(1 << 62), 1 << 62)) * int(rng.integers(1, 1 << 9)) + int(rng.integers(0, 1 << 40)) for _ in range(n)]
+    words = np.array([[v & ((1 << 64) - 1), (v >> 64) & ((1 << 64) - 1)] for v in vals], dtype=np.uint64).reshape(n, 2)
+    valid = (rng.random(n) >= nulls) if nulls > 0 else None
+    return vals, Col(words, valid=valid, decimal=(38, 4))
+
+
+@pytest.mark.parametrize("n", [0, 1, 1000, 30_000])
+@pytest.mark.parametrize("nulls", [0.0, 0.2])
+def test_decimal128_sum(n, nulls):
+    """Extension without a counterpart in the reference (parity unpinned): checked against the oracle's definition and
+    against Python integers."""
+    rng = np.random.default_rng(9000 + n)
+    vals, dec = _decimal_column(rng, n, nulls)
+    key = rng.integers(0, 5, n).astype(np.int32)
+    flt = rng.random(n) > 0.3
+    res = [(1, "d"), (2, "k"), (3, "f")]
+    batch = {"d": dec, "k": key, "f": flt}
+    p = Program().filter(3).group_by([Aggregate(10, AGG.SUM, [1]), Aggregate(11, AGG.COUNT, [1])])
+    got, exp = both(res, p, batch)
+    compare_batches(got, exp)
+    assert got["10"].type == "decimal128"
+    ok = flt & (dec.valid if dec.valid is not None else True)
+    want = sum(v for v, o in zip(vals, ok) if o)
+    if ok.any():
+        w = (want + (1 << 127)) % (1 << 128) - (1 << 127)
+        assert got["10"].to_pylist() == [w]
+    else:
+        assert got["10"].to_pylist() == [None]
+    p = Program().filter(3).group_by([Aggregate(10, AGG.SUM, [1]), Aggregate(11, AGG.COUNT, []), Aggregate(12, AGG.MAX, [2])], keys=[2])
+    got, exp = both(res, p, batch)
+    compare_batches(got, exp, key_names=["k"])
+    for k, s in zip(got["k"].to_pylist(), got["10"].to_pylist()):
+        sel = ok & (key == k)
+        want = sum(v for v, o in zip(vals, sel) if o) if sel.any() else None
+        assert s == want, (k, s, want)

@@ -12,3 +12,27 @@ def oracle_run(resolver, program, batch):
 @pytest.mark.parametrize("name", sorted(GOLDEN_CHECKS))
 def test_oracle_matches_reference_vector(name, golden):
     GOLDEN_CHECKS[name](golden[name], oracle_run)
+
+
+def test_oracle_decimal128_sum_matches_python_integers():
+    """decimal128 SUM has no counterpart in the reference (parity unpinned): the oracle's definition -- wrapping
+    two's-complement 128-bit sum, null when no value is valid -- is checked against Python integers."""
+    import numpy as np
+    from ydb_amd.arrow_c import Col
+    from ydb_amd.ssa_pb import AGG, Aggregate, Program
+    rng = np.random.default_rng(5)
+    n = 5000
+    vals = [int(rng.integers(-(1 << 62), 1 << 62)) * int(rng.integers(1, 1 << 40)) for _ in range(n)]
+    words = np.array([[v & ((1 << 64) - 1), (v >> 64) & ((1 << 64) - 1)] for v in vals], dtype=np.uint64)
+    valid = rng.random(n) > 0.1
+    key = rng.integers(0, 7, n).astype(np.int32)
+    batch = {"d": Col(words, valid=valid, decimal=(38, 0)), "k": key}
+    res = [(1, "d"), (2, "k")]
+    out = oracle_run(res, Program().group_by([Aggregate(10, AGG.SUM, [1])]), batch)
+    want = sum(v for v, ok in zip(vals, valid) if ok)
+    assert out["10"].to_pylist() == [(want + (1 << 127)) % (1 << 128) - (1 << 127)]
+    out = oracle_run(res, Program().group_by([Aggregate(10, AGG.SUM, [1])], keys=[2]), batch)
+    for k, s in zip(out["k"].to_pylist(), out["10"].to_pylist()):
+        assert s == sum(v for v, ok, kk in zip(vals, valid, key) if ok and kk == k)
+    allnull = {"d": Col(words, valid=np.zeros(n, dtype=bool), decimal=(38, 0)), "k": key}
+    assert oracle_run(res, Program().group_by([Aggregate(10, AGG.SUM, [1])]), allnull)["10"].to_pylist() == [None]

@@ -648,7 +648,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
             lastUse[si] = int(i);
             ++useCount[si];
         }
-        if (op == OP_STRLEN || op == OP_STRMATCH || op == OP_STRCMP) {
+        if (op == OP_STRLEN || op == OP_STRMATCH || op == OP_STRCMP || op == OP_DECPART) {
             lastUse[si] = kLiveToEnd;
             if (op == OP_STRCMP && (InsnB(ins) & 16)) lastUse[InsnA(ins)] = kLiveToEnd;
         }
@@ -959,7 +959,16 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
         col.Field.Type = oc.Type;
         col.Length = 1;
         uint64_t stored = v;
-        if (ap.SomeInputColumn >= 0) {
+        uint64_t storedHi = 0;
+        if (ap.DecMid >= 0) {
+            // 128-bit sum from the sums of its three parts
+            const unsigned __int128 total = (unsigned __int128)v + ((unsigned __int128)hv[ap.DecMid] << 32) +
+                                            ((unsigned __int128)hv[ap.DecHi] << 64);
+            stored = uint64_t(total);
+            storedHi = uint64_t(total >> 64);
+            col.Field.Precision = ap.Precision;
+            col.Field.Scale = ap.Scale;
+        } else if (ap.SomeInputColumn >= 0) {
             // `v` is the smallest row index with a non-null argument: fetch that value.
             stored = 0;
             if (valid) {
@@ -973,10 +982,11 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
             std::memcpy(&b, &f, 4);
             stored = b;
         }
-        if (!valid) stored = 0;
+        if (!valid) stored = storedHi = 0;
         col.Values = Buffer::Alloc(32);
         if (!col.Values) return Status::Hip("out of device memory");
-        SSA_HIP(hipMemcpy(col.Values->Ptr, &stored, 8, hipMemcpyHostToDevice));
+        const uint64_t words[2] = {stored, storedHi};
+        SSA_HIP(hipMemcpy(col.Values->Ptr, words, 16, hipMemcpyHostToDevice));
         if (!valid) {
             col.Validity = Buffer::Alloc(32);
             if (!col.Validity) return Status::Hip("out of device memory");
@@ -1344,7 +1354,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         Column& col = aggCols[size_t(k)];
         col.Field.Type = ap.OutType;
         col.Length = ngroups;
-        fa.agg_out_type[k] = ap.OutType;
+        fa.agg_out_type[k] = ap.OutType == T_DEC128 ? int32_t(T_U64) : ap.OutType;  // decimal: the low-part sum
         if (ap.SomeInputColumn >= 0) {
             aggRowIdx[size_t(k)] = Buffer::Alloc(size_t(ngroups) * 8 + 16);
             if (!aggRowIdx[size_t(k)]) return Status::Hip("out of device memory");
@@ -1352,7 +1362,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             fa.agg_vals[k] = aggRowIdx[size_t(k)]->Ptr;
             continue;
         }
-        col.Values = Buffer::Alloc(size_t(ngroups) * TypeWidth(ap.OutType) + 16);
+        col.Values = Buffer::Alloc(size_t(ngroups) * 8 + 16);
         if (!col.Values) return Status::Hip("out of device memory");
         fa.agg_vals[k] = col.Values->Ptr;
         if (ap.Spec.kind != AGG_COUNT && ap.Spec.check_valid) {
@@ -1380,6 +1390,17 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     if (ngroups > 0) SSA_HIP(LaunchKeyedEmit(fa, StreamHandle));
     for (int k = 0; k < naggsUser; ++k) {
         const AggPlan& ap = plan.Aggs[size_t(k)];
+        if (ap.DecMid >= 0) {
+            BufferPtr wide = Buffer::Alloc(size_t(ngroups) * 16 + 16);
+            if (!wide) return Status::Hip("out of device memory");
+            SSA_HIP(LaunchCombineDecimal(static_cast<const uint64_t*>(aggCols[size_t(k)].Values->Ptr),
+                                         static_cast<const uint64_t*>(aggCols[size_t(ap.DecMid)].Values->Ptr),
+                                         static_cast<const uint64_t*>(aggCols[size_t(ap.DecHi)].Values->Ptr), ngroups,
+                                         static_cast<uint64_t*>(wide->Ptr), StreamHandle));
+            aggCols[size_t(k)].Values = wide;
+            aggCols[size_t(k)].Field.Precision = ap.Precision;
+            aggCols[size_t(k)].Field.Scale = ap.Scale;
+        }
         if (ap.SomeInputColumn >= 0) {
             SSA_RETURN_NOT_OK(GatherRows(in.Cols[size_t(ap.SomeInputColumn)], aggRowIdx[size_t(k)], ngroups, true, aggCols[size_t(k)]));
         } else if (aggValid[size_t(k)]) {
@@ -1406,6 +1427,10 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         col.Field.Name = oc.Name;
         col.Field.Type = oc.Type;
         col.Field.Nullable = nullable;
+        if (oc.Source == OutColumn::FROM_AGG && oc.Type == T_DEC128) {
+            col.Field.Precision = oc.Precision;
+            col.Field.Scale = oc.Scale;
+        }
         out->Cols.push_back(std::move(col));
     }
     SSA_HIP(hipStreamSynchronize(StreamHandle));

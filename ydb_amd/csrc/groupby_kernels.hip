@@ -735,6 +735,15 @@ __global__ __launch_bounds__(kBlock) void GatherStringBytesKernel(const int32_t*
     }
 }
 
+__global__ __launch_bounds__(kBlock) void CombineDecimalKernel(const uint64_t* lo32, const uint64_t* mid32, const uint64_t* hi,
+                                                             int64_t n, uint64_t* out) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) {
+        const unsigned __int128 total = (unsigned __int128)lo32[i] + ((unsigned __int128)mid32[i] << 32) + ((unsigned __int128)hi[i] << 64);
+        out[2 * i] = uint64_t(total);
+        out[2 * i + 1] = uint64_t(total >> 64);
+    }
+}
+
 struct G128 {
     uint64_t lo, hi;
 };
@@ -782,6 +791,13 @@ hipError_t LaunchKeyedCount(const uint64_t* tKeyLo, uint64_t capacity, unsigned 
 
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(KeyedEmitKernel, dim3(GridFor(int64_t(a.capacity))), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t LaunchCombineDecimal(const uint64_t* lo32, const uint64_t* mid32, const uint64_t* hi, int64_t n, uint64_t* out,
+                                hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(CombineDecimalKernel, dim3(GridFor(n)), dim3(kBlock), 0, st, lo32, mid32, hi, n, out);
     return hipGetLastError();
 }
 

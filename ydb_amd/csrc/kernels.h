@@ -138,6 +138,9 @@ uint64_t KeyedTableIdentity(int aggKind);  // initial value of a level-2 accumul
 hipError_t ConfigureKeyedKernels(int maxLdsBytes);
 hipError_t LaunchKeyedCount(const uint64_t* t_key_lo, uint64_t capacity, unsigned long long* count, hipStream_t st);
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st);
+// out[i] = (lo32[i] + (mid32[i] << 32) + (hi[i] << 64)) mod 2^128 as two little-endian 64-bit words.
+hipError_t LaunchCombineDecimal(const uint64_t* lo32, const uint64_t* mid32, const uint64_t* hi, int64_t n, uint64_t* out,
+                                hipStream_t st);
 // Gather rows of a fixed-width column by 64-bit row index (idx == ~0 -> zero + invalid).
 hipError_t LaunchGatherFixed(const void* src, const uint8_t* src_valid, int64_t src_valid_off, int width,
                              const uint64_t* rows, int64_t n, void* dst, uint8_t* dst_valid_bytes, hipStream_t st);

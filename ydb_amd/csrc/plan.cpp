@@ -483,6 +483,17 @@ struct Compiler {
         }
     }
 
+    static ExprPtr DecimalPart(const ExprPtr& col, int part) {
+        auto e = std::make_shared<Expr>();
+        e->Kind = Expr::STROP;
+        e->Op = OP_DECPART;
+        e->A = part;
+        e->L = col;
+        e->Type = T_U64;
+        e->Nullable = col->Nullable;
+        return e;
+    }
+
     // A non-null input to is_null yields an all-false array; keep it array-shaped (not a scalar).
     ExprPtr MakeConstArrayFalse() {
         auto e = MakeConst(NumScalar(T_BOOL, 0, true));
@@ -729,6 +740,8 @@ struct Compiler {
                 int slot = ColSlot(col, st);
                 if (e->Op == OP_STRLEN) {
                     Emit(MakeInsn(OP_STRLEN, SRC_NONE, slot), st);
+                } else if (e->Op == OP_DECPART) {
+                    Emit(MakeInsn(OP_DECPART, SRC_NONE, slot, e->A), st);
                 } else if (e->Op == OP_STRMATCH) {
                     int k = ConstIndex(e->R->Scalar, st);
                     if (!e->R->Scalar.Valid) Plan.Nullable = true;
@@ -872,6 +885,7 @@ struct Compiler {
             // key8 lookup-table path does not look at argument validity (IAggregateFunction.h:258-296,384-459).
             const bool key8Path = !hasNullableKey && keyExprs.size() == 1 && TypeWidth(keyExprs[0]->Type) == 1;
 
+            std::vector<int> decimalSums;
             for (size_t i = 0; i < Step.GroupBy.size(); ++i) {
                 const TAggregateAssign& g = Step.GroupBy[i];
                 AggPlan ap{};
@@ -902,7 +916,7 @@ struct Compiler {
                         if (IsSignedInt(at)) { ap.Spec.kind = AGG_SUM_I; ap.OutType = T_I64; }
                         else if (IsUnsignedInt(at)) { ap.Spec.kind = AGG_SUM_I; ap.OutType = T_U64; }
                         else if (IsFloat(at)) { ap.Spec.kind = AGG_SUM_F; ap.OutType = T_F64; }
-                        else if (at == T_DEC128) return Status::Unsupported("decimal128 SUM inside a fused step");
+                        else if (at == T_DEC128) { ap.Spec.kind = AGG_SUM_I; ap.OutType = T_DEC128; }
                         else return Status::Invalid(std::string("Function 'sum' has no kernel matching input types (") + TypeName(at) + ")");
                         break;
                     case EAggregate::Min: case EAggregate::Max: {
@@ -938,6 +952,15 @@ struct Compiler {
                     ap.Spec.arg_class = CLS_U;
                     ap.SomeInputColumn = ap.ArgInputColumn;
                     ap.Spec.reg = addRegOut(rowIdx);
+                } else if (arg && ap.OutType == T_DEC128) {
+                    // Extension (the reference has no decimal SUM): wrapping 128-bit sum as three 64-bit sums.
+                    Expr* s = Strip(arg.get());
+                    if (s->Kind != Expr::COL) return Status::Unsupported("decimal128 SUM over a computed expression");
+                    ap.Precision = Input[s->InputIndex].Precision;
+                    ap.Scale = Input[s->InputIndex].Scale;
+                    ap.Spec.arg_class = CLS_U;
+                    ap.Spec.reg = addRegOut(DecimalPart(arg, 0));
+                    decimalSums.push_back(int(i));
                 } else if (arg) {
                     const bool needValue = ap.Spec.kind != AGG_COUNT;
                     if (needValue || ap.ArgNullable) {
@@ -964,8 +987,24 @@ struct Compiler {
                 oc.Type = ap.OutType;
                 oc.Index = int(i);
                 oc.Nullable = ap.Spec.kind != AGG_COUNT;
+                oc.Precision = ap.Precision;
+                oc.Scale = ap.Scale;
                 Plan.Outs.push_back(oc);
             }
+            for (int user : decimalSums) {
+                for (int part = 1; part <= 2; ++part) {
+                    AggPlan hidden = Plan.Aggs[size_t(user)];
+                    hidden.Hidden = true;
+                    hidden.OutType = T_U64;
+                    hidden.DecMid = hidden.DecHi = -1;
+                    ExprPtr arg = Lookup(Step.GroupBy[size_t(user)].Arguments[0].ColumnName);
+                    hidden.Spec.reg = addRegOut(DecimalPart(arg, part));
+                    (part == 1 ? Plan.Aggs[size_t(user)].DecMid : Plan.Aggs[size_t(user)].DecHi) = int(Plan.Aggs.size());
+                    Plan.Aggs.push_back(hidden);
+                }
+            }
+            if (Plan.Aggs.size() > size_t(kMaxAggs)) return Status::Unsupported("too many aggregates in one step");
+            if (!st.ok()) return st;
             for (size_t i = 0; i < keyExprs.size(); ++i) {
                 ExprPtr e = keyExprs[i];
                 KeyPlan kp{};

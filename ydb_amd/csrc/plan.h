@@ -61,6 +61,11 @@ struct AggPlan {
     bool ArgNullable;
     int ArgInputColumn = -1;  // argument is a plain input column (index into the step's input batch), else -1
     int SomeInputColumn = -1; // SOME: the kernel aggregates MIN(row index); the value is gathered from this input column
+    // decimal128 SUM: this entry sums bits 0..31 of the values; two hidden entries appended after the step's own
+    // aggregates sum bits 32..63 and the high words.  The executor recombines the three 64-bit sums modulo 2^128.
+    int DecMid = -1, DecHi = -1;
+    int32_t Precision = 0, Scale = 0;
+    bool Hidden = false;
 };
 
 struct KeyPlan {

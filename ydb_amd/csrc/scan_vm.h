@@ -639,6 +639,22 @@ struct Machine {
 #pragma unroll
             for (int u = 0; u < U; ++u) A.v[u] = uint64_t(Row(u));
             break;
+        case OP_DECPART: {
+            // 128-bit sums are carried as three 64-bit sums of these parts (the 32-bit halves of the low word cannot
+            // overflow a 64-bit accumulator below 2^32 rows)
+            A.ok = ValidityOf(si);
+            const uint64_t* words = reinterpret_cast<const uint64_t*>(ReadLane64(tColVal, si));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint64_t v = 0;
+                if (((act & A.ok) >> u) & 1u) {
+                    const uint64_t w = words[2 * Row(u) + (fa == 2 ? 1 : 0)];
+                    v = fa == 0 ? (w & 0xFFFFFFFFull) : fa == 1 ? (w >> 32) : w;
+                }
+                A.v[u] = v;
+            }
+            break;
+        }
         case OP_STRLEN: {
             A.ok = ValidityOf(si);
             const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, si));

@@ -125,6 +125,7 @@ enum OpCode : int32_t {
     OP_PRED,      // P &= (A != 0)   -- value bit only, validity ignored (reference: program.cpp:517-527)
     OP_ROWIDX,    // A.value = global row index; A's validity is kept
     OP_PREDCMP,   // P &= (column si  cmp  constant a); b = CmpOp | (class << 4).  Fusion of LD col; CMP const; PRED
+    OP_DECPART,   // A = part a of decimal128 column si: 0 = bits 0..31, 1 = bits 32..63, 2 = bits 64..127 (validity of the column)
 };
 
 SSA_HD uint32_t MakeInsn(int op, int sk = 0, int si = 0, int a = 0, int b = 0) {
