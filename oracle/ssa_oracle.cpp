@@ -200,6 +200,8 @@ struct Program {
     std::vector<std::pair<uint32_t, std::string>> sources;  // in first-use order
     std::map<std::string, DatumPtr> constants;      // TProgramBuilder::Constants
     std::map<std::string, DatumPtr> parameters;     // row 0 of the parameters batch, by name
+    uint32_t defaultId = 0;                         // IColumnResolver::GetDefaultColumn(): the resolver's first column
+    std::string defaultName;
 
     // TProgramBuilder::GetColumnInfo (ydb/core/tx/program/program.cpp:36-68): a non-zero Id wins and resolves to
     // the table column of that id, else the generated name is the explicit Name or the decimal Id.
@@ -423,6 +425,8 @@ static void ParseProgramBody(Program& prog, Wire w) {
         }
     }
     if (!step.Empty()) prog.steps.push_back(step);
+    // Query 'SELECT count(*) FROM table' needs a column (ydb/core/tx/program/program.cpp:601-605)
+    if (prog.sources.empty() && !prog.defaultName.empty()) prog.AddSource(prog.defaultId, prog.defaultName);
     // OptimizeProgram (ydb/core/formats/arrow/ssa_program_optimizer.cpp:7-30): COUNT(*) counts the first GROUP BY
     // key of its step, else any source column of the program (the first one in use order here; the scan's
     // default column when the program reads none).
@@ -1417,6 +1421,7 @@ void* orc_program_create(const uint8_t* pb, size_t n, int olap_wrapper, const ui
     try {
         auto prog = std::make_unique<Program>();
         for (size_t i = 0; i < ncols; ++i) { prog->resolver[ids[i]] = names[i]; prog->byName[names[i]] = ids[i]; }
+        if (ncols) { prog->defaultId = ids[0]; prog->defaultName = names[0]; }
         for (size_t i = 0; i < nparams; ++i) {
             DatumPtr d = ImportCol(params[i]);
             if (d->n < 1) throw Error("empty parameter");
