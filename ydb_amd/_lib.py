@@ -56,6 +56,13 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The executor has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and cannot initialise after the system one
+    # has been loaded by this library, so when torch is installed (the tests and the benchmark use it for device memory)
+    # it is imported first and both share the runtime it brought.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     P = ctypes.POINTER
     vp, cp, i64, i32, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t

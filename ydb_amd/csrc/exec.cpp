@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 
@@ -610,6 +611,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
         d.validity = col.Validity ? static_cast<const uint8_t*>(col.Validity->Ptr) : nullptr;
         d.chars = col.Chars ? static_cast<const uint8_t*>(col.Chars->Ptr) : nullptr;
         d.type = col.Field.Type;
+        d.chars_bytes = col.Chars ? int32_t(std::min<size_t>(col.Chars->Size, size_t(INT32_MAX))) : 0;
         d.val_bit_off = col.ValBitOff;
         d.valid_bit_off = col.ValidBitOff;
         args.lds_col_off[c] = -1;
@@ -1172,7 +1174,10 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     aggSrc.resize(size_t(naggsUser));
     for (int k = 0; k < naggsUser; ++k) {
         AggSpec spec = plan.Aggs[size_t(k)].Spec;
-        if (spec.kind == AGG_COUNT && !spec.check_valid) spec.reg = -1;  // counts rows
+        if (spec.kind == AGG_COUNT && !spec.check_valid) {  // counts rows, whatever its argument
+            spec.reg = -1;
+            spec.arg_class = CLS_U;
+        }
         int found = -1;
         for (size_t j = 0; j < phys.size(); ++j) {
             if (phys[j].kind == spec.kind && phys[j].reg == spec.reg && phys[j].check_valid == spec.check_valid &&
@@ -1219,9 +1224,13 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         allSimple = allSimple && !a.check_valid && ((a.kind == AGG_COUNT && a.reg == -1) || a.kind == AGG_SUM_F || a.kind == AGG_SUM_I);
     }
     int L = hint.LdsCap, R = 1;
-    if (L == 16 && !(allSimple && naggs <= kHotAggs)) {
-        R = 8;
-        while (R > 1 && L * R * naggs * 8 > 16 * 1024) R >>= 1;
+    if (L == 16) {
+        if (allSimple && naggs <= kHotAggs) {
+            L = 64;  // unreplicated accumulators are small: spend LDS on fewer first-probe collisions instead
+        } else {
+            R = 8;
+            while (R > 1 && L * R * naggs * 8 > 16 * 1024) R >>= 1;
+        }
     }
     if (const char* env = std::getenv("SSA_KEYED_LDS")) {
         int l = 0, r = 1;
@@ -1272,6 +1281,11 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         sink.hot_off[k] = off;
     }
 
+    if (std::getenv("SSA_DEBUG_PLAN")) {
+        std::fprintf(stderr, "keyed: naggs %d L %d R %d lds %u grid %d hashed %d two %d hot", naggs, L, R, cfg.lds_bytes, cfg.grid, int(hashed), int(twoWords));
+        for (int k = 0; k < kHotAggs; ++k) std::fprintf(stderr, " %d@%d", sink.hot_kind[k], sink.hot_off[k]);
+        std::fprintf(stderr, "\n");
+    }
     BufferPtr tLo, tHi, tAcc, tSeen, tRep;
     for (;;) {
         tLo = Buffer::Alloc(cap * 8);
@@ -1300,6 +1314,14 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             ProfileBegin();
             SSA_HIP(LaunchScanKeyed(args, sink, cfg));
             ProfileEnd("ScanKeyedKernel", algoBytes);
+        }
+        if (std::getenv("SSA_PHASE_TIMING")) {  // diagnostics build only (-DSSA_PHASE_TIMING): cycles per phase, summed over waves
+            unsigned long long t[8];
+            SSA_HIP(hipStreamSynchronize(StreamHandle));
+            SSA_HIP(hipMemcpy(t, static_cast<char*>(StatusWord->Ptr) + 64, 64, hipMemcpyDeviceToHost));
+            SSA_HIP(hipMemset(static_cast<char*>(StatusWord->Ptr) + 64, 0, 64));
+            std::fprintf(stderr, "phases: stage %llu vm %llu keys %llu upsert %llu hot %llu table %llu loop %llu\n", t[0], t[1], t[2], t[3],
+                         t[4], t[5], t[7]);
         }
         bool tableFull = false;
         SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull));

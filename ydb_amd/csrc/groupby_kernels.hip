@@ -279,6 +279,12 @@ __device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint
 
 // kHashed: the batch has string keys or more than 119 key bits (per-row packing with a hash for rows that do not fit);
 // otherwise all keys pack exactly at wave-uniform positions.
+#ifdef SSA_PHASE_TIMING
+#define SSA_T(i) do { const uint64_t now_ = __builtin_readcyclecounter(); tphase[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define SSA_T(i) do {} while (0)
+#endif
+
 template <int U, bool kHashed>
 __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>) {
     const ScanArgs& a = KernArgs<KeyedSink>().a;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         const uint64_t ident = TableIdentity(s.aggs[k].kind);
         for (int i = threadIdx.x; i < L * R; i += kBlock) lAcc[size_t(k) * L * R + i] = ident;
     }
-    // (the barriers of the first BeginTile order this initialisation before any use)
+    __syncthreads();  // the table is shared by the workgroup's waves
     const int rep = threadIdx.x & (R - 1);
     const uint32_t ldsProbes = L < 8 ? uint32_t(L) : 8u;
 
@@ -337,10 +343,17 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
     const uint32_t tHotOff = uint32_t(s.hot_off[hi_]);
     const int nkeys = s.nkeys;
 
+#ifdef SSA_PHASE_TIMING
+    uint64_t tphase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast = __builtin_readcyclecounter();
+#endif
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        SSA_T(7);
         m.BeginTile(tile * (kBlock * U));
+        SSA_T(0);
         m.Run();
+        SSA_T(1);
         if (m.P == 0) continue;
 
         // Keys of the lane's rows.  Batches whose keys all have a fixed width of at most 119 bits pack them at
@@ -361,21 +374,28 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             ks.fetch_kind = ReadLane32(tKeyFk, k);
             ks.fetch_payload = ReadLane32(tKeyPayload, k);
             if (kHashed && ks.col >= 0) {
-                // string key; the validity of the column is not part of these keys
+                // string key; the validity of the column is not part of these keys.  The loads of the lane's rows are
+                // issued together, then consumed.
+                const uint8_t* p[U];
+                int32_t n[U];
+                uint64_t w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    p[u] = nullptr;
+                    n[u] = 0;
+                    if ((m.P >> u) & 1u) m.StringAt(ks.col, u, p[u], n[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) w[u] = m.StringHead(ks.col, p[u], n[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (!((m.P >> u) & 1u)) continue;
-                    const uint8_t* p;
-                    int32_t n;
-                    m.StringAt(ks.col, u, p, n);
-                    if (n > 8) {
+                    if (n[u] > 8) {
                         toHash |= 1u << u;
                         continue;
                     }
-                    uint64_t w = 0;
-                    for (int32_t j = 0; j < n; ++j) w |= uint64_t(p[j]) << (8 * j);
-                    kb.AppendAt(u, uint64_t(uint32_t(n)), 8, at[u]);
-                    kb.AppendAt(u, w, uint32_t(8 * n), at[u]);
+                    kb.AppendAt(u, uint64_t(uint32_t(n[u])), 8, at[u]);
+                    kb.AppendAt(u, w[u], uint32_t(8 * n[u]), at[u]);
                 }
                 continue;
             }
@@ -438,17 +458,41 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             }
         }
 
+        SSA_T(2);
         // group of each row: >= 0 dense id in level 1, <= -2 level-2 slot g as -2 - g, -1 no row
         int64_t slot[U];
+        uint32_t hpos[U];
+        uint64_t seenLo[U], seenHi[U];
+        uint32_t seenId[U];
+        // first probe of every row, issued together: in the steady state the group is there
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             slot[u] = -1;
+            hpos[u] = 0;
+            seenLo[u] = kEmpty;
+            seenHi[u] = 0;
+            seenId[u] = kNoDense;
             if (!((m.P >> u) & 1u)) continue;
             kb.Finish(u, ((toHash >> u) & 1u) != 0);
-            const uint32_t h = Fold32(kb.lo[u], kb.hi[u]);
+            hpos[u] = Fold32(kb.lo[u], kb.hi[u]);
+            if (L > 0) {
+                const uint32_t pos = hpos[u] & uint32_t(L - 1);
+                seenLo[u] = __hip_atomic_load(lLo + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (twoWords) seenHi[u] = __hip_atomic_load(lHi + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                seenId[u] = __hip_atomic_load(lDense + pos, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!((m.P >> u) & 1u)) continue;
+            const uint32_t h = hpos[u];
             int64_t sl = -1;
-            if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
-                                           uint64_t(m.Row(u)), ldsProbes);
+            if (seenLo[u] == kb.lo[u] && (!twoWords || seenHi[u] == kb.hi[u]) && seenId[u] != kNoDense) {
+                sl = int64_t(seenId[u]);
+            } else if (L > 0) {
+                sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
+                                    uint64_t(m.Row(u)), ldsProbes);
+            }
             if (sl < 0) {
                 const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, kb.lo[u], kb.hi[u], twoWords, 4096u);
                 if (g < 0) {
@@ -462,6 +506,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             slot[u] = sl;
         }
 
+        SSA_T(3);
         // membership of the lane's rows in the register-held groups: bit u of hit[g]; as 0.0 / 1.0 factors for the
         // floating-point sums (one FMA per row and group)
         uint32_t hit[kHotGroups];
@@ -492,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
                     bool finite = true;
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        x[u] = src[u * kBlock + threadIdx.x];
+                        x[u] = src[m.Idx(u)];
                         finite = finite && (x[u] - x[u] == 0.0);
                     }
                     // x * 0.0 must be 0: an infinity / NaN anywhere in the wave's rows sends this aggregate through
@@ -511,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
                     const uint64_t* src = reinterpret_cast<const uint64_t*>(gLds + ReadLane32(tHotOff, k));
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const uint64_t x = src[u * kBlock + threadIdx.x];
+                        const uint64_t x = src[m.Idx(u)];
 #pragma unroll
                         for (int g = 0; g < kHotGroups; ++g) hot[g][k] += ((hit[g] >> u) & 1u) ? x : 0ull;
                     }
@@ -524,8 +569,10 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             }
         }
 
+        SSA_T(4);
         // Table path: everything else, and the rows of groups that are not register-held.
-        for (int k = 0; k < naggs && !(a.debug_flags & (2 | 16)); ++k) {
+        const bool tablesIdle = hotDone == ((1u << naggs) - 1u) && !__any((m.P & ~hotRows) != 0);
+        for (int k = 0; k < naggs && !tablesIdle && !(a.debug_flags & (2 | 16)); ++k) {
             uint32_t live = m.P & (((hotDone >> k) & 1u) ? ~hotRows : ~0u);
             if (!__any(live != 0)) continue;
             AggSpec spec;
@@ -578,8 +625,15 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
                 }
             }
         }
+        SSA_T(5);
     }
 
+#ifdef SSA_PHASE_TIMING
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.status) + 8;
+        for (int i = 0; i < 8; ++i) atomicAdd(dbg + i, static_cast<unsigned long long>(tphase[i]));
+    }
+#endif
     // fold the register accumulators into level 1 (dense ids 0 .. kHotGroups-1): wave butterfly, then one lane adds
     if (useHot) {
 #pragma unroll

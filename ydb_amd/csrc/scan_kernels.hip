@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void ScanFilterKernel(const KArgs<FilterSin
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t word = __ballot((m.P >> u) & 1u);
-            const int64_t firstRow = tileBase + int64_t(u) * kBlock + WaveId() * 64;
+            const int64_t firstRow = tileBase + int64_t(WaveId()) * (64 * U) + u * 64;
             if (LaneId() == 0 && firstRow < a.nrows) s.bitmap[firstRow >> 6] = word;
             count += __popcll(word);
         }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void ScanProjectKernel(const KArgs<ProjectS
             if (s.tile_offsets[tile + 1] == tileOff) continue;  // nothing selected in this tile
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int wordInTile = u * kWaves + WaveId();
+                const int wordInTile = WaveId() * U + u;
                 const int64_t wordIdx = (tileBase >> 6) + wordInTile;
                 const uint64_t word = wordIdx < nwords ? s.bitmap[wordIdx] : 0;
                 const uint32_t before = SelectedBeforeWord(s.bitmap, tileBase >> 6, wordInTile, nwords);

@@ -1,7 +1,8 @@
 // Device-side scan VM: evaluates the per-step expression program (vm.h) for a tile of rows.
 //
 // Work decomposition: a workgroup of kBlock = 256 lanes (4 wavefronts of 64) owns a tile of
-// kBlock * U consecutive rows; lane t evaluates rows tile + u * kBlock + t (u = 0..U-1), so every
+// kBlock * U consecutive rows; wave w owns the 64 * U consecutive rows tile + w * 64 * U ..., lane t of it evaluates
+// rows tile + w * 64 * U + u * 64 + t (u = 0..U-1): a wave stages, reads and writes only its own rows, so every
 // column access of a wavefront is 64 consecutive elements -- fully coalesced at any element width.
 // At the start of a tile every fixed-width source column is staged into LDS by direct global->LDS
 // loads (no VGPRs, all columns in flight together, 16 bytes per lane); the interpreter then runs the
@@ -173,7 +174,7 @@ struct Machine {
     static constexpr int kTile = kBlock * U;
     const ScanArgs& a;   // kernel-argument segment (read once at kernel start)
     int64_t row0;        // row of u = 0 for this lane
-    uint32_t act;        // bit u: row0 + u * kBlock < nrows
+    uint32_t act;        // bit u: Row(u) < nrows
     uint32_t P;          // bit u: row passes every Filter so far
     uint32_t err;        // ScanStatus bits raised by this lane
     Val<U> A;
@@ -183,14 +184,14 @@ struct Machine {
     // wave-uniform index -- no memory access, no latency -- instead of dependent scalar loads.
     uint32_t tCode0, tCode1, tCode2;         // pre-decoded instruction [lane]: dispatch word, operand payload, generic form
     uint32_t tColOff, tColType, tColW;       // column slot (lane & 15): LDS offset (or -1), TypeId, width
-    uint32_t tColValBit, tColValidBit;
+    uint32_t tColValBit, tColValidBit, tColCharsBytes;
     uint64_t tColVal, tColValid, tColChars;
     uint32_t tRegOff;                        // R register (lane): LDS offset of its value tile
     uint64_t tConstBits;                     // constant (lane)
     uint32_t tConstValid;
-    uint64_t tPieceSrc;                      // staging piece (lane): column base + piece offset
-    uint32_t tPieceLds, tPieceW, tPieceOff;  // LDS offset, element width, byte offset of the piece inside the tile
-    int nPieces;
+    uint32_t tColStageW;                     // column slot: bytes per row of the staged buffer
+    int waveBase;                            // first tile row of this wave: wave * 64 * U
+    int ncols;
     int64_t nrows;
     int ncode;
 
@@ -207,6 +208,7 @@ struct Machine {
         tColW = uint32_t(TypeWidth(a.cols[c].type));
         tColValBit = uint32_t(a.cols[c].val_bit_off);
         tColValidBit = uint32_t(a.cols[c].valid_bit_off);
+        tColCharsBytes = uint32_t(a.cols[c].chars_bytes);
         tColVal = reinterpret_cast<uint64_t>(a.cols[c].values);
         tColValid = reinterpret_cast<uint64_t>(a.cols[c].validity);
         tColChars = reinterpret_cast<uint64_t>(a.cols[c].chars);
@@ -214,58 +216,46 @@ struct Machine {
         const int k = lane < kMaxConsts ? lane : 0;
         tConstBits = a.consts[k].bits;
         tConstValid = uint32_t(a.consts[k].valid);
-        // staging pieces: one wave-instruction (64 lanes x 16 bytes = 1 KiB) each
-        tPieceSrc = 0;
-        tPieceLds = 0;
-        tPieceW = 0;
-        tPieceOff = 0;
-        int acc = 0;
-        for (int col = 0; col < a.ncols; ++col) {
-            const int off = a.lds_col_off[col];
-            if (off < 0) continue;
-            const int w = StageWidth(a.cols[col].type);
-            const int np = (kTile * w) >> 10;
-            if (lane >= acc && lane < acc + np) {
-                tPieceSrc = reinterpret_cast<uint64_t>(a.cols[col].values) + uint64_t(lane - acc) * 1024u;
-                tPieceLds = uint32_t(off + (lane - acc) * 1024);
-                tPieceW = uint32_t(w);
-                tPieceOff = uint32_t((lane - acc) * 1024);
-            }
-            acc += np;
-        }
-        nPieces = acc;
+        tColStageW = uint32_t(StageWidth(a.cols[c].type));
+        waveBase = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)) * (64 * U);
+        ncols = a.ncols;
     }
 
-    __device__ __forceinline__ int64_t Row(int u) const { return row0 + int64_t(u) * kBlock; }
+    __device__ __forceinline__ int64_t Row(int u) const { return row0 + int64_t(u) * 64; }
+    // index of the lane's u-th row inside the tile (staged columns, R registers)
+    __device__ __forceinline__ int Idx(int u) const { return waveBase + u * 64 + int(threadIdx.x & 63); }
 
-    // Stage the tile's fixed-width source columns into LDS with direct global->LDS loads
-    // (global_load_lds_dwordx4: one wave-instruction moves 1 KiB, no VGPRs are involved), then
-    // make them visible to the workgroup.  In the last, partial tile the lanes whose 16-byte chunk
-    // starts past the end of the column issue nothing (those rows are inactive); a chunk that straddles
-    // the end reads at most 15 bytes of the allocation's tail padding.
+    // Stage the wave's rows of every staged source column into LDS with direct global->LDS loads
+    // (global_load_lds_dwordx4: 16 bytes per lane, no VGPRs involved).  Waves do not wait for each other: each one
+    // loads, and later reads, only its own 64 * U rows, so a vmcnt(0) of its own is all the ordering needed.  In the
+    // last, partial tile the lanes whose 16-byte chunk starts past the end of the column issue nothing (those rows are
+    // inactive); a chunk that straddles the end reads at most 15 bytes of the allocation's tail padding.
     __device__ __forceinline__ void BeginTile(int64_t tileBase) {
-        row0 = tileBase + threadIdx.x;
+        const int lane = threadIdx.x & 63;
+        row0 = tileBase + waveBase + lane;
         act = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) act |= (Row(u) < nrows ? 1u : 0u) << u;
         const bool full = (tileBase + kTile <= nrows);
-        __syncthreads();  // every wave is done reading the previous tile
+        const int64_t slice0 = tileBase + waveBase;  // first row of the wave's slice
+        // the wave's own LDS traffic of the previous tile (register stores included) has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(a.debug_flags & 1)) {
-            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            const int lane = threadIdx.x & 63;
-            for (int p = wave; p < nPieces; p += kBlock / 64) {
-                const uint64_t src = ReadLane64(tPieceSrc, p);
-                const uint32_t ldsOff = ReadLane32(tPieceLds, p);
-                const uint32_t w = ReadLane32(tPieceW, p);
-                const unsigned char* g = reinterpret_cast<const unsigned char*>(src) + tileBase * w + lane * 16;
-                // byte position of this lane's chunk inside the column
-                const int64_t pos = tileBase * w + int64_t(ReadLane32(tPieceOff, p)) + lane * 16;
-                if (full || pos < nrows * int64_t(w)) {
-                    __builtin_amdgcn_global_load_lds((GlobalPtr)g, (LdsPtr)(gLds + ldsOff), 16, 0, 0);
+            for (int c = 0; c < ncols; ++c) {
+                const int off = int(ReadLane32(tColOff, c));
+                if (off < 0) continue;
+                const int w = int(ReadLane32(tColStageW, c));
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(ReadLane64(tColVal, c)) + slice0 * w;
+                const int sliceBytes = 64 * U * w;
+                for (int chunk = 0; chunk < sliceBytes; chunk += 1024) {
+                    const int b = chunk + lane * 16;
+                    if (b < sliceBytes && (full || (slice0 * w + b) < nrows * int64_t(w))) {
+                        __builtin_amdgcn_global_load_lds((GlobalPtr)(src + b), (LdsPtr)(gLds + off + waveBase * w + chunk), 16, 0, 0);
+                    }
                 }
             }
         }
-        __syncthreads();  // waits for the LDS-DMA (vmcnt(0)) before the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     __device__ __forceinline__ uint32_t ValidityOf(int c) const {
@@ -287,7 +277,7 @@ struct Machine {
             const int off = int(ReadLane32(tColOff, c));
             if (off >= 0) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) out.v[u] = LdsLoadRaw(gLds + off, w, u * kBlock + int(threadIdx.x));
+                for (int u = 0; u < U; ++u) out.v[u] = LdsLoadRaw(gLds + off, w, Idx(u));
             } else {
                 const void* values = reinterpret_cast<const void*>(ReadLane64(tColVal, c));
 #pragma unroll
@@ -307,19 +297,19 @@ struct Machine {
         out.ok = ValidityOf(c);
     }
 
-    // R registers live in LDS: lane t owns elements [u * kBlock + t] of every register, so no
+    // R registers live in LDS: a lane owns elements Idx(u) of every register, so no
     // barrier is needed between a store and a later fetch.
     __device__ __forceinline__ void FetchReg(int r, Val<U>& out) {
         const uint64_t* vals = reinterpret_cast<const uint64_t*>(gLds + ReadLane32(tRegOff, r));
 #pragma unroll
-        for (int u = 0; u < U; ++u) out.v[u] = vals[u * kBlock + threadIdx.x];
+        for (int u = 0; u < U; ++u) out.v[u] = vals[Idx(u)];
         out.ok = (gLds + a.lds_regok_off)[r * kBlock + threadIdx.x];
     }
 
     __device__ __forceinline__ void StoreReg(int r, const Val<U>& in) {
         uint64_t* vals = reinterpret_cast<uint64_t*>(gLds + ReadLane32(tRegOff, r));
 #pragma unroll
-        for (int u = 0; u < U; ++u) vals[u * kBlock + threadIdx.x] = in.v[u];
+        for (int u = 0; u < U; ++u) vals[Idx(u)] = in.v[u];
         (gLds + a.lds_regok_off)[r * kBlock + threadIdx.x] = uint8_t(in.ok);
     }
 
@@ -341,8 +331,8 @@ struct Machine {
     }
 
     // Bytes of the string in row u of the lane.  Offsets come from the staged tile when the column's offsets are in
-    // LDS.  Only the offsets of the tile's own rows are staged (and in the last tile only those below `nrows`), so
-    // the end offset of the tile's last row and of the batch's last row is read from memory.
+    // LDS.  A wave stages the offsets of its own rows only (and in the last tile only those below `nrows`), so the
+    // end offset of the last row of its slice and of the batch's last row is read from memory.
     __device__ __forceinline__ void StringAt(int c, int u, const uint8_t*& p, int32_t& n) const {
         const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, c));
         const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
@@ -351,9 +341,10 @@ struct Machine {
         int32_t b, e;
         if (off >= 0) {
             const int32_t* l = reinterpret_cast<const int32_t*>(gLds + off);
-            const int idx = u * kBlock + int(threadIdx.x);
+            const int idx = Idx(u);
             b = l[idx];
-            e = (idx + 1 < kTile && row + 1 < nrows) ? l[idx + 1] : offs[row + 1];
+            // only the wave's own slice is known to have arrived
+            e = (idx + 1 < waveBase + 64 * U && row + 1 < nrows) ? l[idx + 1] : offs[row + 1];
         } else {
             b = offs[row];
             e = offs[row + 1];
@@ -362,45 +353,59 @@ struct Machine {
         n = e - b;
     }
 
+    // Up to the first 8 bytes of a string (little-endian in the result, bytes past the string's end are zero).  One
+    // unaligned 8-byte load when that stays inside the column's chars buffer, byte loads next to its end.
+    __device__ __forceinline__ uint64_t StringHead(int c, const uint8_t* p, int32_t n) const {
+        if (n <= 0) return 0;
+        const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
+        const int64_t off = p - chars;
+        uint64_t w = 0;
+        if (off + 8 <= int64_t(ReadLane32(tColCharsBytes, c))) {
+            __builtin_memcpy(&w, p, 8);
+        } else {
+            for (int32_t j = 0; j < n && j < 8; ++j) w |= uint64_t(p[j]) << (8 * j);
+        }
+        return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1ull));
+    }
+
     // Operand fetch by pre-decoded kind: the host resolved column type, width and LDS offset, so a
     // staged column costs U LDS reads and no further dispatch.
     __device__ __forceinline__ void FetchFast(uint32_t fk, uint32_t w1, Val<U>& B) {
         const unsigned char* base = gLds + (w1 & 0xFFFFFFu);
-        const int idx = threadIdx.x;
         switch (fk & 0x7Fu) {
             case FK_NONE:
                 return;
             case FK_LDS_64:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint64_t*>(base)[u * kBlock + idx];
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint64_t*>(base)[Idx(u)];
                 break;
             case FK_LDS_I32:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int32_t*>(base)[u * kBlock + idx]));
+                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int32_t*>(base)[Idx(u)]));
                 break;
             case FK_LDS_U32:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint32_t*>(base)[u * kBlock + idx];
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint32_t*>(base)[Idx(u)];
                 break;
             case FK_LDS_I16:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int16_t*>(base)[u * kBlock + idx]));
+                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int16_t*>(base)[Idx(u)]));
                 break;
             case FK_LDS_U16:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint16_t*>(base)[u * kBlock + idx];
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint16_t*>(base)[Idx(u)];
                 break;
             case FK_LDS_I8:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int8_t*>(base)[u * kBlock + idx]));
+                for (int u = 0; u < U; ++u) B.v[u] = uint64_t(int64_t(reinterpret_cast<const int8_t*>(base)[Idx(u)]));
                 break;
             case FK_LDS_U8:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint8_t*>(base)[u * kBlock + idx];
+                for (int u = 0; u < U; ++u) B.v[u] = reinterpret_cast<const uint8_t*>(base)[Idx(u)];
                 break;
             case FK_LDS_F32:
 #pragma unroll
-                for (int u = 0; u < U; ++u) B.v[u] = F64ToBits(double(reinterpret_cast<const float*>(base)[u * kBlock + idx]));
+                for (int u = 0; u < U; ++u) B.v[u] = F64ToBits(double(reinterpret_cast<const float*>(base)[Idx(u)]));
                 break;
             case FK_REG:
                 FetchReg(int(w1 & 0xFFFFFFu), B);

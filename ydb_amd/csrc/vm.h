@@ -162,7 +162,7 @@ struct DevColumn {
     int32_t type;
     int32_t val_bit_off;      // BOOL columns: bit offset of row 0 inside `values`
     int32_t valid_bit_off;    // bit offset of row 0 inside `validity`
-    int32_t pad;
+    int32_t chars_bytes;      // strings: readable bytes at `chars` (an 8-byte read at offset o is safe while o + 8 <= chars_bytes)
 };
 
 struct DevConst {
