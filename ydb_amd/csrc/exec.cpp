@@ -1240,7 +1240,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         }
     }
     if (L == 0) R = 1;
-    const int sinkLds = L * 24 + naggs * L * R * 8 + L * 8 + 16;
+    const int sinkLds = L * 24 + 64 + naggs * L * R * 8 + L * 8 + 16;
 
     ScanArgs args;
     LaunchCfg cfg;

@@ -239,7 +239,7 @@ constexpr int kHotGroups = 4;               // groups whose SUM / COUNT accumula
 // (order of first appearance in this workgroup), records a representative row and publishes the id.  Accumulators are
 // indexed by dense id, so the first kHotGroups groups of a workgroup are the ones kept in registers.
 __device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint64_t* lRep, uint32_t* lDense, uint32_t* lCount,
-                                              uint32_t mask, uint64_t start, uint64_t lo, uint64_t hi, bool twoWords,
+                                              uint64_t* lHotKey, uint32_t mask, uint64_t start, uint64_t lo, uint64_t hi, bool twoWords,
                                               uint64_t row, uint32_t maxProbes) {
     uint32_t s = uint32_t(start) & mask;
     uint32_t probes = 0;
@@ -252,6 +252,10 @@ __device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint
                 const uint32_t id = atomicAdd(lCount, 1u);
                 lRep[s] = row;
                 if (twoWords) __hip_atomic_store(lHi + s, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (id < uint32_t(kHotGroups)) {  // key of a register-held group: waves pick it up at their next tile
+                    lHotKey[2 * id + 1] = hi;
+                    __hip_atomic_store(lHotKey + 2 * id, lo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 __hip_atomic_store(lDense + s, id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return int(id);
             }
@@ -295,11 +299,13 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
     const bool twoWords = kHashed || s.two_words != 0;
     constexpr bool hashed = kHashed;
     // level-1 table in the sink area of LDS:
-    //   by hash position: lo[L], hi[L], rep[L], dense[L];  by dense id: acc[naggs][L][R], seen[L];  count
+    //   by hash position: lo[L], hi[L], rep[L], dense[L];  by dense id: acc[naggs][L][R], seen[L];  count;
+    //   keys of the register-held groups: hot[kHotGroups][2]
     uint64_t* lLo = reinterpret_cast<uint64_t*>(gLds + a.lds_sink_off);
     uint64_t* lHi = lLo + L;
     uint64_t* lRep = lHi + L;
-    uint64_t* lAcc = lRep + L;
+    uint64_t* lHotKey = lRep + L;
+    uint64_t* lAcc = lHotKey + 2 * kHotGroups;
     uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(naggs) * L * R);
     uint32_t* lDense = lSeen + L;
     uint32_t* lCount = lDense + L;
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         lDense[i] = kNoDense;
     }
     if (threadIdx.x == 0) *lCount = 0;
+    if (threadIdx.x < 2 * kHotGroups) lHotKey[threadIdx.x] = kEmpty;
     for (int k = 0; k < naggs; ++k) {
         const uint64_t ident = TableIdentity(s.aggs[k].kind);
         for (int i = threadIdx.x; i < L * R; i += kBlock) lAcc[size_t(k) * L * R + i] = ident;
@@ -328,6 +335,11 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         for (int k = 0; k < kHotAggs; ++k) hot[g][k] = 0;
     }
     const bool useHot = L >= kHotGroups && !(a.debug_flags & 8);
+    // keys of the register-held groups as this wave knows them (a free marker never equals a key)
+    uint64_t hotLo[kHotGroups], hotHi[kHotGroups];
+#pragma unroll
+    for (int g = 0; g < kHotGroups; ++g) hotLo[g] = kEmpty, hotHi[g] = 0;
+    int hotKnown = 0;
 
     // Sink description in VGPR lanes (lane i: key i / accumulator i), decoded with v_readlane inside the tile loop:
     // re-reading the kernel-argument segment there costs a scalar-memory round trip per field and tile.
@@ -464,16 +476,42 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         uint32_t hpos[U];
         uint64_t seenLo[U], seenHi[U];
         uint32_t seenId[U];
-        // first probe of every row, issued together: in the steady state the group is there
+        // Groups held in registers are recognised by comparing with their keys: no hashing, no LDS round trip.
+        if (useHot && hotKnown < kHotGroups) {
+#pragma unroll
+            for (int g = 0; g < kHotGroups; ++g) {
+                if (g == hotKnown) {
+                    const uint64_t lo = __hip_atomic_load(lHotKey + 2 * g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (__builtin_amdgcn_readfirstlane(uint32_t(lo >> 32)) != 0xFFFFFFFFu) {
+                        hotLo[g] = lo;
+                        hotHi[g] = lHotKey[2 * g + 1];
+                        hotKnown = g + 1;
+                    }
+                }
+            }
+        }
+        uint32_t pending = 0;  // rows whose group still has to be looked up in the tables
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             slot[u] = -1;
+            if (!((m.P >> u) & 1u)) continue;
+            kb.Finish(u, ((toHash >> u) & 1u) != 0);
+            int id = -1;
+#pragma unroll
+            for (int g = 0; g < kHotGroups; ++g) {
+                if (kb.lo[u] == hotLo[g] && (!twoWords || kb.hi[u] == hotHi[g])) id = g;
+            }
+            if (id >= 0 && useHot) slot[u] = id; else pending |= 1u << u;
+        }
+        if (__any(pending != 0)) {
+        // first probe of every row, issued together: in the steady state the group is there
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             hpos[u] = 0;
             seenLo[u] = kEmpty;
             seenHi[u] = 0;
             seenId[u] = kNoDense;
-            if (!((m.P >> u) & 1u)) continue;
-            kb.Finish(u, ((toHash >> u) & 1u) != 0);
+            if (!((pending >> u) & 1u)) continue;
             hpos[u] = Fold32(kb.lo[u], kb.hi[u]);
             if (L > 0) {
                 const uint32_t pos = hpos[u] & uint32_t(L - 1);
@@ -484,13 +522,13 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!((m.P >> u) & 1u)) continue;
+            if (!((pending >> u) & 1u)) continue;
             const uint32_t h = hpos[u];
             int64_t sl = -1;
             if (seenLo[u] == kb.lo[u] && (!twoWords || seenHi[u] == kb.hi[u]) && seenId[u] != kNoDense) {
                 sl = int64_t(seenId[u]);
             } else if (L > 0) {
-                sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
+                sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
                                     uint64_t(m.Row(u)), ldsProbes);
             }
             if (sl < 0) {
@@ -505,6 +543,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             }
             slot[u] = sl;
         }
+        }  // pending rows
 
         SSA_T(3);
         // membership of the lane's rows in the register-held groups: bit u of hit[g]; as 0.0 / 1.0 factors for the
