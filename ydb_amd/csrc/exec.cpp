@@ -727,6 +727,16 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     args.lds_regok_off = lds;
     lds += plan.NumRegsUsed * kBlock;
     lds = (lds + 15) & ~15;
+    // string heads: only for string columns whose offsets are staged, and only while they do not cost a workgroup
+    for (int c = 0; c < kMaxCols; ++c) args.lds_chars_off[c] = -1;
+    for (int c = 0; c < args.ncols && !noTuning; ++c) {
+        if (!IsStringLike(args.cols[c].type) || args.lds_col_off[c] < 0) continue;
+        if (reinterpret_cast<uintptr_t>(args.cols[c].chars) & 15) continue;  // chunks are copied from 16-byte aligned addresses
+        const int bytes = (kBlock / 64) * kCharsStageBytes;
+        if (kLdsPerCU / (lds + sinkLdsBytes + 1024) != kLdsPerCU / (lds + bytes + sinkLdsBytes + 1024)) continue;
+        args.lds_chars_off[c] = lds;
+        lds += bytes;
+    }
     args.lds_sink_off = lds;
     lds += sinkLdsBytes;
     if (lds > kLdsPerCU - 1024) return Status::Unsupported("step needs more LDS than one CU has");

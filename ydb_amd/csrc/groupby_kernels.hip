@@ -397,6 +397,7 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
                     n[u] = 0;
                     if ((m.P >> u) & 1u) m.StringAt(ks.col, u, p[u], n[u]);
                 }
+                m.WaitStringHeads();
 #pragma unroll
                 for (int u = 0; u < U; ++u) w[u] = m.StringHead(ks.col, p[u], n[u]);
 #pragma unroll

@@ -190,7 +190,13 @@ struct Machine {
     uint64_t tConstBits;                     // constant (lane)
     uint32_t tConstValid;
     uint32_t tColStageW;                     // column slot: bytes per row of the staged buffer
+    uint32_t tColCharsLds;                   // column slot: LDS offset of this wave's string-head area, or -1
+    // string heads staged for the current tile, per column slot (lane c): first staged byte (offset inside the
+    // column's chars) and number of staged bytes; 0 bytes = not staged
+    uint32_t tCharsBegin, tCharsBytes, tCharsSkew;
     int waveBase;                            // first tile row of this wave: wave * 64 * U
+    bool charsPending;                       // a string-head copy of this tile has been issued and not yet awaited
+    bool anyCharsStage;                      // some string column has a head area
     int ncols;
     int64_t nrows;
     int ncode;
@@ -217,6 +223,12 @@ struct Machine {
         tConstBits = a.consts[k].bits;
         tConstValid = uint32_t(a.consts[k].valid);
         tColStageW = uint32_t(StageWidth(a.cols[c].type));
+        tColCharsLds = a.lds_chars_off[c] < 0 ? 0xFFFFFFFFu
+                                              : uint32_t(a.lds_chars_off[c]) + (threadIdx.x >> 6) * uint32_t(kCharsStageBytes);
+        tCharsBegin = tCharsBytes = tCharsSkew = 0;
+        anyCharsStage = false;
+        for (int col = 0; col < a.ncols; ++col) anyCharsStage = anyCharsStage || a.lds_chars_off[col] >= 0;
+        charsPending = false;
         waveBase = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)) * (64 * U);
         ncols = a.ncols;
     }
@@ -256,6 +268,56 @@ struct Machine {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (anyCharsStage) StageStringHeads(slice0);
+    }
+
+    // Second staging phase, for string columns: with the offsets of the wave's rows now in LDS, copy the bytes from
+    // the first row's string to 8 bytes past the start of the last row's string into the wave's head area.  Nothing
+    // waits for this copy here: WaitStringHeads() is called right before the first use, after other work.
+    __device__ __forceinline__ void StageStringHeads(int64_t slice0) {
+        const int lane = threadIdx.x & 63;
+        charsPending = false;
+        const int64_t last = (slice0 + 64 * U <= nrows ? slice0 + 64 * U : nrows) - 1;  // last row of the slice
+        for (int c = 0; c < ncols; ++c) {
+            const uint32_t area = ReadLane32(tColCharsLds, c);
+            if (area == 0xFFFFFFFFu) continue;
+            uint32_t begin = 0, bytes = 0, skew = 0;
+            if (last >= slice0) {
+                const int32_t* l = reinterpret_cast<const int32_t*>(gLds + int(ReadLane32(tColOff, c)));
+                const uint32_t b0 = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase]));
+                const uint32_t bl = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase + int(last - slice0)]));
+                const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
+                const uint32_t limit = ReadLane32(tColCharsBytes, c);
+                uint32_t endb = bl + 8;
+                if (endb > limit) endb = limit;
+                skew = uint32_t(reinterpret_cast<uintptr_t>(chars + b0) & 15u);
+                // the copy moves whole 16-byte chunks: it must fit the area and stay inside the chars buffer
+                if (endb > b0 && endb - b0 + skew <= uint32_t(kCharsStageBytes - 16) &&
+                    uint64_t(b0 - skew) + ((uint64_t(endb - b0 + skew) + 15u) & ~15ull) <= uint64_t(limit)) {
+                    begin = b0;
+                    bytes = endb - b0;
+                    const uint8_t* src = chars + b0 - skew;
+                    const uint32_t total = bytes + skew;
+                    for (uint32_t chunk = 0; chunk < total; chunk += 1024) {
+                        const uint32_t o = chunk + uint32_t(lane) * 16;
+                        if (o < total) __builtin_amdgcn_global_load_lds((GlobalPtr)(src + o), (LdsPtr)(gLds + area + chunk), 16, 0, 0);
+                    }
+                    charsPending = true;
+                }
+            }
+            if (lane == c) {
+                tCharsBegin = begin;
+                tCharsBytes = bytes;
+                tCharsSkew = skew;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void WaitStringHeads() {
+        if (charsPending) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            charsPending = false;
+        }
     }
 
     __device__ __forceinline__ uint32_t ValidityOf(int c) const {
@@ -360,10 +422,19 @@ struct Machine {
         const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
         const int64_t off = p - chars;
         uint64_t w = 0;
+        const uint32_t staged = ReadLane32(tCharsBytes, c);
+        const int64_t rel = off - int64_t(ReadLane32(tCharsBegin, c));
+        const int32_t m = n < 8 ? n : 8;
+        if (staged != 0 && rel >= 0 && rel + m <= int64_t(staged)) {
+            // from the wave's head area in LDS (WaitStringHeads() has been called)
+            const uint8_t* l = gLds + ReadLane32(tColCharsLds, c) + ReadLane32(tCharsSkew, c) + rel;
+            for (int32_t j = 0; j < m; ++j) w |= uint64_t(l[j]) << (8 * j);
+            return w;
+        }
         if (off + 8 <= int64_t(ReadLane32(tColCharsBytes, c))) {
             __builtin_memcpy(&w, p, 8);
         } else {
-            for (int32_t j = 0; j < n && j < 8; ++j) w |= uint64_t(p[j]) << (8 * j);
+            for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[j]) << (8 * j);
         }
         return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1ull));
     }
