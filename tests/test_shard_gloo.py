@@ -60,6 +60,60 @@ def test_two_rank_partial_aggregate_merge(tmp_path, codes):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _worker_alltoall(rank, world, port, rows_per_rank, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pickle
+    import torch.distributed as dist
+    from oracle import ssa_oracle
+    from ydb_amd import shard, tpch
+    from ydb_amd.ssa_pb import AGG, Aggregate, Program
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # high-cardinality grouping: by the price column's value, with a string key next to it
+        prog = Program().group_by([Aggregate(120, AGG.COUNT, []), Aggregate(121, AGG.SUM, [tpch.L_QUANTITY]),
+                                   Aggregate(122, AGG.MIN, [tpch.L_SHIPDATE])], keys=[tpch.L_EXTENDEDPRICE, tpch.L_RETURNFLAG])
+        cols = ["l_extendedprice", "l_returnflag", "l_quantity", "l_shipdate"]
+        li = tpch.lineitem_host(rank * rows_per_rank, rows_per_rank)
+        local = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply({c: li[c] for c in cols})
+        parts = shard.all_to_all_results(local, ["l_extendedprice", "l_returnflag"])
+        mp_, mr = shard.merge_program(prog, tpch.LINEITEM_RESOLVER)
+        mine = ssa_oracle.Oracle(mr, mp_).apply(shard.partial_batch(parts, prog, tpch.LINEITEM_RESOLVER))
+        rows = list(zip(mine["l_extendedprice"].to_pylist(), mine["l_returnflag"].to_pylist(), mine["120"].to_pylist(),
+                        mine["121"].to_pylist(), mine["122"].to_pylist()))
+        with open(os.path.join(out_dir, f"part{rank}.pkl"), "wb") as f:
+            pickle.dump(rows, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_hash_partitioned_exchange(tmp_path):
+    """High-cardinality path: groups are exchanged point-to-point to the rank that owns their key hash; the union of the
+    ranks' merged parts is the program applied to the whole table, and no group appears on two ranks."""
+    import pickle
+    sys.path.insert(0, ROOT)
+    from oracle import ssa_oracle
+    from ydb_amd import tpch
+    from ydb_amd.ssa_pb import AGG, Aggregate, Program
+    world, rows_per_rank = 2, 30_000
+    mp.spawn(_worker_alltoall, args=(world, _free_port(), rows_per_rank, str(tmp_path)), nprocs=world, join=True)
+    got = []
+    for r in range(world):
+        with open(os.path.join(tmp_path, f"part{r}.pkl"), "rb") as f:
+            got.extend(pickle.load(f))
+    prog = Program().group_by([Aggregate(120, AGG.COUNT, []), Aggregate(121, AGG.SUM, [tpch.L_QUANTITY]),
+                               Aggregate(122, AGG.MIN, [tpch.L_SHIPDATE])], keys=[tpch.L_EXTENDEDPRICE, tpch.L_RETURNFLAG])
+    full = tpch.lineitem_host(0, world * rows_per_rank)
+    exp = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply({c: full[c] for c in ["l_extendedprice", "l_returnflag", "l_quantity", "l_shipdate"]})
+    want = list(zip(exp["l_extendedprice"].to_pylist(), exp["l_returnflag"].to_pylist(), exp["120"].to_pylist(),
+                    exp["121"].to_pylist(), exp["122"].to_pylist()))
+    assert len(got) == len(want) and len({(a, b) for a, b, *_ in got}) == len(got)
+    assert sorted(got) == sorted(want)
+
+
 def test_merge_program_shape():
     sys.path.insert(0, ROOT)
     from ydb_amd import shard, tpch

@@ -11,8 +11,9 @@ program over its own rows; the only exchange is the small table of partial aggre
     partial columns (SUM of sums and counts, MIN of mins, MAX of maxes, SOME of somes) with the same keys
     -- which runs through the same GPU executor as any other program.
 
-High-cardinality groupings would instead hash-partition the partial tables with an all-to-all so that
-each rank merges 1/N of the groups; `partition_of_keys` provides the rank assignment for that path.
+High-cardinality groupings instead hash-partition the partial tables (`all_to_all_results`: point-to-point
+sends to the rank that owns each key hash, `partition_of_keys`), so that each rank merges 1/N of the groups
+and the result stays distributed.
 """
 from __future__ import annotations
 
@@ -179,6 +180,66 @@ def all_gather_results(result: Dict[str, ResultColumn], device=None) -> List[Dic
     return [unpack_result(b[:int(s.item())].cpu().numpy().tobytes()) for b, s in zip(bufs, sizes)]
 
 
+def key_hashes(result: Dict[str, ResultColumn], key_names: Sequence[str]) -> np.ndarray:
+    """64-bit hash of every row's key tuple (value bytes; a null hashes as its own marker), the same on every rank."""
+    n = len(next(iter(result.values())).valid) if result else 0
+    h = np.full(n, 0x9E3779B97F4A7C15, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for name in key_names:
+            c = result[name]
+            if isinstance(c.values, list):
+                import zlib
+                v = np.array([zlib.crc32(bytes(x)) | (len(x) << 32) for x in c.values], dtype=np.uint64)
+            else:
+                a = np.ascontiguousarray(c.values)
+                v = a.view(np.dtype(f"u{a.dtype.itemsize}")).astype(np.uint64)
+            v = np.where(np.asarray(c.valid, dtype=np.bool_), v, np.uint64(0xDEADBEEFCAFEF00D))
+            h = (h ^ v) * np.uint64(0xFF51AFD7ED558CCD)
+            h ^= h >> np.uint64(33)
+    return h
+
+
+def take_rows(result: Dict[str, ResultColumn], rows: np.ndarray) -> Dict[str, ResultColumn]:
+    out: Dict[str, ResultColumn] = {}
+    for key, c in result.items():
+        if isinstance(c.values, list):
+            vals = [c.values[i] for i in rows]
+        else:
+            vals = np.asarray(c.values)[rows]
+        out[key] = ResultColumn(c.name, c.type, vals, np.asarray(c.valid)[rows], getattr(c, "decimal", None))
+    return out
+
+
+def all_to_all_results(result: Dict[str, ResultColumn], key_names: Sequence[str], device=None) -> List[Dict[str, ResultColumn]]:
+    """Hash-partitioned exchange for high-cardinality groupings: every group goes to the rank that owns its key hash,
+    so each rank merges 1/N of the groups and the final result stays distributed.  Point-to-point sends (RCCL over
+    xGMI keeps all links busy; gloo on CPU) -- one size exchange, one payload exchange."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    owner = partition_of_keys(key_hashes(result, key_names), world)
+    payloads = [pack_result(take_rows(result, np.nonzero(owner == r)[0])) for r in range(world)]
+    sizes_out = torch.tensor([len(p) for p in payloads], dtype=torch.int64, device=dev)
+    sizes_all = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes_all, sizes_out)
+    sizes_in = [int(sizes_all[r][rank].item()) for r in range(world)]
+    send = [torch.frombuffer(bytearray(p), dtype=torch.uint8).to(dev) for p in payloads]
+    recv = [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes_in]
+    ops = []
+    for r in range(world):
+        if r == rank:
+            recv[r] = send[r]
+            continue
+        ops.append(dist.P2POp(dist.isend, send[r], r))
+        ops.append(dist.P2POp(dist.irecv, recv[r], r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return [unpack_result(t.cpu().numpy().tobytes()) for t in recv]
+
+
 def partition_of_keys(key_hashes: np.ndarray, world: int) -> np.ndarray:
     """Rank that owns each group in the hash-partitioned (all-to-all) merge of high-cardinality groupings."""
     h = np.asarray(key_hashes, dtype=np.uint64)
@@ -209,15 +270,33 @@ class ShardedScan:
             if not ok:
                 raise ValueError(err)
 
-    def run(self, batch, gather_device=None) -> Dict[str, ResultColumn]:
-        """Local scan (HBM-resident `batch`), then -- when torch.distributed is initialised with more than one
-        rank -- the all-gather of the partial tables and the merge program."""
+    # partial tables larger than this go through the hash-partitioned exchange
+    ALL_TO_ALL_GROUPS = 65536
+
+    def run(self, batch, gather_device=None, exchange: str = "auto") -> Dict[str, ResultColumn]:
+        """Local scan (HBM-resident `batch`), then -- when torch.distributed is initialised with more than one rank --
+        the exchange of the partial tables and the merge program.  exchange = "allgather": every rank ends with the
+        whole result; "alltoall": every rank ends with the groups whose key hash it owns (their union is the result);
+        "auto": all-to-all once any rank's partial table exceeds ALL_TO_ALL_GROUPS rows."""
         import torch.distributed as dist
 
         partial = self.local.Export(self.local.ApplyDevice(batch))
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return partial
-        parts = all_gather_results(partial, gather_device)
         if self.merge is None:
             raise ValueError("sharded scan without aggregation: results stay on their shards")
-        return self.merge.ApplyProgram(partial_batch(parts, self.program, self.resolver))
+        return self.merge.ApplyProgram(self.exchange(partial, gather_device, exchange))
+
+    def exchange(self, partial: Dict[str, ResultColumn], device=None, exchange: str = "auto") -> Dict[str, Col]:
+        """The merge program's input batch on this rank."""
+        import torch
+        import torch.distributed as dist
+
+        names = {i: n for i, n in self.resolver}
+        key_names = [_column_name(k, names) for k in last_group_by(self.program).keys]
+        if exchange == "auto":
+            n = torch.tensor([len(next(iter(partial.values())).valid)], dtype=torch.int64, device=device or torch.device("cpu"))
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            exchange = "alltoall" if (key_names and int(n.item()) > self.ALL_TO_ALL_GROUPS) else "allgather"
+        parts = all_to_all_results(partial, key_names, device) if exchange == "alltoall" else all_gather_results(partial, device)
+        return partial_batch(parts, self.program, self.resolver)
