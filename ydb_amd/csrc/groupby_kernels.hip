@@ -474,9 +474,6 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
         SSA_T(2);
         // group of each row: >= 0 dense id in level 1, <= -2 level-2 slot g as -2 - g, -1 no row
         int64_t slot[U];
-        uint32_t hpos[U];
-        uint64_t seenLo[U], seenHi[U];
-        uint32_t seenId[U];
         // Groups held in registers are recognised by comparing with their keys: no hashing, no LDS round trip.
         if (useHot && hotKnown < kHotGroups) {
 #pragma unroll
@@ -505,30 +502,13 @@ __global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>
             if (id >= 0 && useHot) slot[u] = id; else pending |= 1u << u;
         }
         if (__any(pending != 0)) {
-        // first probe of every row, issued together: in the steady state the group is there
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            hpos[u] = 0;
-            seenLo[u] = kEmpty;
-            seenHi[u] = 0;
-            seenId[u] = kNoDense;
-            if (!((pending >> u) & 1u)) continue;
-            hpos[u] = Fold32(kb.lo[u], kb.hi[u]);
-            if (L > 0) {
-                const uint32_t pos = hpos[u] & uint32_t(L - 1);
-                seenLo[u] = __hip_atomic_load(lLo + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (twoWords) seenHi[u] = __hip_atomic_load(lHi + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                seenId[u] = __hip_atomic_load(lDense + pos, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
+        // rows of other groups (and of the first groups until their keys are known): one at a time through the tables
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!((pending >> u) & 1u)) continue;
-            const uint32_t h = hpos[u];
+            const uint32_t h = Fold32(kb.lo[u], kb.hi[u]);
             int64_t sl = -1;
-            if (seenLo[u] == kb.lo[u] && (!twoWords || seenHi[u] == kb.hi[u]) && seenId[u] != kNoDense) {
-                sl = int64_t(seenId[u]);
-            } else if (L > 0) {
+            if (L > 0) {
                 sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
                                     uint64_t(m.Row(u)), ldsProbes);
             }
