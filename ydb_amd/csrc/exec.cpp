@@ -1,4 +1,5 @@
 #include "exec.h"
+#include "jit.h"
 
 #include <hip/hip_runtime.h>
 
@@ -6,7 +7,9 @@
 #include <cstdlib>
 #include <climits>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <set>
 
 #include "vm_ops.h"
 
@@ -779,6 +782,57 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     return Status::OK();
 }
 
+// The scan kernel compiled for this launch's step program (jit.h), or nullptr: then the generic kernel runs.  The
+// constant image is the {ScanArgs, Sink} pair with everything that changes from batch to batch cleared; `cfg` gets the
+// grid for the residency of the compiled kernel.
+hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry, const std::string& defines, const ScanArgs& args,
+                                          const void* sinkImage, size_t sinkBytes, int64_t rows, LaunchCfg& cfg) {
+    std::vector<uint32_t> image((sizeof(ScanArgs) + sinkBytes + 3) / 4, 0u);
+    ScanArgs a = args;
+    a.nrows = 0;
+    a.status = nullptr;
+    for (int c = 0; c < kMaxCols; ++c) {
+        a.cols[c].values = nullptr;
+        a.cols[c].validity = nullptr;
+        a.cols[c].chars = nullptr;
+        a.cols[c].chars_bytes = 0;
+        a.cols[c].val_bit_off = 0;
+        a.cols[c].valid_bit_off = 0;
+    }
+    std::memcpy(image.data(), &a, sizeof(a));
+    std::memcpy(reinterpret_cast<char*>(image.data()) + sizeof(ScanArgs), sinkImage, sinkBytes);
+    SpecKernel k;
+    std::string why;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool got = KernelJit::Instance().Get(Device, header, entry, image.data(), image.size() * 4, defines, cfg.lds_bytes, k, why);
+    if (std::getenv("SSA_DEBUG_PLAN")) {
+        std::fprintf(stderr, "specialised %s: %s, %.1f ms, %d workgroups per CU\n", entry, got ? "ok" : "none",
+                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), k.BlocksPerCU);
+    }
+    if (!got) {
+        static std::mutex lock;
+        static std::set<std::string> told;
+        std::lock_guard<std::mutex> g(lock);
+        if (told.insert(why.substr(0, 200)).second) {
+            std::fprintf(stderr, "ydb_ssa_hip: no kernel built for this program, the generic one runs (%s)\n", why.c_str());
+        }
+        return nullptr;
+    }
+    const int64_t ntiles = (rows + kTileRows - 1) / kTileRows;
+    const int perCU = std::max(1, std::min(4, k.BlocksPerCU));
+    cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU));
+    return k.Function;
+}
+
+hipError_t Executor::LaunchSpecialized(hipFunction_t fn, const ScanArgs& args, const void* sink, size_t sinkBytes, const LaunchCfg& cfg) {
+    std::vector<char> kargs(sizeof(ScanArgs) + sinkBytes);
+    std::memcpy(kargs.data(), &args, sizeof(ScanArgs));
+    std::memcpy(kargs.data() + sizeof(ScanArgs), sink, sinkBytes);
+    size_t bytes = kargs.size();
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kargs.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(fn, unsigned(cfg.grid), 1, 1, kBlock, 1, 1, cfg.lds_bytes, cfg.stream, nullptr, extra);
+}
+
 // ---------------------------------------------------------------------------------------------
 // helpers producing output columns
 // ---------------------------------------------------------------------------------------------
@@ -936,20 +990,30 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
     int64_t algoBytes;
     const int naggs = int(plan.Aggs.size());
     SSA_RETURN_NOT_OK(FillScanArgs(plan, in, naggs * kBlock * 8, SCAN_NOKEY, args, cfg, algoBytes));
-    BufferPtr partial = Buffer::Alloc(size_t(cfg.grid) * kMaxAggs * 8);
-    BufferPtr seen = Buffer::Alloc(size_t(cfg.grid) * 4);
-    BufferPtr outVals = Buffer::Alloc(kMaxAggs * 8 + kMaxAggs);
-    if (!partial || !seen || !outVals) return Status::Hip("out of device memory");
     NoKeySink sink{};
     sink.naggs = naggs;
     for (int k = 0; k < naggs; ++k) {
         sink.aggs[k] = plan.Aggs[size_t(k)].Spec;
         if (sink.aggs[k].reg != -1) EncodeOperand(args, sink.aggs[k].reg, sink.aggs[k].fetch_kind, sink.aggs[k].fetch_payload);
     }
+    // a scan of many rows runs the kernel built for this step program, when that can be had
+    hipFunction_t spec = nullptr;
+    if (JitWanted(in.Rows)) {
+        const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n";
+        spec = SpecializedKernel("nokey_scan.h", "ssa_spec_nokey", defines, args, &sink, sizeof(sink), in.Rows, cfg);
+    }
+    BufferPtr partial = Buffer::Alloc(size_t(cfg.grid) * kMaxAggs * 8);
+    BufferPtr seen = Buffer::Alloc(size_t(cfg.grid) * 4);
+    BufferPtr outVals = Buffer::Alloc(kMaxAggs * 8 + kMaxAggs);
+    if (!partial || !seen || !outVals) return Status::Hip("out of device memory");
     sink.partial = static_cast<uint64_t*>(partial->Ptr);
     sink.partial_seen = static_cast<uint32_t*>(seen->Ptr);
     ProfileBegin();
-    SSA_HIP(LaunchScanNoKey(args, sink, cfg));
+    if (spec) {
+        SSA_HIP(LaunchSpecialized(spec, args, &sink, sizeof(sink), cfg));
+    } else {
+        SSA_HIP(LaunchScanNoKey(args, sink, cfg));
+    }
     ProfileEnd("ScanNoKeyKernel", algoBytes);
     uint64_t* dv = static_cast<uint64_t*>(outVals->Ptr);
     uint8_t* dvalid = reinterpret_cast<uint8_t*>(dv + kMaxAggs);
@@ -1321,8 +1385,25 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         sink.t_seen = static_cast<uint32_t*>(tSeen->Ptr);
         sink.t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
         if (in.Rows > 0) {
+            // a scan of many rows runs the kernel built for this step program, when that can be had
+            hipFunction_t spec = nullptr;
+            LaunchCfg specCfg = cfg;
+            if (JitWanted(in.Rows)) {
+                KeyedSink image = sink;
+                image.t_key_lo = image.t_key_hi = image.t_acc = nullptr;
+                image.t_seen = nullptr;
+                image.t_rep_row = nullptr;
+                image.table_mask = 0;
+                const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n#define SSA_SPEC_HASHED " +
+                                            (hashed ? "1" : "0") + "\n";
+                spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, args, &image, sizeof(image), in.Rows, specCfg);
+            }
             ProfileBegin();
-            SSA_HIP(LaunchScanKeyed(args, sink, cfg));
+            if (spec) {
+                SSA_HIP(LaunchSpecialized(spec, args, &sink, sizeof(sink), specCfg));
+            } else {
+                SSA_HIP(LaunchScanKeyed(args, sink, cfg));
+            }
             ProfileEnd("ScanKeyedKernel", algoBytes);
         }
         if (std::getenv("SSA_PHASE_TIMING")) {  // diagnostics build only (-DSSA_PHASE_TIMING): cycles per phase, summed over waves

@@ -105,6 +105,9 @@ private:
                            int64_t& selected);
     Status FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, int kernelId, ScanArgs& args,
                         LaunchCfg& cfg, int64_t& algoBytes);
+    hipFunction_t SpecializedKernel(const char* header, const char* entry, const std::string& defines, const ScanArgs& args,
+                                    const void* sinkImage, size_t sinkBytes, int64_t rows, LaunchCfg& cfg);
+    hipError_t LaunchSpecialized(hipFunction_t fn, const ScanArgs& args, const void* sink, size_t sinkBytes, const LaunchCfg& cfg);
     Status CheckScanStatus(bool* tableFull = nullptr);
     Status CompactColumn(const Column& src, int64_t rows, const BufferPtr& bitmap, const BufferPtr& tileOffsets,
                          int64_t selected, Column& dst);

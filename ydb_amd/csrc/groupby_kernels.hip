@@ -1,704 +1,11 @@
-// Keyed GROUP BY: the scan VM feeding a hash aggregation sink, and the kernels that turn the hash table
-// into output columns.
-//
-// The reference aggregates through a ClickHouse-derived hash aggregator, one batch at a time
-// (ydb/library/arrow_clickhouse/Aggregator.cpp:132-226 picks the hash method from the key columns,
-// Aggregator.cpp:228-330 executes a batch).  Here one fused pass evaluates the step's expressions and
-// feeds every passing row into a two-level table:
-//
-//   * level 1 lives in the workgroup's LDS and absorbs low-cardinality groupings entirely: each slot
-//     carries R replicas of every accumulator so that the lanes of a wave that hit the same group
-//     spread over R addresses instead of serialising on one;
-//   * level 2 is an open-addressing table in HBM.  Rows whose key does not fit level 1 go there
-//     directly; level 1 is merged into it once, when the workgroup has consumed its last tile.
-//
-// Keys are 128 bits (lo, hi).  Fixed-width keys of up to 119 bits in total are packed exactly (value
-// bits and, for the null-aware methods, one null flag per key), so the table compares keys, not
-// hashes, and the output key columns are decoded from the table.  Anything wider -- and every string
-// key -- is reduced to a 126-bit hash; those tables also keep the smallest row index of each group and
-// the output keys are gathered from that row of the input.
-//
-// HBM traffic of the scan is the referenced source columns once plus the table, which is tiny for the
-// groupings this path is for; the bound is HBM bandwidth.
+// Group-by kernels of the library build: the keyed scan (keyed_scan.h) in its generic form, and the kernels that turn
+// the hash table into output columns.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
-#include "scan_vm.h"
+#include "keyed_scan.h"
 
 namespace ssa {
-
-namespace {
-
-constexpr uint64_t kEmpty = ~0ull;        // lo word of a free slot (real keys keep bit 63 of lo clear)
-constexpr uint64_t kUnpublished = ~0ull;  // hi word of a slot whose owner has not stored it yet
-
-__device__ __forceinline__ uint64_t Mix64(uint64_t x) {
-    x ^= x >> 33;
-    x *= 0xFF51AFD7ED558CCDull;
-    x ^= x >> 33;
-    x *= 0xC4CEB9FE1A85EC53ull;
-    x ^= x >> 33;
-    return x;
-}
-
-// Table position of a key.  Only the spread matters (equality is decided on the key words), so 32 bits of
-// multiply-xorshift are enough; both table levels take their index from it.
-__device__ __forceinline__ uint32_t Fold32(uint64_t lo, uint64_t hi) {
-    uint32_t x = uint32_t(lo) ^ (uint32_t(lo >> 32) * 0x9E3779B1u) ^ (uint32_t(hi) * 0x85EBCA6Bu) ^ (uint32_t(hi >> 32) * 0xC2B2AE35u);
-    x ^= x >> 16;
-    x *= 0x7FEB352Du;
-    x ^= x >> 15;
-    x *= 0x846CA68Bu;
-    x ^= x >> 16;
-    return x;
-}
-
-// Order-preserving map double -> uint64 (so float min/max become integer atomics) and back.
-__device__ __forceinline__ uint64_t OrderedFromF64(uint64_t bits) {
-    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
-}
-__device__ __forceinline__ uint64_t F64FromOrdered(uint64_t enc) {
-    return (enc >> 63) ? (enc & 0x7FFFFFFFFFFFFFFFull) : ~enc;
-}
-
-// What the tables hold for an untouched accumulator.
-__device__ __host__ inline uint64_t TableIdentity(int kind) {
-    switch (kind) {
-        case AGG_MIN_I: return uint64_t(INT64_MAX);
-        case AGG_MAX_I: return uint64_t(INT64_MIN);
-        case AGG_MIN_U: return ~0ull;
-        case AGG_MIN_F: return 0xFFF0000000000000ull;  // ordered(+inf)
-        case AGG_MAX_F: return 0x000FFFFFFFFFFFFFull;  // ordered(-inf)
-        default: return 0;
-    }
-}
-
-// Accumulator update.  The same code serves LDS and HBM accumulators: after inlining the compiler
-// knows the address space and picks ds_* or global_* atomics.
-__device__ __forceinline__ void AccUpdate(int kind, uint64_t* p, uint64_t v) {
-    switch (kind) {
-        case AGG_COUNT:
-        case AGG_SUM_I:
-            atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
-            break;
-        case AGG_SUM_F:
-            atomicAdd(reinterpret_cast<double*>(p), BitsToF64(v));
-            break;
-        case AGG_MIN_I:
-            atomicMin(reinterpret_cast<long long*>(p), static_cast<long long>(v));
-            break;
-        case AGG_MAX_I:
-            atomicMax(reinterpret_cast<long long*>(p), static_cast<long long>(v));
-            break;
-        case AGG_MIN_U:
-        case AGG_MIN_F:
-            atomicMin(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
-            break;
-        case AGG_MAX_U:
-        case AGG_MAX_F:
-            atomicMax(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
-            break;
-        default:
-            break;
-    }
-}
-
-// Merge of two table states of one aggregate (level-1 replicas; level 1 into level 2 goes through
-// AccUpdate because other workgroups update level 2 concurrently).
-__device__ __forceinline__ uint64_t TableCombine(int kind, uint64_t a, uint64_t b) {
-    switch (kind) {
-        case AGG_COUNT: case AGG_SUM_I: return a + b;
-        case AGG_SUM_F: return F64ToBits(BitsToF64(a) + BitsToF64(b));
-        case AGG_MIN_I: return int64_t(b) < int64_t(a) ? b : a;
-        case AGG_MAX_I: return int64_t(b) > int64_t(a) ? b : a;
-        case AGG_MIN_U: case AGG_MIN_F: return b < a ? b : a;
-        case AGG_MAX_U: case AGG_MAX_F: return b > a ? b : a;
-        default: return a;
-    }
-}
-
-// Find or claim the slot of key (lo, hi) in an open-addressing table of `mask + 1` slots, starting at
-// `start`.  A slot is claimed by a compare-and-swap on its lo word; the owner then publishes hi.  A
-// lane that finds its own lo with hi not yet published looks at the same slot again on the next trip
-// of the loop: the lanes of a wave take every trip together, so the owner's store has been issued by
-// then, and owners in other waves make progress on their own.  Returns -1 after `maxProbes` slots.
-__device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uint64_t mask, uint64_t start, uint64_t lo,
-                                               uint64_t hi, bool twoWords, uint32_t maxProbes) {
-    uint64_t s = start & mask;
-    uint32_t probes = 0;
-    while (probes < maxProbes) {
-        uint64_t cur = __hip_atomic_load(tLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == kEmpty) {
-            cur = atomicCAS(reinterpret_cast<unsigned long long*>(tLo + s), static_cast<unsigned long long>(kEmpty),
-                            static_cast<unsigned long long>(lo));
-            if (cur == kEmpty) {
-                if (twoWords) __hip_atomic_store(tHi + s, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return int64_t(s);
-            }
-        }
-        if (cur == lo) {
-            if (!twoWords) return int64_t(s);
-            const uint64_t ch = __hip_atomic_load(tHi + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ch == hi) return int64_t(s);
-            if (ch == kUnpublished) continue;
-        }
-        s = (s + 1) & mask;
-        ++probes;
-    }
-    return -1;
-}
-
-// Hash of a string key: its length, then its bytes in 8-byte little-endian words.  Takes and returns
-// the two hash lanes by value so that the caller's key state stays in registers.
-struct HashPair {
-    uint64_t lo, hi;
-};
-__device__ __forceinline__ void AbsorbWord(HashPair& h, uint64_t w) {
-    h.lo = (h.lo ^ w) * 0x9E3779B97F4A7C15ull;
-    h.lo ^= h.lo >> 29;
-    h.hi = (h.hi + w) * 0xC2B2AE3D27D4EB4Full;
-    h.hi ^= h.hi >> 31;
-}
-__device__ __noinline__ HashPair AbsorbString(HashPair h, const uint8_t* p, int32_t n) {
-    AbsorbWord(h, uint64_t(uint32_t(n)));
-    for (int32_t i = 0; i < n; i += 8) {
-        uint64_t w = 0;
-        const int32_t m = (n - i) < 8 ? (n - i) : 8;
-        for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[i + j]) << (8 * j);
-        AbsorbWord(h, w);
-    }
-    return h;
-}
-
-// ---- key construction ---------------------------------------------------------------------------------
-template <int U>
-struct KeyBuilder {
-    uint64_t lo[U], hi[U];
-    int pos;  // exact packing: bits used so far (wave-uniform)
-
-    __device__ __forceinline__ void Begin(bool hashed) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            lo[u] = hashed ? 0x243F6A8885A308D3ull : 0ull;
-            hi[u] = hashed ? 0x13198A2E03707344ull : 0ull;
-        }
-        pos = 0;
-    }
-    // exact: append the low `nbits` of `bits`
-    __device__ __forceinline__ void Append(int u, uint64_t bits, int nbits) {
-        (void)nbits;
-        if (pos < 64) {
-            lo[u] |= bits << pos;
-            if (pos > 0 && pos + nbits > 64) hi[u] |= bits >> (64 - pos);
-        } else {
-            hi[u] |= bits << (pos - 64);
-        }
-    }
-    // exact packing at a per-row position (rows of a batch with string keys differ in length)
-    __device__ __forceinline__ void AppendAt(int u, uint64_t bits, uint32_t nbits, uint32_t& at) {
-        if (at < 64) {
-            lo[u] |= bits << at;
-            if (at > 0 && at + nbits > 64) hi[u] |= bits >> (64 - at);
-        } else if (at < 128) {
-            hi[u] |= bits << (at - 64);
-        }
-        at += nbits;
-    }
-    // hashed: absorb one 64-bit word into both lanes of the hash
-    __device__ __forceinline__ void Absorb(int u, uint64_t w) {
-        HashPair h{lo[u], hi[u]};
-        AbsorbWord(h, w);
-        lo[u] = h.lo;
-        hi[u] = h.hi;
-    }
-    // Final table key: bit 63 of lo stays clear (so lo never equals the free marker) and hi never
-    // equals the unpublished marker: exact keys keep its top byte zero, hashed keys force 0b10 on top.
-    __device__ __forceinline__ void Finish(int u, bool hashed) {
-        if (hashed) {
-            lo[u] = Mix64(lo[u]) & 0x7FFFFFFFFFFFFFFFull;
-            hi[u] = (Mix64(hi[u]) | 0x8000000000000000ull) & ~0x4000000000000000ull;
-        } else {
-            const uint64_t l = lo[u], h = hi[u];
-            lo[u] = l & 0x7FFFFFFFFFFFFFFFull;
-            hi[u] = (h << 1) | (l >> 63);
-        }
-    }
-};
-
-__device__ __forceinline__ uint64_t WidthMask(int nbits) { return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull); }
-
-}  // namespace
-
-// ---- sink: keyed aggregation ------------------------------------------------------------------------
-namespace {
-
-constexpr uint32_t kNoDense = 0xFFFFFFFFu;  // dense id of a level-1 slot not yet published by its owner
-constexpr int kHotGroups = 4;               // groups whose SUM / COUNT accumulators live in registers
-
-// Level-1 upsert.  Hash positions are claimed like level 2; the owner then numbers the group with the next dense id
-// (order of first appearance in this workgroup), records a representative row and publishes the id.  Accumulators are
-// indexed by dense id, so the first kHotGroups groups of a workgroup are the ones kept in registers.
-__device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint64_t* lRep, uint32_t* lDense, uint32_t* lCount,
-                                              uint64_t* lHotKey, uint32_t mask, uint64_t start, uint64_t lo, uint64_t hi, bool twoWords,
-                                              uint64_t row, uint32_t maxProbes) {
-    uint32_t s = uint32_t(start) & mask;
-    uint32_t probes = 0;
-    while (probes < maxProbes) {
-        uint64_t cur = __hip_atomic_load(lLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (cur == kEmpty) {
-            cur = atomicCAS(reinterpret_cast<unsigned long long*>(lLo + s), static_cast<unsigned long long>(kEmpty),
-                            static_cast<unsigned long long>(lo));
-            if (cur == kEmpty) {
-                const uint32_t id = atomicAdd(lCount, 1u);
-                lRep[s] = row;
-                if (twoWords) __hip_atomic_store(lHi + s, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (id < uint32_t(kHotGroups)) {  // key of a register-held group: waves pick it up at their next tile
-                    lHotKey[2 * id + 1] = hi;
-                    __hip_atomic_store(lHotKey + 2 * id, lo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                __hip_atomic_store(lDense + s, id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return int(id);
-            }
-        }
-        if (cur == lo) {
-            bool same = true;
-            if (twoWords) {
-                const uint64_t ch = __hip_atomic_load(lHi + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (ch == kUnpublished) continue;  // owner is between its two stores: look again next trip
-                same = ch == hi;
-            }
-            if (same) {
-                const uint32_t id = __hip_atomic_load(lDense + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (id == kNoDense) continue;
-                return int(id);
-            }
-        }
-        s = (s + 1) & mask;
-        ++probes;
-    }
-    return -1;
-}
-
-}  // namespace
-
-// kHashed: the batch has string keys or more than 119 key bits (per-row packing with a hash for rows that do not fit);
-// otherwise all keys pack exactly at wave-uniform positions.
-#ifdef SSA_PHASE_TIMING
-#define SSA_T(i) do { const uint64_t now_ = __builtin_readcyclecounter(); tphase[i] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define SSA_T(i) do {} while (0)
-#endif
-
-template <int U, bool kHashed>
-__global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>) {
-    const ScanArgs& a = KernArgs<KeyedSink>().a;
-    const KeyedSink& s = KernArgs<KeyedSink>().s;
-    Machine<U> m(a);
-    const int naggs = s.naggs;
-    const int L = s.lds_cap, R = s.lds_rep;
-    const bool twoWords = kHashed || s.two_words != 0;
-    constexpr bool hashed = kHashed;
-    // level-1 table in the sink area of LDS:
-    //   by hash position: lo[L], hi[L], rep[L], dense[L];  by dense id: acc[naggs][L][R], seen[L];  count;
-    //   keys of the register-held groups: hot[kHotGroups][2]
-    uint64_t* lLo = reinterpret_cast<uint64_t*>(gLds + a.lds_sink_off);
-    uint64_t* lHi = lLo + L;
-    uint64_t* lRep = lHi + L;
-    uint64_t* lHotKey = lRep + L;
-    uint64_t* lAcc = lHotKey + 2 * kHotGroups;
-    uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(naggs) * L * R);
-    uint32_t* lDense = lSeen + L;
-    uint32_t* lCount = lDense + L;
-    for (int i = threadIdx.x; i < L; i += kBlock) {
-        lLo[i] = kEmpty;
-        lHi[i] = kUnpublished;
-        lRep[i] = ~0ull;
-        lSeen[i] = 0;
-        lDense[i] = kNoDense;
-    }
-    if (threadIdx.x == 0) *lCount = 0;
-    if (threadIdx.x < 2 * kHotGroups) lHotKey[threadIdx.x] = kEmpty;
-    for (int k = 0; k < naggs; ++k) {
-        const uint64_t ident = TableIdentity(s.aggs[k].kind);
-        for (int i = threadIdx.x; i < L * R; i += kBlock) lAcc[size_t(k) * L * R + i] = ident;
-    }
-    __syncthreads();  // the table is shared by the workgroup's waves
-    const int rep = threadIdx.x & (R - 1);
-    const uint32_t ldsProbes = L < 8 ? uint32_t(L) : 8u;
-
-    // Register accumulators of the first kHotGroups groups x first kHotAggs aggregates (SUM / COUNT only; their
-    // identity is 0 in every representation).  Lane-private for the whole kernel, folded into level 1 at the end.
-    uint64_t hot[kHotGroups][kHotAggs];
-#pragma unroll
-    for (int g = 0; g < kHotGroups; ++g) {
-#pragma unroll
-        for (int k = 0; k < kHotAggs; ++k) hot[g][k] = 0;
-    }
-    const bool useHot = L >= kHotGroups && !(a.debug_flags & 8);
-    // keys of the register-held groups as this wave knows them (a free marker never equals a key)
-    uint64_t hotLo[kHotGroups], hotHi[kHotGroups];
-#pragma unroll
-    for (int g = 0; g < kHotGroups; ++g) hotLo[g] = kEmpty, hotHi[g] = 0;
-    int hotKnown = 0;
-
-    // Sink description in VGPR lanes (lane i: key i / accumulator i), decoded with v_readlane inside the tile loop:
-    // re-reading the kernel-argument segment there costs a scalar-memory round trip per field and tile.
-    const int lane = threadIdx.x & 63;
-    const int ki = lane < kMaxKeys ? lane : 0;
-    const uint32_t tKeyCol = uint32_t(s.keys[ki].col), tKeyType = uint32_t(s.keys[ki].type), tKeyNullable = uint32_t(s.keys[ki].nullable);
-    const uint32_t tKeyFk = s.keys[ki].fetch_kind, tKeyPayload = s.keys[ki].fetch_payload;
-    const int ai = lane < kMaxAggs ? lane : 0;
-    const uint32_t tAggKind = uint32_t(s.aggs[ai].kind), tAggReg = uint32_t(s.aggs[ai].reg), tAggCheck = uint32_t(s.aggs[ai].check_valid);
-    const uint32_t tAggFk = s.aggs[ai].fetch_kind, tAggPayload = s.aggs[ai].fetch_payload;
-    const int hi_ = lane < kHotAggs ? lane : 0;
-    const uint32_t tHotKind = (lane < kHotAggs && !(a.debug_flags & 32)) ? uint32_t(s.hot_kind[hi_]) : 0u;
-    const uint32_t tHotOff = uint32_t(s.hot_off[hi_]);
-    const int nkeys = s.nkeys;
-
-#ifdef SSA_PHASE_TIMING
-    uint64_t tphase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t tlast = __builtin_readcyclecounter();
-#endif
-    const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        SSA_T(7);
-        m.BeginTile(tile * (kBlock * U));
-        SSA_T(0);
-        m.Run();
-        SSA_T(1);
-        if (m.P == 0) continue;
-
-        // Keys of the lane's rows.  Batches whose keys all have a fixed width of at most 119 bits pack them at
-        // wave-uniform positions.  Otherwise every row first tries the same exact packing at its own positions, a
-        // string of up to 8 bytes as (length byte, bytes); rows that do not fit in 119 bits -- and only those -- are
-        // reduced to a 126-bit hash.  Exact and hashed keys cannot meet: they differ in the top bits of `hi`.
-        KeyBuilder<U> kb;
-        kb.Begin(false);
-        uint32_t at[U];
-        uint32_t toHash = 0;  // bit u: row u needs the hash
-#pragma unroll
-        for (int u = 0; u < U; ++u) at[u] = 0;
-        for (int k = 0; k < nkeys; ++k) {
-            KeySpec ks;
-            ks.col = int32_t(ReadLane32(tKeyCol, k));
-            ks.type = int32_t(ReadLane32(tKeyType, k));
-            ks.nullable = int32_t(ReadLane32(tKeyNullable, k));
-            ks.fetch_kind = ReadLane32(tKeyFk, k);
-            ks.fetch_payload = ReadLane32(tKeyPayload, k);
-            if (kHashed && ks.col >= 0) {
-                // string key; the validity of the column is not part of these keys.  The loads of the lane's rows are
-                // issued together, then consumed.
-                const uint8_t* p[U];
-                int32_t n[U];
-                uint64_t w[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    p[u] = nullptr;
-                    n[u] = 0;
-                    if ((m.P >> u) & 1u) m.StringAt(ks.col, u, p[u], n[u]);
-                }
-                m.WaitStringHeads();
-#pragma unroll
-                for (int u = 0; u < U; ++u) w[u] = m.StringHead(ks.col, p[u], n[u]);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!((m.P >> u) & 1u)) continue;
-                    if (n[u] > 8) {
-                        toHash |= 1u << u;
-                        continue;
-                    }
-                    kb.AppendAt(u, uint64_t(uint32_t(n[u])), 8, at[u]);
-                    kb.AppendAt(u, w[u], uint32_t(8 * n[u]), at[u]);
-                }
-                continue;
-            }
-            Val<U> x;
-            m.FetchOperand(ks.fetch_kind, ks.fetch_payload, x);
-            const int nbits = 8 * TypeWidth(ks.type);
-            const uint64_t wmask = WidthMask(nbits);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool isNull = ks.nullable && !((x.ok >> u) & 1u);
-                const uint64_t bits = isNull ? 0ull : (PayloadToStored(x.v[u], ks.type) & wmask);
-                if constexpr (hashed) {
-                    kb.AppendAt(u, bits, uint32_t(nbits), at[u]);
-                    if (ks.nullable) kb.AppendAt(u, isNull ? 1ull : 0ull, 1, at[u]);
-                } else {
-                    kb.Append(u, bits, nbits);
-                }
-            }
-            if constexpr (!hashed) {
-                kb.pos += nbits;
-                if (ks.nullable) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) kb.Append(u, ((x.ok >> u) & 1u) ? 0ull : 1ull, 1);
-                    kb.pos += 1;
-                }
-            }
-        }
-        if constexpr (hashed) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (at[u] > 119) toHash |= 1u << u;
-            }
-            toHash &= m.P;
-            if (__any(toHash != 0)) {
-                // the rare rows: long strings or more than 119 key bits
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!((toHash >> u) & 1u)) continue;
-                    HashPair h{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
-                    for (int k = 0; k < nkeys; ++k) {
-                        const int col = int32_t(ReadLane32(tKeyCol, k));
-                        if (col >= 0) {
-                            const uint8_t* p;
-                            int32_t n;
-                            m.StringAt(col, u, p, n);
-                            h = AbsorbString(h, p, n);
-                        } else {
-                            Val<U> x;
-                            m.FetchOperand(ReadLane32(tKeyFk, k), ReadLane32(tKeyPayload, k), x);
-                            const int type = int32_t(ReadLane32(tKeyType, k));
-                            const bool nullable = ReadLane32(tKeyNullable, k) != 0;
-                            const bool isNull = nullable && !((x.ok >> u) & 1u);
-                            AbsorbWord(h, isNull ? 0ull : (PayloadToStored(x.v[u], type) & WidthMask(8 * TypeWidth(type))));
-                            if (nullable) AbsorbWord(h, isNull ? 1ull : 0ull);
-                        }
-                    }
-                    kb.lo[u] = h.lo;
-                    kb.hi[u] = h.hi;
-                }
-            }
-        }
-
-        SSA_T(2);
-        // group of each row: >= 0 dense id in level 1, <= -2 level-2 slot g as -2 - g, -1 no row
-        int64_t slot[U];
-        // Groups held in registers are recognised by comparing with their keys: no hashing, no LDS round trip.
-        if (useHot && hotKnown < kHotGroups) {
-#pragma unroll
-            for (int g = 0; g < kHotGroups; ++g) {
-                if (g == hotKnown) {
-                    const uint64_t lo = __hip_atomic_load(lHotKey + 2 * g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (__builtin_amdgcn_readfirstlane(uint32_t(lo >> 32)) != 0xFFFFFFFFu) {
-                        hotLo[g] = lo;
-                        hotHi[g] = lHotKey[2 * g + 1];
-                        hotKnown = g + 1;
-                    }
-                }
-            }
-        }
-        uint32_t pending = 0;  // rows whose group still has to be looked up in the tables
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            slot[u] = -1;
-            if (!((m.P >> u) & 1u)) continue;
-            kb.Finish(u, ((toHash >> u) & 1u) != 0);
-            int id = -1;
-#pragma unroll
-            for (int g = 0; g < kHotGroups; ++g) {
-                if (kb.lo[u] == hotLo[g] && (!twoWords || kb.hi[u] == hotHi[g])) id = g;
-            }
-            if (id >= 0 && useHot) slot[u] = id; else pending |= 1u << u;
-        }
-        if (__any(pending != 0)) {
-        // rows of other groups (and of the first groups until their keys are known): one at a time through the tables
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!((pending >> u) & 1u)) continue;
-            const uint32_t h = Fold32(kb.lo[u], kb.hi[u]);
-            int64_t sl = -1;
-            if (L > 0) {
-                sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
-                                    uint64_t(m.Row(u)), ldsProbes);
-            }
-            if (sl < 0) {
-                const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, kb.lo[u], kb.hi[u], twoWords, 4096u);
-                if (g < 0) {
-                    m.err |= SCAN_TABLE_FULL;
-                    m.P &= ~(1u << u);
-                } else {
-                    sl = -2 - g;
-                    if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(s.t_rep_row + g), static_cast<unsigned long long>(m.Row(u)));
-                }
-            }
-            slot[u] = sl;
-        }
-        }  // pending rows
-
-        SSA_T(3);
-        // membership of the lane's rows in the register-held groups: bit u of hit[g]; as 0.0 / 1.0 factors for the
-        // floating-point sums (one FMA per row and group)
-        uint32_t hit[kHotGroups];
-        double one[kHotGroups][U];
-        uint32_t hotRows = 0;
-#pragma unroll
-        for (int g = 0; g < kHotGroups; ++g) {
-            hit[g] = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool in = useHot && slot[u] == g;
-                hit[g] |= (in ? 1u : 0u) << u;
-                one[g][u] = in ? 1.0 : 0.0;
-            }
-            hotRows |= hit[g];
-        }
-
-        // Register path: aggregates the host marked as plain 64-bit SUMs over an LDS-resident operand (a staged
-        // column or an R register) and the row counter.  Kept tiny on purpose: it is unrolled per aggregate.
-        uint32_t hotDone = 0;
-        if (useHot && !(a.debug_flags & 2)) {
-#pragma unroll
-            for (int k = 0; k < kHotAggs; ++k) {
-                const int hk = int(ReadLane32(tHotKind, k));
-                if (hk == HOT_SUM_F64) {
-                    const double* src = reinterpret_cast<const double*>(gLds + ReadLane32(tHotOff, k));
-                    double x[U];
-                    bool finite = true;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        x[u] = src[m.Idx(u)];
-                        finite = finite && (x[u] - x[u] == 0.0);
-                    }
-                    // x * 0.0 must be 0: an infinity / NaN anywhere in the wave's rows sends this aggregate through
-                    // the tables for this tile
-                    if (__all(finite)) {
-#pragma unroll
-                        for (int g = 0; g < kHotGroups; ++g) {
-                            double acc = BitsToF64(hot[g][k]);
-#pragma unroll
-                            for (int u = 0; u < U; ++u) acc = __builtin_fma(x[u], one[g][u], acc);
-                            hot[g][k] = F64ToBits(acc);
-                        }
-                        hotDone |= 1u << k;
-                    }
-                } else if (hk == HOT_SUM_I64) {
-                    const uint64_t* src = reinterpret_cast<const uint64_t*>(gLds + ReadLane32(tHotOff, k));
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint64_t x = src[m.Idx(u)];
-#pragma unroll
-                        for (int g = 0; g < kHotGroups; ++g) hot[g][k] += ((hit[g] >> u) & 1u) ? x : 0ull;
-                    }
-                    hotDone |= 1u << k;
-                } else if (hk == HOT_ROWS) {
-#pragma unroll
-                    for (int g = 0; g < kHotGroups; ++g) hot[g][k] += uint64_t(__popc(hit[g]));
-                    hotDone |= 1u << k;
-                }
-            }
-        }
-
-        SSA_T(4);
-        // Table path: everything else, and the rows of groups that are not register-held.
-        const bool tablesIdle = hotDone == ((1u << naggs) - 1u) && !__any((m.P & ~hotRows) != 0);
-        for (int k = 0; k < naggs && !tablesIdle && !(a.debug_flags & (2 | 16)); ++k) {
-            uint32_t live = m.P & (((hotDone >> k) & 1u) ? ~hotRows : ~0u);
-            if (!__any(live != 0)) continue;
-            AggSpec spec;
-            spec.kind = int32_t(ReadLane32(tAggKind, k));
-            spec.reg = int32_t(ReadLane32(tAggReg, k));
-            spec.check_valid = int32_t(ReadLane32(tAggCheck, k));
-            spec.fetch_kind = ReadLane32(tAggFk, k);
-            spec.fetch_payload = ReadLane32(tAggPayload, k);
-            Val<U> x;
-            if (spec.reg != -1) {
-                m.FetchOperand(spec.fetch_kind, spec.fetch_payload, x);
-                if (spec.check_valid) live &= x.ok;
-            }
-            if (live == 0) continue;
-            const int kind = spec.kind;
-            if (spec.check_valid) {
-                // a nullable argument was seen for the group: set once
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!((live >> u) & 1u)) continue;
-                    if (slot[u] >= 0) {
-                        if (!((lSeen[slot[u]] >> k) & 1u)) atomicOr(lSeen + slot[u], 1u << k);
-                    } else {
-                        uint32_t* g = s.t_seen + (-2 - slot[u]);
-                        if (!((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> k) & 1u)) atomicOr(g, 1u << k);
-                    }
-                }
-            }
-            if (kind == AGG_COUNT) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) x.v[u] = 1;
-            } else if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
-                // fmin / fmax semantics: a NaN never replaces a number (and the identity is an infinity)
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const double d = BitsToF64(x.v[u]);
-                    if (d != d) live &= ~(1u << u);
-                    x.v[u] = OrderedFromF64(x.v[u]);
-                }
-            }
-            uint64_t* accK = lAcc + size_t(k) * L * R;
-            uint64_t* tabK = s.t_acc + size_t(k) * (s.table_mask + 1);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!((live >> u) & 1u)) continue;
-                if (slot[u] >= 0) {
-                    AccUpdate(kind, accK + slot[u] * R + rep, x.v[u]);
-                } else {
-                    AccUpdate(kind, tabK + (-2 - slot[u]), x.v[u]);
-                }
-            }
-        }
-        SSA_T(5);
-    }
-
-#ifdef SSA_PHASE_TIMING
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.status) + 8;
-        for (int i = 0; i < 8; ++i) atomicAdd(dbg + i, static_cast<unsigned long long>(tphase[i]));
-    }
-#endif
-    // fold the register accumulators into level 1 (dense ids 0 .. kHotGroups-1): wave butterfly, then one lane adds
-    if (useHot) {
-#pragma unroll
-        for (int k = 0; k < kHotAggs; ++k) {
-            const int hk = int(ReadLane32(tHotKind, k));
-            if (hk == HOT_NONE) continue;
-#pragma unroll
-            for (int g = 0; g < kHotGroups; ++g) {
-                uint64_t v = hot[g][k];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const uint64_t o = uint64_t(__shfl_xor(static_cast<unsigned long long>(v), off, 64));
-                    v = hk == HOT_SUM_F64 ? F64ToBits(BitsToF64(v) + BitsToF64(o)) : v + o;
-                }
-                if ((threadIdx.x & 63) == 0 && v != 0) AccUpdate(hk == HOT_SUM_F64 ? AGG_SUM_F : AGG_SUM_I, lAcc + (size_t(k) * L + g) * R, v);
-            }
-        }
-    }
-
-    // merge level 1 into level 2
-    __syncthreads();
-    for (int i = threadIdx.x; i < L; i += kBlock) {
-        const uint64_t lo = lLo[i];
-        if (lo == kEmpty) continue;
-        const uint64_t hi = twoWords ? lHi[i] : 0ull;
-        const uint32_t d = lDense[i];
-        const uint32_t h = Fold32(lo, twoWords ? hi : 0ull);
-        const int64_t g = TableUpsert(s.t_key_lo, s.t_key_hi, s.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, lo, hi, twoWords, 4096u);
-        if (g < 0) {
-            m.err |= SCAN_TABLE_FULL;
-            continue;
-        }
-        if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(s.t_rep_row + g), static_cast<unsigned long long>(lRep[i]));
-        for (int k = 0; k < naggs; ++k) {
-            const int kind = s.aggs[k].kind;
-            const uint64_t* src = lAcc + (size_t(k) * L + d) * R;
-            uint64_t v = src[0];
-            for (int r = 1; r < R; ++r) v = TableCombine(kind, v, src[r]);
-            if (v != TableIdentity(kind)) AccUpdate(kind, s.t_acc + size_t(k) * (s.table_mask + 1) + g, v);
-        }
-        const uint32_t seen = lSeen[d];
-        if (seen) atomicOr(s.t_seen + g, seen);
-    }
-    m.ReportErrors();
-}
 
 namespace {
 

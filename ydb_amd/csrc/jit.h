@@ -1,0 +1,46 @@
+// Run-time specialisation of the scan kernels.
+//
+// The library ships generic scan kernels that interpret any step program.  For a program that is going to scan many
+// rows the same hand-written kernel source (scan_vm.h, keyed_scan.h, ...) is compiled once more at run time with the
+// step's tables fixed as constants (see the SSA_SPEC notes in scan_vm.h): loops unroll, the interpreter's dispatch
+// folds away and what is left is the straight-line code of that one program.  Compilation goes through hiprtc, loaded
+// with dlopen so that the library itself does not depend on it.  Compiled kernels are kept in the memory of the
+// process only (keyed by a hash of the constant image and the kernel variant); nothing is written to or read from
+// disk.  Whenever anything here fails the caller keeps using the generic kernel.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace ssa {
+
+struct SpecKernel {
+    hipFunction_t Function = nullptr;
+    int BlocksPerCU = 0;  // resident workgroups per CU at the LDS size given to Get()
+};
+
+class KernelJit {
+public:
+    static KernelJit& Instance();
+
+    // Kernel `entry` of the translation unit `mainHeader` (one of the embedded kernel headers) built for the constant
+    // image `image` (imageBytes, a multiple of 4) and the given defines (e.g. "#define SSA_SPEC_U 4\n").
+    // Returns false when run-time compilation is unavailable or failed; `why` then says what happened.
+    bool Get(int device, const char* mainHeader, const char* entry, const void* image, size_t imageBytes,
+             const std::string& defines, uint32_t ldsBytes, SpecKernel& out, std::string& why);
+
+    // Number of kernels compiled so far; for tests and logs.
+    int64_t Compiled() const;
+
+private:
+    KernelJit() = default;
+};
+
+// Policy knob, read from SSA_JIT at every call: "0" never, "1" always, otherwise specialise scans of at least
+// kJitMinRows rows.
+constexpr int64_t kJitMinRows = int64_t(1) << 23;
+bool JitWanted(int64_t rows);
+
+}  // namespace ssa

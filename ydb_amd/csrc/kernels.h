@@ -1,7 +1,9 @@
 // Host-visible launch interface of the HIP kernels.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#endif
 
 #include "vm.h"
 
@@ -66,6 +68,14 @@ struct KeyedSink {
     int32_t hot_off[kHotAggs];   // LDS byte offset of its 64-bit operand tile
 };
 
+// Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.
+template <class Sink>
+struct KArgs {
+    ScanArgs a;
+    Sink s;
+};
+
+#ifndef __HIPCC_RTC__  // the rest is the host's launch interface
 struct LaunchCfg {
     int grid;
     uint32_t lds_bytes;   // dynamic LDS per workgroup: staged column tiles + R registers + sink area
@@ -166,5 +176,6 @@ struct LineitemColumns {
     int8_t* ls_code;         // (0 = "F", 1 = "O")
 };
 hipError_t LaunchGenLineitem(const LineitemColumns& c, int64_t row0, int64_t nrows, uint64_t seed, hipStream_t st);
+#endif  // !__HIPCC_RTC__
 
 }  // namespace ssa

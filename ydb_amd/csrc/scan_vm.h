@@ -12,10 +12,25 @@
 // Instruction words, column descriptors and constants live in the kernel-argument segment and the
 // program counter is wave-uniform, so decode is scalar work and every `switch` is a scalar branch.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 #include "kernels.h"
 #include "vm_ops.h"
+
+// Two ways to build these kernels.  Ahead of time (the library): one generic kernel per sink interprets whatever step
+// program arrives in the kernel arguments.  At run time, for one step program (SSA_SPEC defined by the generated
+// prelude, which also carries kSpecImage: the bytes of the launch's {ScanArgs, Sink} pair with the pointers cleared):
+// every table read below goes to that constant image instead, loops over instructions, columns, keys and aggregates
+// have constant trip counts and unroll, and the interpreter's switches fold away -- the compiler turns the same
+// source into the straight-line code of that one program.  Addresses, row counts and the like still come from the
+// kernel arguments.
+#ifdef SSA_SPEC
+#define SSA_UNROLL_STATIC _Pragma("unroll")
+#else
+#define SSA_UNROLL_STATIC
+#endif
 
 namespace ssa {
 
@@ -227,11 +242,39 @@ struct Machine {
                                               : uint32_t(a.lds_chars_off[c]) + (threadIdx.x >> 6) * uint32_t(kCharsStageBytes);
         tCharsBegin = tCharsBytes = tCharsSkew = 0;
         anyCharsStage = false;
-        for (int col = 0; col < a.ncols; ++col) anyCharsStage = anyCharsStage || a.lds_chars_off[col] >= 0;
+        SSA_UNROLL_STATIC
+        for (int col = 0; col < S().ncols; ++col) anyCharsStage = anyCharsStage || S().lds_chars_off[col] >= 0;
         charsPending = false;
         waveBase = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)) * (64 * U);
         ncols = a.ncols;
     }
+
+#ifdef SSA_SPEC
+    static constexpr bool kStatic = true;
+    __device__ __forceinline__ const ScanArgs& S() const { return *reinterpret_cast<const ScanArgs*>(kSpecImage); }
+#else
+    static constexpr bool kStatic = false;
+    __device__ __forceinline__ const ScanArgs& S() const { return a; }
+#endif
+    // Table reads: a v_readlane of the lane tables, or the constant image.
+    __device__ __forceinline__ uint32_t Code0(int pc) const { return kStatic ? S().code[3 * pc] : ReadLane32(tCode0, pc); }
+    __device__ __forceinline__ uint32_t Code1(int pc) const { return kStatic ? S().code[3 * pc + 1] : ReadLane32(tCode1, pc); }
+    __device__ __forceinline__ uint32_t Code2(int pc) const { return kStatic ? S().code[3 * pc + 2] : ReadLane32(tCode2, pc); }
+    __device__ __forceinline__ uint32_t ColOff(int c) const { return kStatic ? uint32_t(S().lds_col_off[c]) : ReadLane32(tColOff, c); }
+    __device__ __forceinline__ uint32_t ColType(int c) const { return kStatic ? uint32_t(S().cols[c].type) : ReadLane32(tColType, c); }
+    __device__ __forceinline__ uint32_t ColW(int c) const { return kStatic ? uint32_t(TypeWidth(S().cols[c].type)) : ReadLane32(tColW, c); }
+    __device__ __forceinline__ uint32_t ColStageW(int c) const {
+        return kStatic ? uint32_t(StageWidth(S().cols[c].type)) : ReadLane32(tColStageW, c);
+    }
+    __device__ __forceinline__ uint32_t ColCharsLds(int c) const {
+        if (!kStatic) return ReadLane32(tColCharsLds, c);
+        return S().lds_chars_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_chars_off[c]) + uint32_t(waveBase / (64 * U)) * uint32_t(kCharsStageBytes);
+    }
+    __device__ __forceinline__ uint32_t RegOff(int r) const { return kStatic ? uint32_t(S().lds_reg_offs[r]) : ReadLane32(tRegOff, r); }
+    __device__ __forceinline__ uint64_t ConstBits(int k) const { return kStatic ? S().consts[k].bits : ReadLane64(tConstBits, k); }
+    __device__ __forceinline__ uint32_t ConstValid(int k) const { return kStatic ? uint32_t(S().consts[k].valid) : ReadLane32(tConstValid, k); }
+    __device__ __forceinline__ int NumCode() const { return kStatic ? S().ncode : ncode; }
+    __device__ __forceinline__ int NumCols() const { return kStatic ? S().ncols : ncols; }
 
     __device__ __forceinline__ int64_t Row(int u) const { return row0 + int64_t(u) * 64; }
     // index of the lane's u-th row inside the tile (staged columns, R registers)
@@ -252,11 +295,12 @@ struct Machine {
         const int64_t slice0 = tileBase + waveBase;  // first row of the wave's slice
         // the wave's own LDS traffic of the previous tile (register stores included) has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(a.debug_flags & 1)) {
-            for (int c = 0; c < ncols; ++c) {
-                const int off = int(ReadLane32(tColOff, c));
+        if (!(S().debug_flags & 1)) {
+            SSA_UNROLL_STATIC
+            for (int c = 0; c < NumCols(); ++c) {
+                const int off = int(ColOff(c));
                 if (off < 0) continue;
-                const int w = int(ReadLane32(tColStageW, c));
+                const int w = int(ColStageW(c));
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(ReadLane64(tColVal, c)) + slice0 * w;
                 const int sliceBytes = 64 * U * w;
                 for (int chunk = 0; chunk < sliceBytes; chunk += 1024) {
@@ -278,12 +322,13 @@ struct Machine {
         const int lane = threadIdx.x & 63;
         charsPending = false;
         const int64_t last = (slice0 + 64 * U <= nrows ? slice0 + 64 * U : nrows) - 1;  // last row of the slice
-        for (int c = 0; c < ncols; ++c) {
-            const uint32_t area = ReadLane32(tColCharsLds, c);
+        SSA_UNROLL_STATIC
+        for (int c = 0; c < NumCols(); ++c) {
+            const uint32_t area = ColCharsLds(c);
             if (area == 0xFFFFFFFFu) continue;
             uint32_t begin = 0, bytes = 0, skew = 0;
             if (last >= slice0) {
-                const int32_t* l = reinterpret_cast<const int32_t*>(gLds + int(ReadLane32(tColOff, c)));
+                const int32_t* l = reinterpret_cast<const int32_t*>(gLds + int(ColOff(c)));
                 const uint32_t b0 = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase]));
                 const uint32_t bl = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase + int(last - slice0)]));
                 const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
@@ -333,10 +378,10 @@ struct Machine {
     }
 
     __device__ __forceinline__ void FetchCol(int c, Val<U>& out) {
-        const int type = int(ReadLane32(tColType, c));
-        const int w = int(ReadLane32(tColW, c));
+        const int type = int(ColType(c));
+        const int w = int(ColW(c));
         if (w > 0 && w <= 8) {
-            const int off = int(ReadLane32(tColOff, c));
+            const int off = int(ColOff(c));
             if (off >= 0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) out.v[u] = LdsLoadRaw(gLds + off, w, Idx(u));
@@ -362,24 +407,24 @@ struct Machine {
     // R registers live in LDS: a lane owns elements Idx(u) of every register, so no
     // barrier is needed between a store and a later fetch.
     __device__ __forceinline__ void FetchReg(int r, Val<U>& out) {
-        const uint64_t* vals = reinterpret_cast<const uint64_t*>(gLds + ReadLane32(tRegOff, r));
+        const uint64_t* vals = reinterpret_cast<const uint64_t*>(gLds + RegOff(r));
 #pragma unroll
         for (int u = 0; u < U; ++u) out.v[u] = vals[Idx(u)];
-        out.ok = (gLds + a.lds_regok_off)[r * kBlock + threadIdx.x];
+        out.ok = (gLds + S().lds_regok_off)[r * kBlock + threadIdx.x];
     }
 
     __device__ __forceinline__ void StoreReg(int r, const Val<U>& in) {
-        uint64_t* vals = reinterpret_cast<uint64_t*>(gLds + ReadLane32(tRegOff, r));
+        uint64_t* vals = reinterpret_cast<uint64_t*>(gLds + RegOff(r));
 #pragma unroll
         for (int u = 0; u < U; ++u) vals[Idx(u)] = in.v[u];
-        (gLds + a.lds_regok_off)[r * kBlock + threadIdx.x] = uint8_t(in.ok);
+        (gLds + S().lds_regok_off)[r * kBlock + threadIdx.x] = uint8_t(in.ok);
     }
 
     __device__ __forceinline__ void FetchConst(int k, Val<U>& out) {
-        const uint64_t bits = ReadLane64(tConstBits, k);
+        const uint64_t bits = ConstBits(k);
 #pragma unroll
         for (int u = 0; u < U; ++u) out.v[u] = bits;
-        out.ok = ReadLane32(tConstValid, k) ? AllMask<U>() : 0u;
+        out.ok = ConstValid(k) ? AllMask<U>() : 0u;
     }
 
     __device__ __forceinline__ void Fetch(int sk, int si, Val<U>& out) {
@@ -398,7 +443,7 @@ struct Machine {
     __device__ __forceinline__ void StringAt(int c, int u, const uint8_t*& p, int32_t& n) const {
         const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, c));
         const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
-        const int off = int(ReadLane32(tColOff, c));
+        const int off = int(ColOff(c));
         const int64_t row = Row(u);
         int32_t b, e;
         if (off >= 0) {
@@ -427,7 +472,7 @@ struct Machine {
         const int32_t m = n < 8 ? n : 8;
         if (staged != 0 && rel >= 0 && rel + m <= int64_t(staged)) {
             // from the wave's head area in LDS (WaitStringHeads() has been called)
-            const uint8_t* l = gLds + ReadLane32(tColCharsLds, c) + ReadLane32(tCharsSkew, c) + rel;
+            const uint8_t* l = gLds + ColCharsLds(c) + ReadLane32(tCharsSkew, c) + rel;
             for (int32_t j = 0; j < m; ++j) w |= uint64_t(l[j]) << (8 * j);
             return w;
         }
@@ -510,10 +555,11 @@ struct Machine {
 #pragma unroll
         for (int u = 0; u < U; ++u) A.v[u] = 0;
 
-        const int ncodeEff = (a.debug_flags & 2) ? 0 : ncode;
+        const int ncodeEff = (S().debug_flags & 2) ? 0 : NumCode();
+        SSA_UNROLL_STATIC
         for (int pc = 0; pc < ncodeEff; ++pc) {
-            const uint32_t w0 = ReadLane32(tCode0, pc);
-            const uint32_t w1 = ReadLane32(tCode1, pc);
+            const uint32_t w0 = Code0(pc);
+            const uint32_t w1 = Code1(pc);
             const uint32_t ok = w0 & 0xFFu, fk = (w0 >> 8) & 0xFFu;
             const int fa = int((w0 >> 16) & 0xFFu), fb = int(w0 >> 24);
             Val<U> B;
@@ -527,7 +573,7 @@ struct Machine {
                     break;
                 case OK_PREDCMP: {  // B = column, constant fa, class fb >> 4, mask fb & 15
                     uint64_t c[U];
-                    const uint64_t cbits = ReadLane64(tConstBits, fa);
+                    const uint64_t cbits = ConstBits(fa);
 #pragma unroll
                     for (int u = 0; u < U; ++u) c[u] = cbits;
                     P &= CompareByMask(fb >> 4, uint32_t(fb & 15), B.v, c);
@@ -583,7 +629,7 @@ struct Machine {
                     break;
                 }
                 default: {
-                    const uint32_t w2 = ReadLane32(tCode2, pc);
+                    const uint32_t w2 = Code2(pc);
                     GenericOp(InsnOp(w2), InsnSi(w2), InsnA(w2), InsnB(w2), B);
                     break;
                 }
@@ -743,10 +789,10 @@ struct Machine {
             break;
         }
         case OP_STRMATCH: {
-            const uint64_t pat = ReadLane64(tConstBits, fa);
-            const uint8_t* pp = a.pattern + uint32_t(pat >> 32);
+            const uint64_t pat = ConstBits(fa);
+            const uint8_t* pp = S().pattern + uint32_t(pat >> 32);
             const int32_t pn = int32_t(uint32_t(pat));
-            A.ok = ValidityOf(si) & (ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u);
+            A.ok = ValidityOf(si) & (ConstValid(fa) ? AllMask<U>() : 0u);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint64_t m = 0;
@@ -766,10 +812,10 @@ struct Machine {
             const uint8_t* pp = nullptr;
             int32_t pn = 0;
             if (!rhsCol) {
-                const uint64_t pat = ReadLane64(tConstBits, fa);
-                pp = a.pattern + uint32_t(pat >> 32);
+                const uint64_t pat = ConstBits(fa);
+                pp = S().pattern + uint32_t(pat >> 32);
                 pn = int32_t(uint32_t(pat));
-                ok &= ReadLane32(tConstValid, fa) ? AllMask<U>() : 0u;
+                ok &= ConstValid(fa) ? AllMask<U>() : 0u;
             } else {
                 ok &= ValidityOf(fa);
             }
@@ -809,12 +855,6 @@ struct Machine {
 // wave-uniform program counter, which the compiler can only turn into scalar loads if the struct is
 // read in place from the kernel-argument segment (a by-value aggregate that is indexed dynamically
 // would otherwise be copied to per-lane scratch memory).
-template <class Sink>
-struct KArgs {
-    ScanArgs a;
-    Sink s;
-};
-
 template <class T>
 __device__ __forceinline__ const T& KernArgsAs() {
 #if defined(__HIP_DEVICE_COMPILE__)

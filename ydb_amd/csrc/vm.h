@@ -8,13 +8,36 @@
 // predicate, and leaves the aggregate arguments / group-by keys / projected values in
 // "output registers" which the kernel's sink consumes.  Intermediates never touch HBM.
 #pragma once
+#if defined(__HIPCC_RTC__)
+// built at run time: the compiler brings the HIP runtime declarations and the fixed-width integer types with it
+#define SSA_HD __host__ __device__ __forceinline__
+typedef signed char int8_t;
+typedef short int16_t;
+typedef int int32_t;
+typedef long int64_t;
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long uint64_t;
+typedef unsigned long uintptr_t;
+typedef unsigned long size_t;
+#ifndef INT64_MAX
+#define INT64_MAX 9223372036854775807LL
+#endif
+#ifndef INT64_MIN
+#define INT64_MIN (-9223372036854775807LL - 1)
+#endif
+#ifndef INT32_MAX
+#define INT32_MAX 2147483647
+#endif
+#else
 #include <stdint.h>
-
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SSA_HD __host__ __device__ __forceinline__
 #else
 #define SSA_HD inline
+#endif
 #endif
 
 namespace ssa {
