@@ -133,6 +133,13 @@ void ssa_batch_destroy(ssa_batch_t* batch);
 void ssa_profile_enable(ssa_program_t* program, int enabled);
 void ssa_profile_read(ssa_program_t* program, double* scan_ms, int64_t* launches, int64_t* algorithmic_bytes);
 
+/* Scan kernels built at run time for one step program (no counterpart in the reference's C++ executor; the
+ * reference compiles MiniKQL graphs with LLVM in ydb/library/yql/minikql/codegen).  A step program whose scans add
+ * up to 2^25 rows gets its scan kernel compiled for it through hiprtc: the generic kernel's source with the
+ * program's tables as constants.  Environment SSA_JIT=0 turns this off, SSA_JIT=1 builds at the first scan.  The
+ * counters are process-wide: kernels built, host milliseconds spent building, launches that ran such a kernel. */
+void ssa_specialization_stats(int64_t* kernels_built, double* build_ms, int64_t* launches);
+
 /* ---- synthetic TPC-H lineitem generated in HBM (benchmark / parity input) ----------------------------------- */
 
 /* Fills caller-provided device arrays with rows [row0, row0 + nrows) of the deterministic synthetic lineitem

@@ -1,0 +1,127 @@
+"""Scan kernels built at run time for one step program (ydb_amd/csrc/jit.h): the same checks as the generic kernels
+pass, against the oracle, when every scan is forced through a kernel compiled for its program (SSA_JIT=1); the
+policy counters move as documented; SSA_JIT=0 keeps everything on the generic kernels."""
+import os
+
+import numpy as np
+import pytest
+
+import test_gpu_parity as P
+from cases import compare_batches
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats():
+    from ydb_amd.program import ProgramContainer
+    return ProgramContainer().SpecializationStats()
+
+
+@pytest.fixture
+def forced(monkeypatch):
+    monkeypatch.setenv("SSA_JIT", "1")
+    before = _stats()
+    yield before
+    after = _stats()
+    assert after[2] > before[2], "no launch used a kernel built for its program"
+
+
+@pytest.mark.parametrize("n", [1, 1025, 100_003])
+@pytest.mark.parametrize("nulls", [0.0, 0.1])
+def test_keyless_aggregation(forced, n, nulls):
+    P.test_filter_sum_nokeys(n, nulls)
+
+
+@pytest.mark.parametrize("n", [1, 4097, 100_003])
+@pytest.mark.parametrize("nulls", [0.0, 0.1])
+def test_group_by_small_keys(forced, n, nulls):
+    P.test_filter_group_by_small_keys(n, nulls)
+
+
+def test_group_by_single_byte_key(forced):
+    P.test_group_by_single_byte_key_ignores_argument_nulls(50_000)
+
+
+@pytest.mark.parametrize("n", [5, 70_000])
+def test_group_by_string_keys(forced, n):
+    P.test_group_by_string_keys(n)
+
+
+def test_group_by_long_and_null_strings(forced):
+    P.test_group_by_long_and_null_strings()
+
+
+def test_group_by_high_cardinality(forced):
+    P.test_group_by_high_cardinality(200_000)
+
+
+def test_projection_with_filter_and_strings(forced):
+    P.test_projection_with_filter_and_strings(70_001)
+
+
+def test_multi_step_program(forced):
+    P.test_multi_step_program()
+
+
+def test_errors_match(forced):
+    P.test_errors_match()
+
+
+def test_tpch_q1_and_q6_on_the_generated_lineitem(forced):
+    from oracle import ssa_oracle
+    from ydb_amd import tpch
+    from ydb_amd.program import ProgramContainer
+    n = 500_000
+    li = tpch.DeviceLineitem(n)
+    host = tpch.lineitem_host(0, n)
+    for prog, cols, keys, sums in (
+            (tpch.q1_program(True), tpch.Q1_COLUMNS_CODES, tpch.Q1_COLUMNS_CODES[-2:], ["130", "131", "132", "133", "136"]),
+            (tpch.q1_program(False), tpch.Q1_COLUMNS_UTF8, tpch.Q1_COLUMNS_UTF8[-2:], ["130", "131", "132", "133", "136"]),
+            (tpch.q6_program(), tpch.Q6_COLUMNS, [], None)):
+        pc = ProgramContainer()
+        ok, err = pc.Init(tpch.LINEITEM_RESOLVER, prog)
+        assert ok, err
+        got = pc.Export(pc.ApplyDevice(li.batch(cols)))
+        exp = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply({c: host[c] for c in cols})
+        if sums is None:
+            sums = list(got.keys())
+        compare_batches(got, exp, key_names=keys, float_sum_names=sums, rtol=1e-11)
+
+
+def test_a_kernel_is_built_once_per_program(monkeypatch):
+    monkeypatch.setenv("SSA_JIT", "1")
+    rng = np.random.default_rng(7)
+    batch = P.lineitem_like(rng, 5000)
+    # a program no other test uses (its constant is part of the kernel)
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
+    p = (Program().assign_const(100, "Int32", 10463).assign_func(110, F.CMP_LESS_EQUAL, [1, 100]).filter(110)
+         .group_by([Aggregate(130, AGG.SUM, [3]), Aggregate(131, AGG.COUNT, [])]))
+    pc = ProgramContainer()
+    ok, err = pc.Init(P.LI, p)
+    assert ok, err
+    b0 = _stats()
+    pc.ApplyProgram(batch)
+    b1 = _stats()
+    pc.ApplyProgram(batch)
+    b2 = _stats()
+    assert b1[0] == b0[0] + 1 and b1[1] > b0[1]
+    assert b2[0] == b1[0] and b2[2] == b1[2] + 1
+
+
+def test_small_scans_and_ssa_jit_0_stay_on_the_generic_kernels(monkeypatch):
+    from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
+    rng = np.random.default_rng(8)
+    batch = P.lineitem_like(rng, 5000)
+    # a program no other test uses: a kernel that exists already is used whatever the size of the scan
+    p = (Program().assign_const(100, "Int32", 10464).assign_func(110, F.CMP_LESS_EQUAL, [1, 100]).filter(110)
+         .group_by([Aggregate(130, AGG.SUM, [3]), Aggregate(131, AGG.COUNT, [])]))
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("SSA_JIT", raising=False)
+        else:
+            monkeypatch.setenv("SSA_JIT", mode)
+        before = _stats()
+        got, exp = P.both(P.LI, p, batch)
+        compare_batches(got, exp, float_sum_names=["130"])
+        assert _stats() == before

@@ -9,6 +9,7 @@
 
 #include "../../include/ydb_ssa_hip.h"
 #include "exec.h"
+#include "jit.h"
 #include "program.h"
 #include "vm_ops.h"
 
@@ -311,6 +312,15 @@ void ssa_profile_enable(ssa_program_t* program, int enabled) {
     std::lock_guard<std::mutex> g(program->Lock);
     if (!EnsureExecutor(program).ok()) return;
     program->Exec->Profile.Enabled = enabled != 0;
+}
+
+void ssa_specialization_stats(int64_t* kernels_built, double* build_ms, int64_t* launches) {
+    int64_t built = 0, n = 0;
+    double ms = 0;
+    ssa::KernelJit::Instance().Stats(built, ms, n);
+    if (kernels_built) *kernels_built = built;
+    if (build_ms) *build_ms = ms;
+    if (launches) *launches = n;
 }
 
 void ssa_profile_read(ssa_program_t* program, double* scan_ms, int64_t* launches, int64_t* algorithmic_bytes) {

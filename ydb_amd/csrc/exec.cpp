@@ -804,12 +804,13 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
     SpecKernel k;
     std::string why;
     const auto t0 = std::chrono::steady_clock::now();
-    const bool got = KernelJit::Instance().Get(Device, header, entry, image.data(), image.size() * 4, defines, cfg.lds_bytes, k, why);
+    const bool got = KernelJit::Instance().Get(Device, header, entry, image.data(), image.size() * 4, defines, cfg.lds_bytes, rows, k, why);
     if (std::getenv("SSA_DEBUG_PLAN")) {
         std::fprintf(stderr, "specialised %s: %s, %.1f ms, %d workgroups per CU\n", entry, got ? "ok" : "none",
                      1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), k.BlocksPerCU);
     }
     if (!got) {
+        if (why.empty()) return nullptr;  // not enough rows yet
         static std::mutex lock;
         static std::set<std::string> told;
         std::lock_guard<std::mutex> g(lock);
@@ -830,6 +831,7 @@ hipError_t Executor::LaunchSpecialized(hipFunction_t fn, const ScanArgs& args, c
     std::memcpy(kargs.data() + sizeof(ScanArgs), sink, sinkBytes);
     size_t bytes = kargs.size();
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, kargs.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    KernelJit::Instance().NoteLaunch();
     return hipModuleLaunchKernel(fn, unsigned(cfg.grid), 1, 1, kBlock, 1, 1, cfg.lds_bytes, cfg.stream, nullptr, extra);
 }
 
@@ -971,8 +973,18 @@ Status Executor::RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, Bu
     SSA_RETURN_NOT_OK(FillScanArgs(filterPlan, in, 0, SCAN_FILTER, args, cfg, algoBytes));
     FilterSink sink{static_cast<uint64_t*>(bitmap->Ptr), static_cast<uint32_t*>(tileCounts->Ptr)};
     if (rows > 0) {
+        hipFunction_t spec = nullptr;
+        if (JitEnabled()) {
+            const FilterSink image{};  // the sink holds addresses only
+            const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n";
+            spec = SpecializedKernel("filter_project_scan.h", "ssa_spec_filter", defines, args, &image, sizeof(image), rows, cfg);
+        }
         ProfileBegin();
-        SSA_HIP(LaunchScanFilter(args, sink, cfg));
+        if (spec) {
+            SSA_HIP(LaunchSpecialized(spec, args, &sink, sizeof(sink), cfg));
+        } else {
+            SSA_HIP(LaunchScanFilter(args, sink, cfg));
+        }
         ProfileEnd("ScanFilterKernel", algoBytes);
     }
     SSA_HIP(LaunchTileScan(static_cast<const uint32_t*>(tileCounts->Ptr), ntiles, static_cast<int64_t*>(tileOffsets->Ptr),
@@ -998,7 +1010,7 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
     }
     // a scan of many rows runs the kernel built for this step program, when that can be had
     hipFunction_t spec = nullptr;
-    if (JitWanted(in.Rows)) {
+    if (JitEnabled()) {
         const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n";
         spec = SpecializedKernel("nokey_scan.h", "ssa_spec_nokey", defines, args, &sink, sizeof(sink), in.Rows, cfg);
     }
@@ -1132,8 +1144,24 @@ Status Executor::RunProject(const TProgramStep& step, const StepPlan& plan, cons
             }
         }
         if (rows > 0) {
+            hipFunction_t spec = nullptr;
+            if (JitEnabled()) {
+                ProjectSink image = sink;
+                image.bitmap = nullptr;
+                image.tile_offsets = nullptr;
+                for (int k = 0; k < kMaxOuts; ++k) {
+                    image.outs[k].values = nullptr;
+                    image.outs[k].valid_bytes = nullptr;
+                }
+                const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n";
+                spec = SpecializedKernel("filter_project_scan.h", "ssa_spec_project", defines, args, &image, sizeof(image), rows, cfg);
+            }
             ProfileBegin();
-            SSA_HIP(LaunchScanProject(args, sink, cfg));
+            if (spec) {
+                SSA_HIP(LaunchSpecialized(spec, args, &sink, sizeof(sink), cfg));
+            } else {
+                SSA_HIP(LaunchScanProject(args, sink, cfg));
+            }
             ProfileEnd("ScanProjectKernel", algoBytes);
         }
         for (size_t k = 0; k < regOuts.size(); ++k) {
@@ -1388,7 +1416,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             // a scan of many rows runs the kernel built for this step program, when that can be had
             hipFunction_t spec = nullptr;
             LaunchCfg specCfg = cfg;
-            if (JitWanted(in.Rows)) {
+            if (JitEnabled()) {
                 KeyedSink image = sink;
                 image.t_key_lo = image.t_key_hi = image.t_acc = nullptr;
                 image.t_seen = nullptr;

@@ -5,6 +5,7 @@
 #include <hip/hiprtc.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,7 +82,9 @@ struct State {
     std::map<std::pair<int, uint64_t>, hipFunction_t> Functions;  // (device, key) -> kernel; modules are never unloaded
     std::map<uint64_t, std::vector<char>> Code;                   // key -> code object (shared by the devices)
     std::map<uint64_t, std::string> Failed;                       // key -> reason (not retried)
-    std::atomic<int64_t> Compiled{0};
+    std::map<uint64_t, int64_t> SeenRows;                         // key -> rows of the scans that asked so far
+    std::atomic<int64_t> Compiled{0}, Launches{0}, BuildMicros{0};
+    std::map<int, std::string> Arch;  // device -> target name
 };
 
 State& St() {
@@ -96,25 +99,32 @@ KernelJit& KernelJit::Instance() {
     return j;
 }
 
-int64_t KernelJit::Compiled() const { return St().Compiled.load(); }
+void KernelJit::Stats(int64_t& built, double& buildMs, int64_t& launches) const {
+    built = St().Compiled.load();
+    buildMs = double(St().BuildMicros.load()) / 1e3;
+    launches = St().Launches.load();
+}
 
-bool JitWanted(int64_t rows) {
+void KernelJit::NoteLaunch() { ++St().Launches; }
+
+bool JitEnabled() {
     const char* mode = std::getenv("SSA_JIT");
-    if (mode && mode[0] == '0') return false;
-    if (mode && mode[0] == '1') return true;
-    return rows >= kJitMinRows;
+    return !(mode && mode[0] == '0');
 }
 
 bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const void* image, size_t imageBytes,
-                    const std::string& defines, uint32_t ldsBytes, SpecKernel& out, std::string& why) {
+                    const std::string& defines, uint32_t ldsBytes, int64_t rows, SpecKernel& out, std::string& why) {
     State& st = St();
     std::lock_guard<std::mutex> g(st.Lock);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
-        why = "no device properties";
-        return false;
+    std::string& arch = st.Arch[device];
+    if (arch.empty()) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+            why = "no device properties";
+            return false;
+        }
+        arch = prop.gcnArchName;
     }
-    const std::string arch = prop.gcnArchName;
     uint64_t key = Fnv(mainHeader, std::strlen(mainHeader));
     key = Fnv(entry, std::strlen(entry), key);
     key = Fnv(defines.data(), defines.size(), key);
@@ -129,6 +139,13 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
         auto bad = st.Failed.find(key);
         if (bad != st.Failed.end()) {
             why = bad->second;
+            return false;
+        }
+        const char* mode = std::getenv("SSA_JIT");
+        int64_t& seen = st.SeenRows[key];
+        seen += rows;
+        if (!(mode && mode[0] == '1') && seen < kJitMinRows) {
+            why.clear();
             return false;
         }
         auto have = st.Code.find(key);
@@ -155,6 +172,7 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
                 st.Failed[key] = why;
                 return false;
             }
+            const auto t0 = std::chrono::steady_clock::now();
             const std::string archOpt = "--offload-arch=" + arch;
             const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm"};
             const hiprtcResult rc = st.R.CompileProgram(prog, int(sizeof(opts) / sizeof(opts[0])), opts);
@@ -174,6 +192,7 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
             if (n) (void)st.R.GetCode(prog, code.data());
             (void)st.R.DestroyProgram(&prog);
             ++st.Compiled;
+            st.BuildMicros += int64_t(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
             have = st.Code.emplace(key, std::move(code)).first;
         }
         (void)hipSetDevice(device);

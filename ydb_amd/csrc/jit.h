@@ -26,21 +26,25 @@ public:
     static KernelJit& Instance();
 
     // Kernel `entry` of the translation unit `mainHeader` (one of the embedded kernel headers) built for the constant
-    // image `image` (imageBytes, a multiple of 4) and the given defines (e.g. "#define SSA_SPEC_U 4\n").
-    // Returns false when run-time compilation is unavailable or failed; `why` then says what happened.
+    // image `image` (imageBytes, a multiple of 4) and the given defines (e.g. "#define SSA_SPEC_U 4\n").  `rows` is the
+    // size of the scan about to run: a kernel is built once the scans asking for it add up to kJitMinRows rows
+    // (SSA_JIT=1: at the first one).  Returns false when there is no such kernel (yet); `why` is empty when that is
+    // only the policy, else it says what failed.
     bool Get(int device, const char* mainHeader, const char* entry, const void* image, size_t imageBytes,
-             const std::string& defines, uint32_t ldsBytes, SpecKernel& out, std::string& why);
+             const std::string& defines, uint32_t ldsBytes, int64_t rows, SpecKernel& out, std::string& why);
 
-    // Number of kernels compiled so far; for tests and logs.
-    int64_t Compiled() const;
+    // Process-wide counters: kernels built, host milliseconds spent building them, launches that used one.
+    void Stats(int64_t& built, double& buildMs, int64_t& launches) const;
+    void NoteLaunch();
 
 private:
     KernelJit() = default;
 };
 
-// Policy knob, read from SSA_JIT at every call: "0" never, "1" always, otherwise specialise scans of at least
-// kJitMinRows rows.
-constexpr int64_t kJitMinRows = int64_t(1) << 23;
-bool JitWanted(int64_t rows);
+// Building a kernel takes about half a second of host time, as much as the generic kernels need for tens of billions
+// of rows: it pays for step programs that keep coming back (every portion of a table, every run of a dashboard query).
+constexpr int64_t kJitMinRows = int64_t(1) << 25;
+// SSA_JIT, read at every call: "0" never specialise, "1" at the first scan, otherwise by the row count above.
+bool JitEnabled();
 
 }  // namespace ssa

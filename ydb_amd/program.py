@@ -173,6 +173,12 @@ class ProgramContainer:
         self._lib.ssa_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b))
         return ms.value, n.value, b.value
 
+    def SpecializationStats(self) -> Tuple[int, float, int]:
+        """Process-wide: scan kernels built at run time, host milliseconds spent building, launches that ran one."""
+        built, ms, n = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_int64(0)
+        self._lib.ssa_specialization_stats(ctypes.byref(built), ctypes.byref(ms), ctypes.byref(n))
+        return built.value, ms.value, n.value
+
     def close(self):
         if self._h:
             self._lib.ssa_program_destroy(self._h)
