@@ -620,9 +620,14 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
         args.lds_col_off[c] = -1;
         const int w = TypeWidth(col.Field.Type);
         const int sw = StageWidth(col.Field.Type);  // strings: their int32 offsets
+        args.lds_end_off[c] = -1;
         if (sw >= 1 && (reinterpret_cast<uintptr_t>(d.values) & 15) == 0 && lds + kTileRows * sw <= kLdsStageBudget) {
             args.lds_col_off[c] = lds;
             lds += kTileRows * sw;
+            if (IsStringLike(col.Field.Type)) {  // per-wave slots for the end offset of each wave's last row
+                args.lds_end_off[c] = lds;
+                lds += (kBlock / 64) * 16;
+            }
         }
         // algorithmic bytes: every referenced source column once
         if (IsStringLike(col.Field.Type)) {
@@ -706,7 +711,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
         for (size_t n = 1; n <= cand.size(); ++n) {
             dropped += kTileRows * StageWidth(args.cols[cand[n - 1]].type);
             if (blocksPerCU(totalLds(lds - dropped)) > base) {
-                for (size_t j = 0; j < n; ++j) args.lds_col_off[cand[j]] = -1;
+                for (size_t j = 0; j < n; ++j) args.lds_col_off[cand[j]] = -1, args.lds_end_off[cand[j]] = -1;
                 break;
             }
         }
@@ -716,6 +721,10 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
             if (args.lds_col_off[c] < 0) continue;
             args.lds_col_off[c] = lds;
             lds += kTileRows * StageWidth(args.cols[c].type);
+            if (args.lds_end_off[c] >= 0) {
+                args.lds_end_off[c] = lds;
+                lds += (kBlock / 64) * 16;
+            }
         }
     }
     for (int r = 0; r < kMaxRegs; ++r) args.lds_reg_offs[r] = 0;
@@ -820,7 +829,8 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
         return nullptr;
     }
     const int64_t ntiles = (rows + kTileRows - 1) / kTileRows;
-    const int perCU = std::max(1, std::min(4, k.BlocksPerCU));
+    int perCU = std::max(1, std::min(4, k.BlocksPerCU));
+    if (const char* pc = std::getenv("SSA_SPEC_BLOCKS_PER_CU")) perCU = std::max(1, std::min(8, std::atoi(pc)));  // experiments
     cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU));
     return k.Function;
 }
@@ -1422,8 +1432,9 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
                 image.t_seen = nullptr;
                 image.t_rep_row = nullptr;
                 image.table_mask = 0;
-                const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n#define SSA_SPEC_HASHED " +
-                                            (hashed ? "1" : "0") + "\n";
+                std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n#define SSA_SPEC_HASHED " +
+                                      (hashed ? "1" : "0") + "\n";
+                if (std::getenv("SSA_PHASE_TIMING")) defines += "#define SSA_PHASE_TIMING 1\n";  // diagnostics
                 spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, args, &image, sizeof(image), in.Rows, specCfg);
             }
             ProfileBegin();

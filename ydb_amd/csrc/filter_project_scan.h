@@ -22,7 +22,7 @@ __device__ __forceinline__ void ScanFilterBody() {
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t tileBase = tile * (kBlock * U);
-        m.BeginTile(tileBase);
+        m.BeginTile(tileBase, (tile + gridDim.x) * (kBlock * U));
         m.Run();
         uint32_t count = 0;
 #pragma unroll
@@ -85,7 +85,7 @@ __device__ __forceinline__ void ScanProjectBody() {
                 pos[u] = tileOff + before + __popcll(word & ((1ull << lane) - 1ull));
             }
         }
-        m.BeginTile(tileBase);
+        m.BeginTile(tileBase, (tile + gridDim.x) * (kBlock * U));
         if (rs.bitmap == nullptr) {
             sel = m.act;
 #pragma unroll

@@ -165,6 +165,12 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
             }
             src << "\n};\n#include \"" << mainHeader << "\"\n";
             const std::string text = src.str();
+            if (const char* dump = std::getenv("SSA_JIT_DUMP")) {  // diagnostics: the translation unit, for offline inspection
+                if (FILE* f = std::fopen(dump, "w")) {
+                    std::fwrite(text.data(), 1, text.size(), f);
+                    std::fclose(f);
+                }
+            }
             hiprtcProgram prog = nullptr;
             if (st.R.CreateProgram(&prog, text.c_str(), "ssa_spec.hip", kEmbeddedCount, const_cast<const char**>(kEmbeddedSources),
                                    const_cast<const char**>(kEmbeddedNames)) != HIPRTC_SUCCESS) {

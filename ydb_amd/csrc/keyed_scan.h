@@ -198,13 +198,13 @@ struct KeyBuilder {
         }
     }
     // exact packing at a per-row position (rows of a batch with string keys differ in length)
+    // (`bits` has nothing above its low `nbits` bits; written without branches: `at` differs from lane to lane)
     __device__ __forceinline__ void AppendAt(int u, uint64_t bits, uint32_t nbits, uint32_t& at) {
-        if (at < 64) {
-            lo[u] |= bits << at;
-            if (at > 0 && at + nbits > 64) hi[u] |= bits >> (64 - at);
-        } else if (at < 128) {
-            hi[u] |= bits << (at - 64);
-        }
+        const uint32_t sh = at & 63u;
+        const uint64_t low = bits << sh;
+        const uint64_t carry = sh ? bits >> (64u - sh) : 0ull;
+        lo[u] |= at < 64 ? low : 0ull;
+        hi[u] |= at < 64 ? carry : (at < 128 ? low : 0ull);
         at += nbits;
     }
     // hashed: absorb one 64-bit word into both lanes of the hash
@@ -375,7 +375,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         SSA_T(7);
-        m.BeginTile(tile * (kBlock * U));
+        m.BeginTile(tile * (kBlock * U), (tile + gridDim.x) * (kBlock * U));
         SSA_T(0);
         m.Run();
         SSA_T(1);
@@ -402,26 +402,17 @@ __device__ __forceinline__ void ScanKeyedBody() {
             if (kHashed && ks.col >= 0) {
                 // string key; the validity of the column is not part of these keys.  The loads of the lane's rows are
                 // issued together, then consumed.
-                const uint8_t* p[U];
                 int32_t n[U];
                 uint64_t w[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    p[u] = nullptr;
-                    n[u] = 0;
-                    if ((m.P >> u) & 1u) m.StringAt(ks.col, u, p[u], n[u]);
-                }
                 m.WaitStringHeads();
 #pragma unroll
-                for (int u = 0; u < U; ++u) w[u] = m.StringHead(ks.col, p[u], n[u]);
+                for (int u = 0; u < U; ++u) m.StringKeyWord(ks.col, u, ((m.P >> u) & 1u) != 0, n[u], w[u]);
+                // (no branches: the key words of rows that fail the predicate are never used, those of rows with a
+                // longer string are replaced by the hash below)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (!((m.P >> u) & 1u)) continue;
-                    if (n[u] > 8) {
-                        toHash |= 1u << u;
-                        continue;
-                    }
-                    kb.AppendAt(u, uint64_t(uint32_t(n[u])), 8, at[u]);
+                    toHash |= (n[u] > 8 ? 1u : 0u) << u;
+                    kb.AppendAt(u, uint64_t(uint32_t(n[u]) & 0xFFu), 8, at[u]);
                     kb.AppendAt(u, w[u], uint32_t(8 * n[u]), at[u]);
                 }
                 continue;
@@ -726,8 +717,9 @@ extern "C" __global__ __launch_bounds__(ssa::kBlock) void ssa_spec_keyed(const s
 }
 namespace ssa {
 #else
+// Two waves per SIMD at least: the register allocator has to stay within 256 VGPRs.
 template <int U, bool kHashed>
-__global__ __launch_bounds__(kBlock) void ScanKeyedKernel(const KArgs<KeyedSink>) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void ScanKeyedKernel(const KArgs<KeyedSink>) {
     ScanKeyedBody<U, kHashed>();
 }
 #endif

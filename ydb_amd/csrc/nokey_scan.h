@@ -70,7 +70,7 @@ __device__ __forceinline__ void ScanNoKeyBody() {
 
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        m.BeginTile(tile * (kBlock * U));
+        m.BeginTile(tile * (kBlock * U), (tile + gridDim.x) * (kBlock * U));
         m.Run();
         if (m.P == 0) continue;
         SSA_UNROLL_STATIC

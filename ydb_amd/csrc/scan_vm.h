@@ -206,11 +206,17 @@ struct Machine {
     uint32_t tConstValid;
     uint32_t tColStageW;                     // column slot: bytes per row of the staged buffer
     uint32_t tColCharsLds;                   // column slot: LDS offset of this wave's string-head area, or -1
+    uint32_t tColEndOff;                     // column slot: LDS offset of this wave's end-offset slot (staged string columns), or -1
     // string heads staged for the current tile, per column slot (lane c): first staged byte (offset inside the
     // column's chars) and number of staged bytes; 0 bytes = not staged
     uint32_t tCharsBegin, tCharsBytes, tCharsSkew;
     int waveBase;                            // first tile row of this wave: wave * 64 * U
     bool charsPending;                       // a string-head copy of this tile has been issued and not yet awaited
+    // String heads one tile ahead: lane c holds, for string column c, the offsets of the first and the last row of the
+    // wave's slice of tile `boundsTile`, read from memory while the previous tile was evaluated.  With them the head
+    // copy of a tile is issued together with its columns -- one memory round trip per tile instead of two.
+    uint32_t boundsFirst, boundsLast;
+    int64_t boundsTile;
     bool anyCharsStage;                      // some string column has a head area
     int ncols;
     int64_t nrows;
@@ -240,11 +246,20 @@ struct Machine {
         tColStageW = uint32_t(StageWidth(a.cols[c].type));
         tColCharsLds = a.lds_chars_off[c] < 0 ? 0xFFFFFFFFu
                                               : uint32_t(a.lds_chars_off[c]) + (threadIdx.x >> 6) * uint32_t(kCharsStageBytes);
+        tColEndOff = a.lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(a.lds_end_off[c]) + (threadIdx.x >> 6) * 16u;
+        boundsFirst = boundsLast = 0;
+        boundsTile = -1;
         tCharsBegin = tCharsBytes = tCharsSkew = 0;
         anyCharsStage = false;
         SSA_UNROLL_STATIC
         for (int col = 0; col < S().ncols; ++col) anyCharsStage = anyCharsStage || S().lds_chars_off[col] >= 0;
         charsPending = false;
+        // The tables above come from memory.  Using them here makes the compiler wait for those loads now: left pending,
+        // its wait lands before their first use inside the tile loop -- between the copies of a tile, which it would
+        // serialise (the explicit waits of BeginTile are invisible to it).
+        asm volatile("" ::"v"(tColOff), "v"(tColType), "v"(tColValBit), "v"(tColValidBit), "v"(tColCharsBytes), "v"(tColVal),
+                     "v"(tColValid), "v"(tColChars), "v"(tRegOff), "v"(tConstBits), "v"(tConstValid), "v"(tColCharsLds), "v"(tColEndOff),
+                     "v"(tCode0), "v"(tCode1), "v"(tCode2));
         waveBase = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)) * (64 * U);
         ncols = a.ncols;
     }
@@ -270,6 +285,10 @@ struct Machine {
         if (!kStatic) return ReadLane32(tColCharsLds, c);
         return S().lds_chars_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_chars_off[c]) + uint32_t(waveBase / (64 * U)) * uint32_t(kCharsStageBytes);
     }
+    __device__ __forceinline__ uint32_t ColEndOff(int c) const {
+        if (!kStatic) return ReadLane32(tColEndOff, c);
+        return S().lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_end_off[c]) + uint32_t(waveBase / (64 * U)) * 16u;
+    }
     __device__ __forceinline__ uint32_t RegOff(int r) const { return kStatic ? uint32_t(S().lds_reg_offs[r]) : ReadLane32(tRegOff, r); }
     __device__ __forceinline__ uint64_t ConstBits(int k) const { return kStatic ? S().consts[k].bits : ReadLane64(tConstBits, k); }
     __device__ __forceinline__ uint32_t ConstValid(int k) const { return kStatic ? uint32_t(S().consts[k].valid) : ReadLane32(tConstValid, k); }
@@ -285,7 +304,8 @@ struct Machine {
     // loads, and later reads, only its own 64 * U rows, so a vmcnt(0) of its own is all the ordering needed.  In the
     // last, partial tile the lanes whose 16-byte chunk starts past the end of the column issue nothing (those rows are
     // inactive); a chunk that straddles the end reads at most 15 bytes of the allocation's tail padding.
-    __device__ __forceinline__ void BeginTile(int64_t tileBase) {
+    // `nextBase`: the tile this workgroup evaluates after this one (any value >= nrows when there is none).
+    __device__ __forceinline__ void BeginTile(int64_t tileBase, int64_t nextBase) {
         const int lane = threadIdx.x & 63;
         row0 = tileBase + waveBase + lane;
         act = 0;
@@ -295,6 +315,17 @@ struct Machine {
         const int64_t slice0 = tileBase + waveBase;  // first row of the wave's slice
         // the wave's own LDS traffic of the previous tile (register stores included) has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // slice bounds of the next tile's strings, for its BeginTile
+        uint32_t nextFirst = 0, nextLast = 0;
+        const int64_t nextSlice0 = nextBase + waveBase;
+        const bool nextWanted = anyCharsStage && nextSlice0 < nrows;
+        if (nextWanted && lane < kMaxCols && lane < NumCols() && tColCharsLds != 0xFFFFFFFFu) {
+            const int32_t* offs = reinterpret_cast<const int32_t*>(tColVal);
+            const int64_t lastRow = (nextSlice0 + 64 * U <= nrows ? nextSlice0 + 64 * U : nrows) - 1;
+            nextFirst = uint32_t(offs[nextSlice0]);
+            nextLast = uint32_t(offs[lastRow]);
+        }
+        const bool haveBounds = anyCharsStage && boundsTile == tileBase;
         if (!(S().debug_flags & 1)) {
             SSA_UNROLL_STATIC
             for (int c = 0; c < NumCols(); ++c) {
@@ -309,16 +340,32 @@ struct Machine {
                         __builtin_amdgcn_global_load_lds((GlobalPtr)(src + b), (LdsPtr)(gLds + off + waveBase * w + chunk), 16, 0, 0);
                     }
                 }
+                // a staged string column: the end offset of the slice's last row goes to the wave's slot (the tile of
+                // offsets ends where the next wave's begins, and that wave's copy is not waited for here)
+                const uint32_t endOff = ColEndOff(c);
+                if (endOff != 0xFFFFFFFFu && slice0 < nrows && lane == 0) {
+                    const int64_t endRow = slice0 + 64 * U < nrows ? slice0 + 64 * U : nrows;
+                    __builtin_amdgcn_global_load_lds((GlobalPtr)(reinterpret_cast<const int32_t*>(src - slice0 * w) + endRow),
+                                                     (LdsPtr)(gLds + endOff), 4, 0, 0);
+                }
             }
         }
+        if (haveBounds) StageStringHeads(slice0, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (anyCharsStage) StageStringHeads(slice0);
+        asm volatile("" ::"v"(nextFirst), "v"(nextLast));  // (the compiler's own wait for these two loads belongs here too)
+        if (haveBounds) charsPending = false;  // the head copies were part of that wait
+        if (anyCharsStage && !haveBounds) StageStringHeads(slice0, false);
+        boundsFirst = nextFirst;
+        boundsLast = nextLast;
+        boundsTile = nextWanted ? nextBase : -1;
     }
 
     // Second staging phase, for string columns: with the offsets of the wave's rows now in LDS, copy the bytes from
     // the first row's string to 8 bytes past the start of the last row's string into the wave's head area.  Nothing
     // waits for this copy here: WaitStringHeads() is called right before the first use, after other work.
-    __device__ __forceinline__ void StageStringHeads(int64_t slice0) {
+    // `fromBounds`: the slice's first and last offsets were read ahead (boundsFirst / boundsLast); otherwise they come
+    // from the staged offsets, which must have arrived.
+    __device__ __forceinline__ void StageStringHeads(int64_t slice0, bool fromBounds) {
         const int lane = threadIdx.x & 63;
         charsPending = false;
         const int64_t last = (slice0 + 64 * U <= nrows ? slice0 + 64 * U : nrows) - 1;  // last row of the slice
@@ -328,9 +375,15 @@ struct Machine {
             if (area == 0xFFFFFFFFu) continue;
             uint32_t begin = 0, bytes = 0, skew = 0;
             if (last >= slice0) {
-                const int32_t* l = reinterpret_cast<const int32_t*>(gLds + int(ColOff(c)));
-                const uint32_t b0 = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase]));
-                const uint32_t bl = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase + int(last - slice0)]));
+                uint32_t b0, bl;
+                if (fromBounds) {
+                    b0 = ReadLane32(boundsFirst, c);
+                    bl = ReadLane32(boundsLast, c);
+                } else {
+                    const int32_t* l = reinterpret_cast<const int32_t*>(gLds + int(ColOff(c)));
+                    b0 = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase]));
+                    bl = uint32_t(__builtin_amdgcn_readfirstlane(l[waveBase + int(last - slice0)]));
+                }
                 const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
                 const uint32_t limit = ReadLane32(tColCharsBytes, c);
                 uint32_t endb = bl + 8;
@@ -437,22 +490,27 @@ struct Machine {
         }
     }
 
-    // Bytes of the string in row u of the lane.  Offsets come from the staged tile when the column's offsets are in
-    // LDS.  A wave stages the offsets of its own rows only (and in the last tile only those below `nrows`), so the
-    // end offset of the last row of its slice and of the batch's last row is read from memory.
+    // Bytes of the string in row u of the lane (nothing for a row past the end of the batch).  Offsets come from the
+    // staged tile when the column's offsets are in LDS.  A wave stages the offsets of its own rows only (and in the
+    // last tile only those below `nrows`): the end offset of the last row of its slice, and of the batch's last row,
+    // is in the wave's slot.
     __device__ __forceinline__ void StringAt(int c, int u, const uint8_t*& p, int32_t& n) const {
         const int32_t* offs = reinterpret_cast<const int32_t*>(ReadLane64(tColVal, c));
         const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
         const int off = int(ColOff(c));
         const int64_t row = Row(u);
-        int32_t b, e;
-        if (off >= 0) {
+        const bool active = (act >> u) & 1u;
+        int32_t b = 0, e = 0;
+        const uint32_t endOff = ColEndOff(c);
+        if (off >= 0 && endOff != 0xFFFFFFFFu) {
             const int32_t* l = reinterpret_cast<const int32_t*>(gLds + off);
             const int idx = Idx(u);
             b = l[idx];
-            // only the wave's own slice is known to have arrived
-            e = (idx + 1 < waveBase + 64 * U && row + 1 < nrows) ? l[idx + 1] : offs[row + 1];
-        } else {
+            const int32_t next = l[idx + 1 < waveBase + 64 * U ? idx + 1 : idx];
+            const int32_t last = *reinterpret_cast<const int32_t*>(gLds + endOff);
+            e = (idx + 1 < waveBase + 64 * U && row + 1 < nrows) ? next : last;
+            if (!active) b = e = 0;
+        } else if (active) {
             b = offs[row];
             e = offs[row + 1];
         }
@@ -460,8 +518,10 @@ struct Machine {
         n = e - b;
     }
 
-    // Up to the first 8 bytes of a string (little-endian in the result, bytes past the string's end are zero).  One
-    // unaligned 8-byte load when that stays inside the column's chars buffer, byte loads next to its end.
+    // Up to the first 8 bytes of a string (little-endian in the result, bytes past the string's end are zero).  From
+    // the wave's head area when the bytes are there (three aligned LDS words and a byte shift, no branches on the
+    // length); else one unaligned 8-byte load when that stays inside the column's chars buffer, byte loads next to its
+    // end.
     __device__ __forceinline__ uint64_t StringHead(int c, const uint8_t* p, int32_t n) const {
         if (n <= 0) return 0;
         const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
@@ -471,17 +531,64 @@ struct Machine {
         const int64_t rel = off - int64_t(ReadLane32(tCharsBegin, c));
         const int32_t m = n < 8 ? n : 8;
         if (staged != 0 && rel >= 0 && rel + m <= int64_t(staged)) {
-            // from the wave's head area in LDS (WaitStringHeads() has been called)
-            const uint8_t* l = gLds + ColCharsLds(c) + ReadLane32(tCharsSkew, c) + rel;
-            for (int32_t j = 0; j < m; ++j) w |= uint64_t(l[j]) << (8 * j);
-            return w;
-        }
-        if (off + 8 <= int64_t(ReadLane32(tColCharsBytes, c))) {
-            __builtin_memcpy(&w, p, 8);
+            // (WaitStringHeads() has been called; the area has 16 spare bytes behind the staged ones)
+            const uint32_t addr = ColCharsLds(c) + ReadLane32(tCharsSkew, c) + uint32_t(rel);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(gLds + (addr & ~3u));
+            const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+            const uint32_t sh = addr & 3u;
+            w = uint64_t(__builtin_amdgcn_alignbyte(q1, q0, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(q2, q1, sh)) << 32);
         } else {
-            for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[j]) << (8 * j);
+            const int64_t limit = int64_t(ReadLane32(tColCharsBytes, c));
+            if (off < 0 || off + m > limit) return 0;  // offsets that do not describe this buffer: never dereferenced
+            if (off + 8 <= limit) {
+                __builtin_memcpy(&w, p, 8);
+            } else {
+                for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[j]) << (8 * j);
+            }
         }
         return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1ull));
+    }
+
+    // Group-by keys: length and first 8 bytes (little-endian, zero past the end) of the string in row u, all in 32-bit
+    // offsets when the column's offsets and heads are staged -- two LDS reads for the offsets, three for the bytes, no
+    // pointer arithmetic.  Rows that are not active (or whose `wanted` is false) give length 0.
+    __device__ __forceinline__ void StringKeyWord(int c, int u, bool wanted, int32_t& n, uint64_t& w) const {
+        const int off = int(ColOff(c));
+        const uint32_t endOff = ColEndOff(c);
+        const uint32_t area = ColCharsLds(c);
+        if (off >= 0 && endOff != 0xFFFFFFFFu && area != 0xFFFFFFFFu) {
+            const int32_t* l = reinterpret_cast<const int32_t*>(gLds + off);
+            const int idx = Idx(u);
+            const bool inSlice = idx + 1 < waveBase + 64 * U;
+            const int32_t b = l[idx];
+            const int32_t next = l[inSlice ? idx + 1 : idx];
+            const int32_t last = *reinterpret_cast<const int32_t*>(gLds + endOff);
+            const int32_t e = (inSlice && Row(u) + 1 < nrows) ? next : last;
+            const bool live = wanted && ((act >> u) & 1u);
+            n = live ? e - b : 0;
+            const uint32_t m = uint32_t(n < 8 ? n : 8);
+            const uint32_t rel = uint32_t(b) - ReadLane32(tCharsBegin, c);  // wraps when b is below the staged range
+            const uint32_t staged = ReadLane32(tCharsBytes, c);
+            if (n <= 0) {
+                w = 0;
+                return;
+            }
+            if (rel < staged && rel + m <= staged) {
+                const uint32_t addr = area + ReadLane32(tCharsSkew, c) + rel;
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(gLds + (addr & ~3u));
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+                const uint32_t sh = addr & 3u;
+                const uint64_t word = uint64_t(__builtin_amdgcn_alignbyte(q1, q0, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(q2, q1, sh)) << 32);
+                w = n >= 8 ? word : (word & ((1ull << (8 * n)) - 1ull));
+                return;
+            }
+            w = StringHead(c, reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c)) + b, n);
+            return;
+        }
+        const uint8_t* p = nullptr;
+        n = 0;
+        if (wanted && ((act >> u) & 1u)) StringAt(c, u, p, n);
+        w = StringHead(c, p, n);
     }
 
     // Operand fetch by pre-decoded kind: the host resolved column type, width and LDS offset, so a

@@ -282,6 +282,7 @@ struct ScanArgs {
     int32_t lds_regok_off;          // R register validity: nregs x lanes bytes
     int32_t nregs;
     int32_t lds_sink_off;           // first byte available to the sink (group-by table)
+    int32_t lds_end_off[kMaxCols];  // staged string column c: one 16-byte slot per wave for the end offset of the wave's last row, or -1
     int32_t debug_flags;            // diagnostics only: 1 = skip staging, 2 = skip evaluation (timing experiments)
 };
 
