@@ -829,9 +829,12 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
         return nullptr;
     }
     const int64_t ntiles = (rows + kTileRows - 1) / kTileRows;
-    int perCU = std::max(1, std::min(4, k.BlocksPerCU));
+    // Three resident workgroups per CU have measured best for these kernels at SF100 (a grid of 4 x 256 workgroups --
+    // tile strides of a power of two -- is the slowest choice, 5 x 256 again close to 3 x 256).
+    int perCU = std::max(1, std::min(3, k.BlocksPerCU));
     if (const char* pc = std::getenv("SSA_SPEC_BLOCKS_PER_CU")) perCU = std::max(1, std::min(8, std::atoi(pc)));  // experiments
     cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU));
+    if (const char* g = std::getenv("SSA_SPEC_GRID")) cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), std::atoi(g)));  // experiments
     return k.Function;
 }
 

@@ -405,8 +405,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 int32_t n[U];
                 uint64_t w[U];
                 m.WaitStringHeads();
-#pragma unroll
-                for (int u = 0; u < U; ++u) m.StringKeyWord(ks.col, u, ((m.P >> u) & 1u) != 0, n[u], w[u]);
+                m.StringKeyWords(ks.col, m.P, n, w);
                 // (no branches: the key words of rows that fail the predicate are never used, those of rows with a
                 // longer string are replaced by the hash below)
 #pragma unroll

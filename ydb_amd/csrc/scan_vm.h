@@ -549,46 +549,61 @@ struct Machine {
         return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1ull));
     }
 
-    // Group-by keys: length and first 8 bytes (little-endian, zero past the end) of the string in row u, all in 32-bit
-    // offsets when the column's offsets and heads are staged -- two LDS reads for the offsets, three for the bytes, no
-    // pointer arithmetic.  Rows that are not active (or whose `wanted` is false) give length 0.
-    __device__ __forceinline__ void StringKeyWord(int c, int u, bool wanted, int32_t& n, uint64_t& w) const {
+    // Group-by keys: length and first 8 bytes (little-endian, zero past the end) of the strings of the lane's rows in
+    // column c; rows outside `rows` (bit u) give length 0.  When the column's offsets and heads are staged everything
+    // is 32-bit offset arithmetic on LDS data without a divergent branch -- two LDS reads for the offsets, three for
+    // the bytes; strings whose bytes are not in the head area (a rare wave) are read from memory afterwards.
+    __device__ __forceinline__ void StringKeyWords(int c, uint32_t rows, int32_t* n, uint64_t* w) const {
         const int off = int(ColOff(c));
         const uint32_t endOff = ColEndOff(c);
         const uint32_t area = ColCharsLds(c);
+        rows &= act;
         if (off >= 0 && endOff != 0xFFFFFFFFu && area != 0xFFFFFFFFu) {
             const int32_t* l = reinterpret_cast<const int32_t*>(gLds + off);
-            const int idx = Idx(u);
-            const bool inSlice = idx + 1 < waveBase + 64 * U;
-            const int32_t b = l[idx];
-            const int32_t next = l[inSlice ? idx + 1 : idx];
             const int32_t last = *reinterpret_cast<const int32_t*>(gLds + endOff);
-            const int32_t e = (inSlice && Row(u) + 1 < nrows) ? next : last;
-            const bool live = wanted && ((act >> u) & 1u);
-            n = live ? e - b : 0;
-            const uint32_t m = uint32_t(n < 8 ? n : 8);
-            const uint32_t rel = uint32_t(b) - ReadLane32(tCharsBegin, c);  // wraps when b is below the staged range
-            const uint32_t staged = ReadLane32(tCharsBytes, c);
-            if (n <= 0) {
-                w = 0;
-                return;
+            const uint32_t begin = ReadLane32(tCharsBegin, c), staged = ReadLane32(tCharsBytes, c);
+            const uint32_t base = area + ReadLane32(tCharsSkew, c);
+            int32_t b[U];
+            uint32_t missing = 0;  // bit u: the bytes of row u are not in the head area
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = Idx(u);
+                const bool inSlice = idx + 1 < waveBase + 64 * U;
+                b[u] = l[idx];
+                const int32_t next = l[inSlice ? idx + 1 : idx];
+                const int32_t e = (inSlice && Row(u) + 1 < nrows) ? next : last;
+                n[u] = ((rows >> u) & 1u) ? e - b[u] : 0;
+                if (n[u] < 0) n[u] = 0;
             }
-            if (rel < staged && rel + m <= staged) {
-                const uint32_t addr = area + ReadLane32(tCharsSkew, c) + rel;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t m = uint32_t(n[u] < 8 ? n[u] : 8);
+                const uint32_t rel = uint32_t(b[u]) - begin;  // wraps when b is below the staged range
+                const bool here = rel < staged && rel + m <= staged;
+                missing |= ((n[u] > 0 && !here) ? 1u : 0u) << u;
+                const uint32_t addr = base + (here ? rel : 0u);
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(gLds + (addr & ~3u));
                 const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
                 const uint32_t sh = addr & 3u;
                 const uint64_t word = uint64_t(__builtin_amdgcn_alignbyte(q1, q0, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(q2, q1, sh)) << 32);
-                w = n >= 8 ? word : (word & ((1ull << (8 * n)) - 1ull));
-                return;
+                w[u] = n[u] >= 8 ? word : (word & ((1ull << (8 * n[u])) - 1ull));
             }
-            w = StringHead(c, reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c)) + b, n);
+            if (__any(missing != 0)) {
+                const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if ((missing >> u) & 1u) w[u] = StringHead(c, chars + b[u], n[u]);
+                }
+            }
             return;
         }
-        const uint8_t* p = nullptr;
-        n = 0;
-        if (wanted && ((act >> u) & 1u)) StringAt(c, u, p, n);
-        w = StringHead(c, p, n);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint8_t* p = nullptr;
+            n[u] = 0;
+            if ((rows >> u) & 1u) StringAt(c, u, p, n[u]);
+            w[u] = StringHead(c, p, n[u]);
+        }
     }
 
     // Operand fetch by pre-decoded kind: the host resolved column type, width and LDS offset, so a
