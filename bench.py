@@ -128,6 +128,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches, algo_bytes = scan.local.ReadProfile()
+    built, build_ms, spec_launches = scan.local.SpecializationStats()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -138,7 +139,7 @@ def main():
         # a ratio to the algorithmic bytes of the same launch; null when no such measurement is committed.
         traffic = None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_b_pmc_traffic.json")) as f:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c_pmc_traffic.json")) as f:
                 pmc = json.load(f).get(args.workload)
             if pmc and "note" not in pmc and launches:
                 traffic = pmc["ratio_to_algorithmic"] * (algo_bytes / launches)
@@ -163,10 +164,14 @@ def main():
             "config": {"workload": f"{name}, SF100-sized lineitem shard per GPU ({rows} rows), whole shard as one HBM-resident batch",
                        "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr,
                        "groups": len(next(iter(result.values())).valid) if result else 0,
+                       "kernels_built_at_run_time": built, "kernel_build_ms_before_the_timed_steps": build_ms,
                        "parallelism": f"row-range shards x{world}, partial aggregates merged by RCCL all-gather + merge program"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "ScanKeyedKernel" if args.workload != "q6" else "ScanNoKeyKernel",
+                         # the scan kernel built at run time for this program (same source as the generic
+                         # ScanKeyedKernel / ScanNoKeyKernel, the program's tables as constants) when one ran
+                         "kernel": (("ssa_spec_keyed" if args.workload != "q6" else "ssa_spec_nokey") if spec_launches
+                                    else ("ScanKeyedKernel" if args.workload != "q6" else "ScanNoKeyKernel")),
                          "avg_kernel_ms": 1e3 * avg_kernel_s, "launches": launches,
                          "algorithmic_bytes_per_launch": algo_bytes // max(1, launches)},
         }
