@@ -125,6 +125,27 @@ int64_t ssa_batch_rows(const ssa_batch_t* batch);
 size_t ssa_batch_columns(const ssa_batch_t* batch);
 void ssa_batch_destroy(ssa_batch_t* batch);
 
+/* ---- compute sharding of a result batch --------------------------------------------------------------------- */
+
+/* NArrow::NHash::TXX64::Execute (ydb/core/formats/arrow/hash/calcer.cpp:52-70): out_hashes[row] (host array of
+ * ssa_batch_rows(batch) values) = XXH64 with `seed` over the concatenated bytes of the row's non-null key fields, in the
+ * order of key_columns (integers, floats, timestamps: their value bytes; booleans: one byte; strings: their bytes;
+ * decimals: nothing).  A key column that is not in the batch is SSA_INVALID (ENoColumnPolicy::Verify). */
+int ssa_sharding_hash(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
+                      uint64_t seed, uint64_t* out_hashes, char** err);
+
+/* THashConstructor::BuildHashUI64 + TShardingSplitIndex::Apply (ydb/core/formats/arrow/permutations.cpp:187-207 and
+ * :259-287, permutations.h:84-125; call site engines/reader/plain_reader/iterator/merge.cpp:38-45): the hash of a row
+ * is the key column itself when there is exactly one key of type (U)Int32/(U)Int64, else XXH64 with seed 34323543;
+ * shard = |hash| % shards_count; the per-shard row lists are balanced as the reference does (records move from the
+ * longest list to the shortest while one is above and one below rows / shards_count + 1).  *out is the input with its
+ * rows reordered shard after shard, rows of a shard in ascending input order (what Take(input, BuildPermutation())
+ * returns), out_shard_rows[s] of them in shard s.  A batch the reference leaves unsharded (one shard, no key columns,
+ * a single missing key column) comes back unchanged with every row counted in shard 0.  Lists of equal length are
+ * ordered by shard number where the reference's std::sort leaves the order open.  Up to 512 shards. */
+int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
+                       uint32_t shards_count, ssa_batch_t** out, uint32_t* out_shard_rows, char** err);
+
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 
 /* When enabled, every fused scan kernel launch of this program is bracketed by HIP events on the program's

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "ssa_program_debug_string", "ssa_program_source_columns", "ssa_program_early_filter_columns",
     "ssa_program_step_count", "ssa_program_explain", "ssa_program_apply", "ssa_program_build_filter", "ssa_batch_import",
     "ssa_batch_from_device", "ssa_program_apply_device", "ssa_batch_export", "ssa_batch_rows",
-    "ssa_batch_columns", "ssa_batch_destroy", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
+    "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
     "ssa_gen_lineitem",
 ]
 
@@ -100,6 +100,10 @@ def load() -> ctypes.CDLL:
     lib.ssa_batch_destroy.argtypes = [vp]
     lib.ssa_profile_enable.argtypes = [vp, i32]
     lib.ssa_profile_read.argtypes = [vp, P(ctypes.c_double), P(i64), P(i64)]
+    lib.ssa_sharding_hash.argtypes = [vp, vp, P(ctypes.c_char_p), sz, ctypes.c_uint64, vp, P(vp)]
+    lib.ssa_sharding_hash.restype = i32
+    lib.ssa_sharding_split.argtypes = [vp, vp, P(ctypes.c_char_p), sz, ctypes.c_uint32, P(vp), vp, P(vp)]
+    lib.ssa_sharding_split.restype = i32
     lib.ssa_specialization_stats.argtypes = [P(i64), P(ctypes.c_double), P(i64)]
     lib.ssa_specialization_stats.restype = None
     lib.ssa_gen_lineitem.argtypes = [P(LineitemColumns), i64, i64, ctypes.c_uint64, i32]

@@ -304,6 +304,47 @@ int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, ArrowArra
     return SSA_OK;
 }
 
+int ssa_sharding_hash(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys, uint64_t seed,
+                      uint64_t* out_hashes, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    std::vector<std::string> names;
+    for (size_t i = 0; i < n_keys; ++i) names.emplace_back(key_columns[i] ? key_columns[i] : "");
+    BufferPtr hashes;
+    Status st = program->Exec->ShardingHash(*batch->Batch, names, seed, hashes);
+    if (!st.ok()) return Fail(st, err);
+    if (batch->Batch->Rows > 0 && out_hashes) {
+        if (hipMemcpyAsync(out_hashes, hashes->Ptr, size_t(batch->Batch->Rows) * 8, hipMemcpyDeviceToHost, program->Exec->Stream()) != hipSuccess ||
+            hipStreamSynchronize(program->Exec->Stream()) != hipSuccess) {
+            return Fail(Status::Hip("copying the hashes to the host failed"), err);
+        }
+    }
+    return SSA_OK;
+}
+
+int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
+                       uint32_t shards_count, ssa_batch_t** out, uint32_t* out_shard_rows, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    std::vector<std::string> names;
+    for (size_t i = 0; i < n_keys; ++i) names.emplace_back(key_columns[i] ? key_columns[i] : "");
+    BatchPtr result;
+    std::vector<uint32_t> rows;
+    Status st = program->Exec->ShardingSplit(*batch->Batch, names, shards_count, result, rows);
+    if (!st.ok()) return Fail(st, err);
+    if (out_shard_rows) std::memcpy(out_shard_rows, rows.data(), rows.size() * sizeof(uint32_t));
+    *out = new ssa_batch{result};
+    return SSA_OK;
+}
+
 int64_t ssa_batch_rows(const ssa_batch_t* batch) { return batch->Batch->Rows; }
 size_t ssa_batch_columns(const ssa_batch_t* batch) { return batch->Batch->Cols.size(); }
 void ssa_batch_destroy(ssa_batch_t* batch) { delete batch; }

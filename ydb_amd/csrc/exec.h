@@ -92,6 +92,14 @@ public:
     // TProgramStep::BuildFilter for the first step: Arrow-order bitmap (LSB first) of rows*1 bits, on the host.
     Status BuildFilter(const TProgramStep& step, const BatchPtr& in, std::vector<uint8_t>& bits, int64_t& selected);
 
+    // THashConstructor::BuildHashUI64's XXH64 branch: hashes[row] = XXH64(seed) over the row's non-null key fields.
+    Status ShardingHash(const Batch& in, const std::vector<std::string>& keyNames, uint64_t seed, BufferPtr& hashes);
+    // BuildHashUI64 + TShardingSplitIndex::Apply: `out` holds the rows shard after shard (ascending row order inside a
+    // shard), shardRows[s] of them in shard s.  A batch that the reference leaves unsharded comes back unchanged with all
+    // rows counted in shard 0.
+    Status ShardingSplit(const Batch& in, const std::vector<std::string>& keyNames, uint32_t shards, BatchPtr& out,
+                         std::vector<uint32_t>& shardRows);
+
     Status Sync();
     hipStream_t Stream() const { return StreamHandle; }
     KernelProfile Profile;

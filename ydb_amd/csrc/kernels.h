@@ -161,6 +161,38 @@ hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, 
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);
 
+// ---- compute sharding of a result batch -------------------------------------------------------------
+constexpr int kMaxShardKeys = 8;
+constexpr uint32_t kMaxShards = 512;  // the partition kernels keep 16 x shards counters in LDS
+struct ShardKeyColumn {
+    const void* values;       // fixed-width values, bit-packed booleans, or int32 offsets of a string column
+    const uint8_t* validity;  // nullptr: no nulls
+    const uint8_t* chars;     // string columns only
+    int32_t width;            // bytes per value; 0 = boolean
+    int32_t val_bit_off;
+    int32_t valid_bit_off;
+};
+struct ShardKeyColumns {
+    int32_t nkeys;
+    ShardKeyColumn cols[kMaxShardKeys];
+};
+// Size correction of the per-shard lists as tables in device memory (see ShardPlaceKernel).
+struct ShardCorrection {
+    const uint32_t* keep;       // [shards]
+    const uint32_t* seg_begin;  // [shards + 1]
+    const uint32_t* seg_start;  // [segments]
+    const uint32_t* seg_to;     // [segments]
+};
+// out[row] = XXH64(seed) of the row's non-null key fields.
+hipError_t LaunchXX64Rows(const ShardKeyColumns& keys, int64_t nrows, uint64_t seed, uint64_t* out, hipStream_t st);
+int64_t ShardBlocks(int64_t nrows);
+// counts: [shards][ShardBlocks(nrows)]; shard ids from the hash column (type T_U64 / T_I64 / T_U32 / T_I32) or from shard_ids.
+hipError_t LaunchShardCount(const void* hashes, int hashType, const uint32_t* shard_ids, int64_t nrows, uint32_t shards,
+                            uint32_t* shard_out, int32_t* counts, unsigned long long* totals, hipStream_t st);
+// offsets: exclusive scan of counts; writes the permutation and / or the corrected shard ids.
+hipError_t LaunchShardPlace(const uint32_t* shard_ids, int64_t nrows, uint32_t shards, const int32_t* offsets, uint64_t* perm,
+                            uint32_t* final_shard, const ShardCorrection& corr, hipStream_t st);
+
 // ---- synthetic data (benchmark / parity inputs generated in HBM) -----------------------------------
 struct LineitemColumns {
     int32_t* l_shipdate;

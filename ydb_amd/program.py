@@ -165,6 +165,31 @@ class ProgramContainer:
         self._check(rc, err)
         return read_batch(out_a, out_s)
 
+    # -- compute sharding of a result batch (THashConstructor::BuildHashUI64 + TShardingSplitIndex) ------------
+    @staticmethod
+    def _names(keys: Sequence[str]):
+        arr = (ctypes.c_char_p * max(1, len(keys)))()
+        for i, k in enumerate(keys):
+            arr[i] = k.encode()
+        return arr
+
+    def ShardingHash(self, batch: DeviceBatch, keys: Sequence[str], seed: int = 0) -> np.ndarray:
+        """NHash::TXX64::Execute: XXH64(seed) per row over the non-null key fields."""
+        out = np.zeros(max(1, batch.rows), dtype=np.uint64)
+        err = ctypes.c_void_p()
+        rc = self._lib.ssa_sharding_hash(self._h, batch._h, self._names(keys), len(keys), seed, out.ctypes.data, ctypes.byref(err))
+        self._check(rc, err)
+        return out[:batch.rows]
+
+    def ShardingSplit(self, batch: DeviceBatch, keys: Sequence[str], shards: int) -> Tuple[DeviceBatch, List[int]]:
+        """The batch with its rows grouped shard after shard, and the number of rows of every shard."""
+        sizes = np.zeros(max(1, shards), dtype=np.uint32)
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = self._lib.ssa_sharding_split(self._h, batch._h, self._names(keys), len(keys), shards, ctypes.byref(out),
+                                          sizes.ctypes.data, ctypes.byref(err))
+        self._check(rc, err)
+        return DeviceBatch(self._lib, out.value), [int(x) for x in sizes[:shards]]
+
     def EnableProfile(self, enabled: bool = True):
         self._lib.ssa_profile_enable(self._h, 1 if enabled else 0)
 
