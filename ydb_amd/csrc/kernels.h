@@ -186,6 +186,8 @@ struct ShardCorrection {
 // out[row] = XXH64(seed) of the row's non-null key fields.
 hipError_t LaunchXX64Rows(const ShardKeyColumns& keys, int64_t nrows, uint64_t seed, uint64_t* out, hipStream_t st);
 int64_t ShardBlocks(int64_t nrows);
+// out[i] = in[i * stride] for i < count (first scanned offset of every shard).
+hipError_t LaunchGatherStrided(const int32_t* in, int64_t stride, int count, int32_t* out, hipStream_t st);
 // counts: [shards][ShardBlocks(nrows)]; shard ids from the hash column (type T_U64 / T_I64 / T_U32 / T_I32) or from shard_ids.
 hipError_t LaunchShardCount(const void* hashes, int hashType, const uint32_t* shard_ids, int64_t nrows, uint32_t shards,
                             uint32_t* shard_out, int32_t* counts, unsigned long long* totals, hipStream_t st);

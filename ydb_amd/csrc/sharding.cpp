@@ -142,20 +142,23 @@ Status Executor::ShardingSplit(const Batch& in, const std::vector<std::string>& 
     BufferPtr counts = Buffer::Alloc(size_t(ncounts + 1) * 4 + 16);
     BufferPtr offsets = Buffer::Alloc(size_t(ncounts + 1) * 4 + 16);
     BufferPtr scanTmp = Buffer::Alloc(size_t((ncounts + 4095) / 4096 + 2) * 8 + 16);
-    BufferPtr totals = Buffer::Alloc(size_t(shards) * 8);
     BufferPtr perm = Buffer::Alloc(size_t(n) * 8);
-    if (!shardIds || !counts || !offsets || !scanTmp || !totals || !perm) return Status::Hip("out of device memory");
+    BufferPtr firstsDev = Buffer::Alloc(size_t(shards + 1) * 4 + 16);
+    if (!shardIds || !counts || !offsets || !scanTmp || !perm || !firstsDev) return Status::Hip("out of device memory");
     uint32_t* ids = static_cast<uint32_t*>(shardIds->Ptr);
 
     auto countAndScan = [&](const void* h, const uint32_t* given, uint32_t* idsOut, std::vector<uint64_t>& sizes) -> Status {
-        SSA_HIP(hipMemsetAsync(totals->Ptr, 0, size_t(shards) * 8, StreamHandle));
-        SSA_HIP(LaunchShardCount(h, hashType, given, n, shards, idsOut, static_cast<int32_t*>(counts->Ptr),
-                                 static_cast<unsigned long long*>(totals->Ptr), StreamHandle));
+        SSA_HIP(LaunchShardCount(h, hashType, given, n, shards, idsOut, static_cast<int32_t*>(counts->Ptr), nullptr, StreamHandle));
         SSA_HIP(LaunchExclusiveScanI32(static_cast<const int32_t*>(counts->Ptr), static_cast<int32_t*>(offsets->Ptr), ncounts,
                                        static_cast<int64_t*>(scanTmp->Ptr), StreamHandle));
-        sizes.assign(shards, 0);
-        SSA_HIP(hipMemcpyAsync(sizes.data(), totals->Ptr, size_t(shards) * 8, hipMemcpyDeviceToHost, StreamHandle));
+        // the first offset of every shard (and the grand total behind the last one)
+        std::vector<int32_t> firsts(shards + 1, 0);
+        SSA_HIP(LaunchGatherStrided(static_cast<const int32_t*>(offsets->Ptr), nblocks, int(shards + 1), static_cast<int32_t*>(firstsDev->Ptr),
+                                    StreamHandle));
+        SSA_HIP(hipMemcpyAsync(firsts.data(), firstsDev->Ptr, size_t(shards + 1) * 4, hipMemcpyDeviceToHost, StreamHandle));
         SSA_HIP(hipStreamSynchronize(StreamHandle));
+        sizes.assign(shards, 0);
+        for (uint32_t s = 0; s < shards; ++s) sizes[s] = uint64_t(firsts[s + 1] - firsts[s]);
         return Status::OK();
     };
 

@@ -215,10 +215,20 @@ __global__ __launch_bounds__(kBlock) void ShardCountKernel(const void* hashes, i
 #pragma unroll
         for (int u = 0; u < kShardBlockRows / kBlock; ++u) {
             const int64_t row = block * kShardBlockRows + u * kBlock + threadIdx.x;
-            if (row < nrows) {
-                const uint32_t s = shardIds ? shardIds[row] : ShardOf(hashes, hashType, row, shards);
+            const bool live = row < nrows;
+            uint32_t s = 0xFFFFFFFFu;
+            if (live) {
+                s = shardIds ? shardIds[row] : ShardOf(hashes, hashType, row, shards);
                 if (shardOut) shardOut[row] = s;
-                atomicAdd(hist + s, 1u);
+            }
+            // one LDS atomic per distinct shard among the wave's 64 rows, not one per row
+            uint64_t todo = __ballot(live);
+            while (todo != 0) {
+                const int leader = __ffsll(static_cast<unsigned long long>(todo)) - 1;
+                const uint32_t s0 = uint32_t(__shfl(int(s), leader, 64));
+                const uint64_t same = __ballot(live && s == s0);
+                if (int(threadIdx.x & 63) == leader) atomicAdd(hist + s0, uint32_t(__popcll(same)));
+                todo &= ~same;
             }
         }
         __syncthreads();
@@ -298,6 +308,11 @@ __global__ __launch_bounds__(kBlock) void ShardPlaceKernel(const uint32_t* shard
     }
 }
 
+// out[i] = in[i * stride]
+__global__ __launch_bounds__(kBlock) void GatherStridedKernel(const int32_t* in, int64_t stride, int count, int32_t* out) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) out[i] = in[int64_t(i) * stride];
+}
+
 int GridForRows(int64_t n, int rowsPerBlock) {
     int64_t g = (n + rowsPerBlock - 1) / rowsPerBlock;
     if (g < 1) g = 1;
@@ -309,6 +324,11 @@ int GridForRows(int64_t n, int rowsPerBlock) {
 
 hipError_t LaunchXX64Rows(const ShardKeyColumns& keys, int64_t nrows, uint64_t seed, uint64_t* out, hipStream_t st) {
     hipLaunchKernelGGL(XX64RowsKernel, dim3(GridForRows(nrows, kBlock)), dim3(kBlock), 0, st, keys, nrows, seed, out);
+    return hipGetLastError();
+}
+
+hipError_t LaunchGatherStrided(const int32_t* in, int64_t stride, int count, int32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(GatherStridedKernel, dim3(GridForRows(count, kBlock)), dim3(kBlock), 0, st, in, stride, count, out);
     return hipGetLastError();
 }
 
