@@ -146,6 +146,55 @@ int ssa_sharding_hash(ssa_program_t* program, const ssa_batch_t* batch, const ch
 int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
                        uint32_t shards_count, ssa_batch_t** out, uint32_t* out_shard_rows, char** err);
 
+/* ---- TColumnFilter: filters kept in HBM and their algebra ---------------------------------------------------------- */
+
+/* NArrow::TColumnFilter (ydb/core/formats/arrow/arrow_filter.h:20-211) with its bits in device memory.  The reference
+ * keeps run lengths of alternating values; the handle keeps a bitmap and gives the run lengths back on request.  A
+ * filter "without a size" (Filter.empty(): BuildAllowFilter / BuildDenyFilter, or one made from no rows) stays that. */
+typedef struct ssa_filter ssa_filter_t;
+
+/* ECompareType (arrow_filter.h:13-18) */
+enum ssa_compare_type { SSA_CMP_LESS = 1, SSA_CMP_LESS_OR_EQUAL = 2, SSA_CMP_GREATER = 3, SSA_CMP_GREATER_OR_EQUAL = 4 };
+
+/* TColumnFilter::BuildAllowFilter / BuildDenyFilter (arrow_filter.h:188-194).  Needs no GPU. */
+int ssa_filter_simple(int allow, ssa_filter_t** out);
+/* TColumnFilter(std::vector<bool>&&) (arrow_filter.h:132-155) with the values given as runs: run j has runs[j] rows of
+ * value first_value ^ (j & 1).  Runs of length 0 are skipped and equal neighbours joined, as TColumnFilter::Add does
+ * (arrow_filter.cpp:239-250); no rows at all give the allow filter without a size. */
+int ssa_filter_from_runs(ssa_program_t* program, int first_value, const uint32_t* runs, size_t n_runs, ssa_filter_t** out, char** err);
+/* TProgramStep::BuildFilter (ydb/core/formats/arrow/program.cpp:921-946) on an HBM-resident batch, the result staying in
+ * HBM.  *out = NULL when the step has no Filter command (the reference returns nullptr). */
+int ssa_filter_from_program(ssa_program_t* program, size_t step_index, const ssa_batch_t* batch, ssa_filter_t** out, char** err);
+/* TColumnFilter::MakePredicateFilter(batch, border, compareType) (arrow_filter.cpp:118-136, 259-311; caller
+ * engines/predicate/container.h:74): `border` is a one-row RecordBatch (host memory, Arrow C Data Interface) whose
+ * columns are the leading key columns; rows are compared with it key after key (values only: validity is not looked
+ * at, strings by memcmp then length) and kept according to `compare_type` (enum ssa_compare_type).  A border column
+ * that is missing from the batch or differs in type is SSA_INVALID (the reference aborts). */
+int ssa_filter_predicate(ssa_program_t* program, const ssa_batch_t* batch, const struct ArrowArray* border,
+                         const struct ArrowSchema* border_schema, int compare_type, ssa_filter_t** out, char** err);
+/* TColumnFilter::And / Or (arrow_filter.cpp:402-513).  Two sized filters must have the same size (SSA_INVALID
+ * otherwise; the reference aborts). */
+int ssa_filter_and(ssa_program_t* program, const ssa_filter_t* a, const ssa_filter_t* b, ssa_filter_t** out, char** err);
+int ssa_filter_or(ssa_program_t* program, const ssa_filter_t* a, const ssa_filter_t* b, ssa_filter_t** out, char** err);
+/* TColumnFilter::CombineSequentialAnd (arrow_filter.cpp:515-575; caller reader/plain_reader/iterator/fetched_data.h:70-80):
+ * `ext` has one row for every row `self` keeps and decides which of those stay. */
+int ssa_filter_combine_sequential_and(ssa_program_t* program, const ssa_filter_t* self, const ssa_filter_t* ext,
+                                      ssa_filter_t** out, char** err);
+/* State as the reference holds it (arrow_filter.h:22-25): *is_empty = Filter.empty(), *default_value =
+ * DefaultFilterValue, *count = Count (Size()).  Needs no GPU. */
+void ssa_filter_info(const ssa_filter_t* filter, int* is_empty, int* default_value, int64_t* count);
+/* The `Filter` vector and LastValue: call with runs = NULL to learn *n_runs, then with an array of that many values. */
+int ssa_filter_runs(ssa_program_t* program, const ssa_filter_t* filter, uint32_t* runs, size_t* n_runs, int* last_value, char** err);
+/* TColumnFilter::BuildSimpleFilter (arrow_filter.cpp:383-400) as an Arrow-order bitmap: ceil(count / 8) bytes. */
+int ssa_filter_bits(ssa_program_t* program, const ssa_filter_t* filter, uint8_t* out_bits, char** err);
+/* TColumnFilter::GetFilteredCount (arrow_filter.cpp:586-608); *out = -1 where the reference returns an empty optional
+ * (the allow filter without a size). */
+int ssa_filter_filtered_count(ssa_program_t* program, const ssa_filter_t* filter, int64_t* out, char** err);
+/* TColumnFilter::Apply(std::shared_ptr<arrow::RecordBatch>&) (arrow_filter.cpp:313-348): the rows the filter keeps, in
+ * order, every column compacted on the GPU. */
+int ssa_filter_apply(ssa_program_t* program, const ssa_filter_t* filter, const ssa_batch_t* batch, ssa_batch_t** out, char** err);
+void ssa_filter_destroy(ssa_filter_t* filter);
+
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 
 /* When enabled, every fused scan kernel launch of this program is bracketed by HIP events on the program's

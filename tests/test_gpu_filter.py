@@ -1,0 +1,311 @@
+"""TColumnFilter on the GPU (ssa_filter_*) against the run-length oracle: the state the reference holds (Filter.empty(),
+DefaultFilterValue, Count, the run vector, LastValue) must be identical after every operation, the kept rows after Apply
+must be the oracle's, and the reference's own known answers must come out of the GPU path."""
+import numpy as np
+import pytest
+
+from tests.test_oracle_filter import key_comparison_columns, random_bits, vectors
+from ydb_amd.arrow_c import Col
+from ydb_amd.ssa_pb import F, Column, Program
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pc():
+    from ydb_amd.program import ProgramContainer
+    c = ProgramContainer()
+    ok, err = c.Init([(1, "x")], Program().project([1]))
+    assert ok, err
+    return c
+
+
+def same_state(gpu, orc):
+    """gpu: ColumnFilter, orc: oracle RleFilter"""
+    empty, default, last, count, nruns = orc.info()
+    assert gpu.IsEmpty() == empty
+    assert gpu.DefaultFilterValue() == default
+    assert gpu.Size() == count
+    runs, glast = gpu.Runs()
+    assert np.array_equal(runs, orc.runs())
+    if not empty:
+        assert glast == last
+        assert np.array_equal(gpu.BuildSimpleFilter(), orc.bools())
+    assert gpu.GetFilteredCount() == orc.filtered_count()
+
+
+def both(pc, bits):
+    from oracle import filter_oracle as fo
+    from ydb_amd.column_filter import ColumnFilter
+    return ColumnFilter.FromValues(pc, bits), fo.RleFilter.from_bools(bits)
+
+
+def test_reference_known_answers(pc):
+    from ydb_amd.column_filter import ColumnFilter
+    v = vectors()
+    c = v["MergeFilters"]
+    r = ColumnFilter.FromValues(pc, c["a"]).Or(ColumnFilter.FromValues(pc, c["b"]))
+    assert r.Size() == c["size"] and r.BuildSimpleFilter().astype(int).tolist() == c["expect"]
+    c = v["CombineFilters"]
+    r = ColumnFilter.FromValues(pc, c["a"]).CombineSequentialAnd(ColumnFilter.FromValues(pc, c["b"]))
+    assert r.Size() == c["size"] and r.BuildSimpleFilter().astype(int).tolist() == c["expect"]
+    c = v["KeyComparison"]
+    dev = pc.Import(key_comparison_columns(c["rows"]))
+    border = {k: np.array([val], dtype=key_comparison_columns(1)[k].dtype) for k, val in c["border"].items()}
+    for name, ct in (("LESS", 1), ("LESS_OR_EQUAL", 2), ("GREATER", 3), ("GREATER_OR_EQUAL", 4)):
+        bits = ColumnFilter.MakePredicateFilter(pc, dev, border, ct).BuildSimpleFilter()
+        lead, value = c["expect_leading"][name]
+        assert len(bits) == c["rows"] and np.all(bits[:lead] == value) and np.all(bits[lead:] != value)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 128, 1000, 4096, 70_001])
+@pytest.mark.parametrize("mean_run", [1.5, 40, 5000])
+def test_algebra_matches_the_oracle(pc, n, mean_run):
+    rng = np.random.default_rng(n * 11 + int(mean_run))
+    a, b = random_bits(rng, n, mean_run), random_bits(rng, n, mean_run)
+    ga, oa = both(pc, a)
+    gb, ob = both(pc, b)
+    same_state(ga, oa)
+    same_state(ga.And(gb), oa.And(ob))
+    same_state(ga.Or(gb), oa.Or(ob))
+    ext = random_bits(rng, int(a.sum()), mean_run)
+    ge, oe = both(pc, ext)
+    same_state(ga.CombineSequentialAnd(ge), oa.CombineSequentialAnd(oe))
+
+
+def test_constant_and_sizeless_filters(pc):
+    from oracle import filter_oracle as fo
+    from ydb_amd.column_filter import ColumnFilter
+    gpu = {"allow": ColumnFilter.BuildAllowFilter(pc), "deny": ColumnFilter.BuildDenyFilter(pc)}
+    orc = {"allow": fo.RleFilter.allow(), "deny": fo.RleFilter.deny()}
+    for name, bits in (("none", []), ("ones", [1] * 130), ("zeros", [0] * 130), ("mixed", [1, 0, 0, 1] * 40)):
+        gpu[name], orc[name] = both(pc, bits)
+    for x in gpu:
+        same_state(gpu[x], orc[x])
+        assert gpu[x].IsTotalAllowFilter() == (x in ("allow", "none", "ones"))
+        assert gpu[x].IsTotalDenyFilter() == (x in ("deny", "zeros"))
+        for y in gpu:
+            sized = [k for k in (x, y) if orc[k].info()[3]]
+            if len(sized) == 2 and orc[x].info()[3] != orc[y].info()[3]:
+                continue
+            same_state(gpu[x].And(gpu[y]), orc[x].And(orc[y]))
+            same_state(gpu[x].Or(gpu[y]), orc[x].Or(orc[y]))
+    # the second filter of CombineSequentialAnd speaks about the kept rows of the first
+    for x, y in (("allow", "mixed"), ("deny", "mixed"), ("mixed", "allow"), ("mixed", "deny"), ("none", "mixed"), ("ones", "ones"),
+                 ("ones", "zeros"), ("zeros", "none"), ("zeros", "allow")):
+        same_state(gpu[x].CombineSequentialAnd(gpu[y]), orc[x].CombineSequentialAnd(orc[y]))
+    ext_g, ext_o = both(pc, [1, 0] * 40)
+    same_state(gpu["mixed"].CombineSequentialAnd(ext_g), orc["mixed"].CombineSequentialAnd(ext_o))
+
+
+def test_runs_given_with_gaps_are_normalised(pc):
+    from oracle import filter_oracle as fo
+    from ydb_amd.column_filter import ColumnFilter
+    # run lengths 3,0,2,0,0,4: the empty runs vanish and their neighbours join, as TColumnFilter::Add does
+    g = ColumnFilter.FromRuns(pc, True, [3, 0, 2, 0, 0, 4])
+    same_state(g, fo.RleFilter.from_bools([1] * 3 + [1] * 2 + [0] * 4))
+    same_state(ColumnFilter.FromRuns(pc, False, [0, 0]), fo.RleFilter.from_bools([]))
+    same_state(ColumnFilter.FromRuns(pc, True, [0, 5]), fo.RleFilter.from_bools([0] * 5))
+
+
+def test_errors_where_the_reference_aborts(pc):
+    from ydb_amd.program import SsaError
+    ga, _ = both(pc, [1, 0])
+    gb, _ = both(pc, [1, 0, 1])
+    with pytest.raises(SsaError) as e:
+        ga.And(gb)
+    assert e.value.code == 1
+    with pytest.raises(SsaError) as e:
+        gb.CombineSequentialAnd(gb)
+    assert e.value.code == 1
+    dev = pc.Import({"k": np.arange(5, dtype=np.int32)})
+    from ydb_amd.column_filter import ColumnFilter
+    with pytest.raises(SsaError):
+        ColumnFilter.MakePredicateFilter(pc, dev, {"missing": np.array([1], dtype=np.int32)}, 1)
+    with pytest.raises(SsaError):
+        ColumnFilter.MakePredicateFilter(pc, dev, {"k": np.array([1], dtype=np.int64)}, 1)   # type differs
+    with pytest.raises(SsaError):
+        ga.Apply(dev)                                                                        # sizes differ
+
+
+def _strings(rng, n, maxlen, alphabet="ab"):
+    letters = np.array(list(alphabet))
+    return ["".join(rng.choice(letters, rng.integers(0, maxlen + 1))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 1000, 30_011])
+def test_predicate_filter_matches_the_oracle(pc, n):
+    from oracle import filter_oracle as fo
+    from ydb_amd.column_filter import ColumnFilter
+    rng = np.random.default_rng(n + 5)
+    f64 = rng.integers(0, 4, n).astype(np.float64)
+    f64[rng.random(n) < 0.1] = np.nan
+    batch = {
+        "i8": rng.integers(-3, 4, n).astype(np.int8),
+        "u16": rng.integers(0, 5, n).astype(np.uint16),
+        "i32": Col(rng.integers(-2, 3, n).astype(np.int32), valid=rng.random(n) > 0.3),   # validity is not looked at
+        "u64": rng.integers(2**63 - 2, 2**63 + 3, n, dtype=np.uint64),
+        "i64": rng.integers(-2, 3, n).astype(np.int64),
+        "f32": rng.integers(0, 4, n).astype(np.float32),
+        "f64": f64,
+        "b": rng.random(n) > 0.5,
+        "s": _strings(rng, n, 3),
+        "u8": rng.integers(0, 256, n).astype(np.uint8),
+    }
+    dev = pc.Import(batch)
+    cases = [
+        (["i8"], [0]), (["u16", "i8"], [2, -1]), (["i32", "u64"], [0, 2**63]), (["u64"], [2**63 + 1]), (["i64", "f32"], [1, 2.0]),
+        (["f64", "u8"], [2.0, 128]), (["b", "s"], [True, "ab"]), (["s"], [""]), (["s", "i8"], ["b", 3]), (["b"], [False]),
+        (["i8", "u16", "i32", "u64", "i64", "f32", "f64", "b"], [1, 2, 0, 2**63, 0, 1.0, 1.0, True]),
+    ]
+    for names, border in cases:
+        cols, bvals, bbatch = [], [], {}
+        for k, bv in zip(names, border):
+            c = batch[k]
+            vals = c.values if isinstance(c, Col) else c
+            if isinstance(vals, list):
+                cols.append([x.encode() for x in vals])
+                bvals.append(bv.encode())
+                bbatch[k] = [bv]
+            else:
+                cols.append(vals)
+                bvals.append(bv)
+                bbatch[k] = np.array([bv], dtype=vals.dtype)
+        for ct in (1, 2, 3, 4):
+            if n == 0:
+                exp = fo.RleFilter.from_bools([])
+            else:
+                exp = fo.predicate_filter(cols, bvals, ct)
+            same_state(ColumnFilter.MakePredicateFilter(pc, dev, bbatch, ct), exp)
+
+
+def _expect_rows(batch, keep):
+    out = {}
+    for k, c in batch.items():
+        vals = c.values if isinstance(c, Col) else c
+        valid = np.asarray(c.valid)[keep] if isinstance(c, Col) and c.valid is not None else None
+        if isinstance(vals, list):
+            out[k] = ([vals[i] for i in np.flatnonzero(keep)], valid)
+        else:
+            out[k] = (vals[keep], valid)
+    return out
+
+
+def _check_rows(got, expect):
+    for k, (vals, valid) in expect.items():
+        g = got[k]
+        if valid is not None:
+            assert np.array_equal(np.asarray(g.valid, dtype=bool), valid), k
+        gv = g.values
+        if isinstance(vals, list):
+            gl = [x.decode() if isinstance(x, (bytes, bytearray)) else x for x in gv]
+            if valid is not None:
+                gl = [x for x, ok in zip(gl, valid) if ok]
+                vals = [x for x, ok in zip(vals, valid) if ok]
+            assert gl == vals, k
+        else:
+            gv = np.asarray(gv)
+            if valid is not None:
+                assert np.array_equal(gv[valid], vals[valid]), k
+            else:
+                assert np.array_equal(gv, vals), k
+
+
+@pytest.mark.parametrize("n,mean_run", [(1, 1.5), (65, 3), (5000, 1.5), (5000, 300), (40_000, 25)])
+def test_apply_keeps_the_selected_rows_in_order(pc, n, mean_run):
+    from ydb_amd.column_filter import ColumnFilter
+    rng = np.random.default_rng(n + int(mean_run * 10))
+    batch = {
+        "i16": rng.integers(-1000, 1000, n).astype(np.int16),
+        "f64": Col(rng.random(n), valid=rng.random(n) > 0.2),
+        "u8": rng.integers(0, 255, n).astype(np.uint8),
+        "b": Col(rng.random(n) > 0.5, valid=rng.random(n) > 0.1),
+        "s": _strings(rng, n, 9, "abcdefgh"),
+        "ns": Col(_strings(rng, n, 5, "xyz"), valid=rng.random(n) > 0.4),
+        "i64": np.arange(n, dtype=np.int64),
+    }
+    dev = pc.Import(batch)
+    for bits in (random_bits(rng, n, mean_run), np.ones(n, dtype=bool), np.zeros(n, dtype=bool)):
+        f = ColumnFilter.FromValues(pc, bits)
+        out = f.Apply(dev)
+        assert out.rows == int(bits.sum())
+        _check_rows(pc.Export(out), _expect_rows(batch, bits))
+    assert ColumnFilter.BuildAllowFilter(pc).Apply(dev).rows == n
+    assert ColumnFilter.BuildDenyFilter(pc).Apply(dev).rows == 0
+    _check_rows(pc.Export(ColumnFilter.BuildDenyFilter(pc).Apply(dev)), _expect_rows(batch, np.zeros(n, dtype=bool)))
+
+
+def test_staged_fetch_like_the_plain_reader():
+    """The reader's stage data (fetched_data.h:70-80) with UseFilter: every new filter is applied to the rows fetched so
+    far and folded into the accumulated filter with CombineSequentialAnd.  PK-range predicate first, then the program's
+    early filter on the surviving rows; the accumulated filter then gates the remaining columns."""
+    from oracle import filter_oracle as fo
+    from oracle import ssa_oracle
+    from ydb_amd.column_filter import ColumnFilter
+    from ydb_amd.program import ProgramContainer
+    rng = np.random.default_rng(77)
+    n = 50_000
+    pk = np.sort(rng.integers(0, 10_000, n)).astype(np.int64)
+    val = rng.integers(0, 100, n).astype(np.int32)
+    payload = rng.random(n)
+    resolver = [(1, "pk"), (2, "val"), (3, "payload")]
+    prog = Program()
+    prog.assign_const(10, "Int32", 30)
+    prog.assign_func(11, F.CMP_LESS, [Column(id=2), Column(id=10)])
+    prog.filter(11)
+    prog.project([1, 2, 3])
+    pc = ProgramContainer()
+    ok, err = pc.Init(resolver, prog)
+    assert ok, err
+    # stage 1: pk in [2000, 7000)
+    keys = pc.Import({"pk": pk})
+    lo = ColumnFilter.MakePredicateFilter(pc, keys, {"pk": np.array([2000], dtype=np.int64)}, 4)
+    hi = ColumnFilter.MakePredicateFilter(pc, keys, {"pk": np.array([7000], dtype=np.int64)}, 1)
+    acc = lo.And(hi)
+    o_acc = fo.predicate_filter([pk], [2000], fo.GREATER_OR_EQUAL).And(fo.predicate_filter([pk], [7000], fo.LESS))
+    same_state(acc, o_acc)
+    in_range = (pk >= 2000) & (pk < 7000)
+    # stage 2: the filter column is fetched, cut to the surviving rows, and the program's filter runs on those
+    stage = acc.Apply(pc.Import({"pk": pk, "val": val}))
+    assert stage.rows == int(in_range.sum())
+    early = ColumnFilter.FromProgram(pc, stage, 0)
+    o_early = fo.RleFilter.from_bools(val[in_range] < 30)
+    same_state(early, o_early)
+    acc2 = acc.CombineSequentialAnd(early)
+    same_state(acc2, o_acc.CombineSequentialAnd(o_early))
+    # stage 3: the remaining column only for the rows that survived everything
+    final = acc2.Apply(pc.Import({"pk": pk, "val": val, "payload": payload}))
+    keep = in_range & (val < 30)
+    got = pc.Export(final)
+    assert np.array_equal(np.asarray(got["payload"].values), payload[keep])
+    assert np.array_equal(np.asarray(got["pk"].values), pk[keep])
+    # the same rows as the whole program on the unfiltered batch restricted to the range
+    res = pc.ApplyProgram({"pk": pk[in_range], "val": val[in_range], "payload": payload[in_range]})
+    assert np.array_equal(np.asarray(res["payload"].values), payload[keep])
+
+
+def test_filter_from_program_equals_build_filter(pc):
+    from ydb_amd.column_filter import ColumnFilter
+    from ydb_amd.program import ProgramContainer
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 1023, 1024, 1025, 9000):
+        batch = {"a": rng.integers(0, 10, n).astype(np.int32), "b": rng.random(n)}
+        prog = Program()
+        prog.assign_const(10, "Int32", 5)
+        prog.assign_func(11, F.CMP_GREATER_EQUAL, [Column(id=1), Column(id=10)])
+        prog.filter(11)
+        prog.project([2])
+        p2 = ProgramContainer()
+        ok, err = p2.Init([(1, "a"), (2, "b")], prog)
+        assert ok, err
+        mask, selected = p2.BuildFilter(batch)
+        f = ColumnFilter.FromProgram(p2, p2.Import(batch), 0)
+        if n == 0:
+            assert f.IsEmpty() and f.DefaultFilterValue()
+        else:
+            assert np.array_equal(f.BuildSimpleFilter(), mask) and f.GetFilteredCount() == selected
+            assert np.array_equal(mask, batch["a"] >= 5)
+    p3 = ProgramContainer()
+    ok, err = p3.Init([(1, "a"), (2, "b")], Program().project([2]))
+    assert ok, err
+    assert ColumnFilter.FromProgram(p3, p3.Import({"b": np.arange(4.0)}), 0) is None   # a step without a Filter command

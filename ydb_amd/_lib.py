@@ -44,6 +44,9 @@ EXPORTED_SYMBOLS = [
     "ssa_batch_from_device", "ssa_program_apply_device", "ssa_batch_export", "ssa_batch_rows",
     "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
     "ssa_gen_lineitem",
+    "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
+    "ssa_filter_combine_sequential_and", "ssa_filter_info", "ssa_filter_runs", "ssa_filter_bits", "ssa_filter_filtered_count",
+    "ssa_filter_apply", "ssa_filter_destroy",
 ]
 
 _lib = None
@@ -108,6 +111,29 @@ def load() -> ctypes.CDLL:
     lib.ssa_specialization_stats.restype = None
     lib.ssa_gen_lineitem.argtypes = [P(LineitemColumns), i64, i64, ctypes.c_uint64, i32]
     lib.ssa_gen_lineitem.restype = i32
+    lib.ssa_filter_simple.argtypes = [i32, P(vp)]
+    lib.ssa_filter_simple.restype = i32
+    lib.ssa_filter_from_runs.argtypes = [vp, i32, vp, sz, P(vp), P(vp)]
+    lib.ssa_filter_from_runs.restype = i32
+    lib.ssa_filter_from_program.argtypes = [vp, sz, vp, P(vp), P(vp)]
+    lib.ssa_filter_from_program.restype = i32
+    lib.ssa_filter_predicate.argtypes = [vp, vp, P(ArrowArray), P(ArrowSchema), i32, P(vp), P(vp)]
+    lib.ssa_filter_predicate.restype = i32
+    for f in (lib.ssa_filter_and, lib.ssa_filter_or, lib.ssa_filter_combine_sequential_and):
+        f.argtypes = [vp, vp, vp, P(vp), P(vp)]
+        f.restype = i32
+    lib.ssa_filter_info.argtypes = [vp, P(i32), P(i32), P(i64)]
+    lib.ssa_filter_info.restype = None
+    lib.ssa_filter_runs.argtypes = [vp, vp, vp, P(sz), P(i32), P(vp)]
+    lib.ssa_filter_runs.restype = i32
+    lib.ssa_filter_bits.argtypes = [vp, vp, vp, P(vp)]
+    lib.ssa_filter_bits.restype = i32
+    lib.ssa_filter_filtered_count.argtypes = [vp, vp, P(i64), P(vp)]
+    lib.ssa_filter_filtered_count.restype = i32
+    lib.ssa_filter_apply.argtypes = [vp, vp, vp, P(vp), P(vp)]
+    lib.ssa_filter_apply.restype = i32
+    lib.ssa_filter_destroy.argtypes = [vp]
+    lib.ssa_filter_destroy.restype = None
     _lib = lib
     return lib
 

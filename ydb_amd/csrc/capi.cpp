@@ -26,6 +26,10 @@ struct ssa_batch {
     BatchPtr Batch;
 };
 
+struct ssa_filter {
+    FilterPtr Filter;
+};
+
 namespace {
 
 char* DupString(const std::string& s) {
@@ -45,10 +49,10 @@ int Fail(const Status& st, char** err) {
     }
 }
 
-// First row of a one-row parameters batch -> named scalars (tx/program/program.cpp:338-356).
-Status ReadParameters(const ArrowArray* arr, const ArrowSchema* schema, TParameters& out) {
+// The columns of a one-row batch as named scalars, in schema order.
+Status ReadRowScalars(const ArrowArray* arr, const ArrowSchema* schema, std::vector<std::pair<std::string, TScalar>>& out) {
     if (!arr || !schema) return Status::OK();
-    if (!schema->format || std::string(schema->format) != "+s") return Status::Invalid("parameters: expected a struct array");
+    if (!schema->format || std::string(schema->format) != "+s") return Status::Invalid("expected a struct array (an exported one-row RecordBatch)");
     for (int64_t i = 0; i < arr->n_children; ++i) {
         const ArrowArray* a = arr->children[i];
         const ArrowSchema* s = schema->children[i];
@@ -75,6 +79,7 @@ Status ReadParameters(const ArrowArray* arr, const ArrowSchema* schema, TParamet
         else if (fmt == "f") num(T_F32, F64ToBits(double(static_cast<const float*>(v)[off])));
         else if (fmt == "g") num(T_F64, F64ToBits(static_cast<const double*>(v)[off]));
         else if (fmt.rfind("tsu:", 0) == 0) num(T_TS, uint64_t(static_cast<const int64_t*>(v)[off]));
+        else if (fmt == "tDu") num(T_DUR, uint64_t(static_cast<const int64_t*>(v)[off]));
         else if (fmt == "u" || fmt == "z") {
             sc.Type = fmt == "u" ? T_STRING : T_BINARY;
             const int32_t* offs = static_cast<const int32_t*>(a->buffers[1]);
@@ -83,8 +88,17 @@ Status ReadParameters(const ArrowArray* arr, const ArrowSchema* schema, TParamet
         } else {
             continue;
         }
-        out[s->name ? s->name : ""] = sc;
+        out.emplace_back(s->name ? s->name : "", sc);
     }
+    return Status::OK();
+}
+
+// First row of a one-row parameters batch -> named scalars (tx/program/program.cpp:338-356).
+Status ReadParameters(const ArrowArray* arr, const ArrowSchema* schema, TParameters& out) {
+    std::vector<std::pair<std::string, TScalar>> row;
+    Status st = ReadRowScalars(arr, schema, row);
+    if (!st.ok()) return st;
+    for (auto& kv : row) out[kv.first] = kv.second;
     return Status::OK();
 }
 
@@ -344,6 +358,139 @@ int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const c
     *out = new ssa_batch{result};
     return SSA_OK;
 }
+
+// ---- TColumnFilter ----------------------------------------------------------------------------------------
+
+int ssa_filter_simple(int allow, ssa_filter_t** out) {
+    auto f = std::make_shared<DeviceFilter>();
+    f->Empty = true;
+    f->DefaultValue = allow != 0;
+    *out = new ssa_filter{f};
+    return SSA_OK;
+}
+
+#define SSA_FILTER_ENTER()                                \
+    if (err) *err = nullptr;                              \
+    std::lock_guard<std::mutex> g(program->Lock);         \
+    {                                                     \
+        Status est = EnsureExecutor(program);             \
+        if (!est.ok()) return Fail(est, err);             \
+    }
+
+int ssa_filter_from_runs(ssa_program_t* program, int first_value, const uint32_t* runs, size_t n_runs, ssa_filter_t** out, char** err) {
+    SSA_FILTER_ENTER();
+    FilterPtr f;
+    Status st = program->Exec->FilterFromRuns(first_value != 0, std::vector<uint32_t>(runs, runs + n_runs), f);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_filter{f};
+    return SSA_OK;
+}
+
+int ssa_filter_from_program(ssa_program_t* program, size_t step_index, const ssa_batch_t* batch, ssa_filter_t** out, char** err) {
+    SSA_FILTER_ENTER();
+    auto& steps = program->Container.GetProgram()->Steps;
+    if (step_index >= steps.size()) return Fail(Status::Invalid("no such step"), err);
+    *out = nullptr;
+    if (steps[step_index]->Filters.empty()) return SSA_OK;
+    FilterPtr f;
+    Status st = program->Exec->FilterFromStep(*steps[step_index], batch->Batch, f);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_filter{f};
+    return SSA_OK;
+}
+
+int ssa_filter_predicate(ssa_program_t* program, const ssa_batch_t* batch, const ArrowArray* border, const ArrowSchema* border_schema,
+                         int compare_type, ssa_filter_t** out, char** err) {
+    SSA_FILTER_ENTER();
+    if (!border || !border_schema) return Fail(Status::Invalid("null border"), err);
+    if (border->length != 1) return Fail(Status::Invalid("the border must have exactly one row"), err);
+    std::vector<std::pair<std::string, TScalar>> row;
+    Status st = ReadRowScalars(border, border_schema, row);
+    if (!st.ok()) return Fail(st, err);
+    if (int64_t(row.size()) != border->n_children) return Fail(Status::Unsupported("border column type"), err);
+    std::vector<BorderValue> keys;
+    for (auto& kv : row) keys.push_back(BorderValue{kv.first, kv.second});
+    FilterPtr f;
+    st = program->Exec->FilterPredicate(*batch->Batch, keys, compare_type, f);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_filter{f};
+    return SSA_OK;
+}
+
+static int FilterMerge(ssa_program_t* program, const ssa_filter_t* a, const ssa_filter_t* b, bool isOr, ssa_filter_t** out, char** err) {
+    SSA_FILTER_ENTER();
+    FilterPtr f;
+    Status st = program->Exec->FilterAndOr(*a->Filter, *b->Filter, isOr, f);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_filter{f};
+    return SSA_OK;
+}
+int ssa_filter_and(ssa_program_t* program, const ssa_filter_t* a, const ssa_filter_t* b, ssa_filter_t** out, char** err) {
+    return FilterMerge(program, a, b, false, out, err);
+}
+int ssa_filter_or(ssa_program_t* program, const ssa_filter_t* a, const ssa_filter_t* b, ssa_filter_t** out, char** err) {
+    return FilterMerge(program, a, b, true, out, err);
+}
+
+int ssa_filter_combine_sequential_and(ssa_program_t* program, const ssa_filter_t* self, const ssa_filter_t* ext, ssa_filter_t** out,
+                                      char** err) {
+    SSA_FILTER_ENTER();
+    FilterPtr f;
+    Status st = program->Exec->FilterCombineSequentialAnd(*self->Filter, *ext->Filter, f);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_filter{f};
+    return SSA_OK;
+}
+
+void ssa_filter_info(const ssa_filter_t* filter, int* is_empty, int* default_value, int64_t* count) {
+    if (is_empty) *is_empty = filter->Filter->Empty ? 1 : 0;
+    if (default_value) *default_value = filter->Filter->DefaultValue ? 1 : 0;
+    if (count) *count = filter->Filter->Empty ? 0 : filter->Filter->Count;
+}
+
+int ssa_filter_runs(ssa_program_t* program, const ssa_filter_t* filter, uint32_t* runs, size_t* n_runs, int* last_value, char** err) {
+    SSA_FILTER_ENTER();
+    std::vector<uint32_t> r;
+    bool last = true;
+    Status st = program->Exec->FilterToRuns(*filter->Filter, r, last);
+    if (!st.ok()) return Fail(st, err);
+    if (runs) {
+        if (!n_runs || *n_runs < r.size()) return Fail(Status::Invalid("the runs array is too small"), err);
+        std::memcpy(runs, r.data(), r.size() * sizeof(uint32_t));
+    }
+    if (n_runs) *n_runs = r.size();
+    if (last_value) *last_value = last ? 1 : 0;
+    return SSA_OK;
+}
+
+int ssa_filter_bits(ssa_program_t* program, const ssa_filter_t* filter, uint8_t* out_bits, char** err) {
+    SSA_FILTER_ENTER();
+    std::vector<uint8_t> bits;
+    Status st = program->Exec->FilterBits(*filter->Filter, bits);
+    if (!st.ok()) return Fail(st, err);
+    if (!bits.empty()) std::memcpy(out_bits, bits.data(), bits.size());
+    return SSA_OK;
+}
+
+int ssa_filter_filtered_count(ssa_program_t* program, const ssa_filter_t* filter, int64_t* out, char** err) {
+    SSA_FILTER_ENTER();
+    int64_t n = 0;
+    Status st = program->Exec->FilterCountSelected(*filter->Filter, n);
+    if (!st.ok()) return Fail(st, err);
+    if (out) *out = n;
+    return SSA_OK;
+}
+
+int ssa_filter_apply(ssa_program_t* program, const ssa_filter_t* filter, const ssa_batch_t* batch, ssa_batch_t** out, char** err) {
+    SSA_FILTER_ENTER();
+    BatchPtr result;
+    Status st = program->Exec->FilterApply(*filter->Filter, batch->Batch, result);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_batch{result};
+    return SSA_OK;
+}
+
+void ssa_filter_destroy(ssa_filter_t* filter) { delete filter; }
 
 int64_t ssa_batch_rows(const ssa_batch_t* batch) { return batch->Batch->Rows; }
 size_t ssa_batch_columns(const ssa_batch_t* batch) { return batch->Batch->Cols.size(); }

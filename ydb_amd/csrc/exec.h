@@ -79,6 +79,22 @@ struct KernelProfile {
 // Column descriptions of a struct ArrowSchema (no data): used to explain / type-check a program on the host.
 Status SchemaFields(const ArrowSchema* schema, std::vector<FieldDesc>& out);
 
+// TColumnFilter (ydb/core/formats/arrow/arrow_filter.h:20-211) with its bits in HBM.  `Empty` mirrors Filter.empty():
+// such a filter has no size and stands for "every row" (DefaultValue) or "no row".
+struct DeviceFilter {
+    bool Empty = true;
+    bool DefaultValue = true;
+    int64_t Count = 0;
+    BufferPtr Bits;  // ceil(Count / 64) words, bit i of word i / 64 (Arrow order), zero past Count
+};
+using FilterPtr = std::shared_ptr<DeviceFilter>;
+
+// One key column of a predicate border (MakePredicateFilter): the border's value as the column's type.
+struct BorderValue {
+    std::string Name;
+    TScalar Value;  // numbers as the VM payload (floats widened to double), strings as bytes
+};
+
 class Executor {
 public:
     explicit Executor(int device);
@@ -99,6 +115,23 @@ public:
     // rows counted in shard 0.
     Status ShardingSplit(const Batch& in, const std::vector<std::string>& keyNames, uint32_t shards, BatchPtr& out,
                          std::vector<uint32_t>& shardRows);
+
+    // -- TColumnFilter ------------------------------------------------------------------------------------
+    // TColumnFilter(std::vector<bool>) given as runs: run j has `runs[j]` rows of value firstValue ^ (j & 1).
+    Status FilterFromRuns(bool firstValue, const std::vector<uint32_t>& runs, FilterPtr& out);
+    // The reference's representation back: run lengths, LastValue, Count (arrow_filter.h:22-25).
+    Status FilterToRuns(const DeviceFilter& f, std::vector<uint32_t>& runs, bool& lastValue);
+    // TProgramStep::BuildFilter kept in HBM.
+    Status FilterFromStep(const TProgramStep& step, const BatchPtr& in, FilterPtr& out);
+    Status FilterAndOr(const DeviceFilter& a, const DeviceFilter& b, bool isOr, FilterPtr& out);
+    Status FilterCombineSequentialAnd(const DeviceFilter& self, const DeviceFilter& ext, FilterPtr& out);
+    Status FilterPredicate(const Batch& in, const std::vector<BorderValue>& border, int compareType, FilterPtr& out);
+    // GetFilteredCount: -1 stands for the reference's empty optional (an allow-all filter that has no size).
+    Status FilterCountSelected(const DeviceFilter& f, int64_t& selected);
+    // BuildSimpleFilter as an Arrow-order bitmap on the host: ceil(Count / 8) bytes.
+    Status FilterBits(const DeviceFilter& f, std::vector<uint8_t>& bits);
+    // TColumnFilter::Apply: the rows the filter keeps, in order.
+    Status FilterApply(const DeviceFilter& f, const BatchPtr& in, BatchPtr& out);
 
     Status Sync();
     hipStream_t Stream() const { return StreamHandle; }

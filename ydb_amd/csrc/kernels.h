@@ -161,8 +161,35 @@ hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, 
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);
 
+constexpr int kMaxShardKeys = 8;  // key columns of a sharding hash / a predicate border
+
+// ---- TColumnFilter on the device ----------------------------------------------------------------------
+enum PredicateKind : int32_t { PK_SIGNED = 0, PK_UNSIGNED = 1, PK_F32 = 2, PK_F64 = 3, PK_BOOL = 4, PK_STRING = 5 };
+struct PredicateKey {
+    const void* values;          // fixed-width values, bit-packed booleans, or int32 offsets of a string column
+    const uint8_t* chars;        // string columns only
+    const uint8_t* border_chars; // string border (device memory)
+    uint64_t border;             // border value bits; for strings its length
+    int32_t kind;                // PredicateKind
+    int32_t width;
+    int32_t val_bit_off;
+};
+struct PredicateKeys {
+    int32_t nkeys;
+    PredicateKey cols[kMaxShardKeys];
+};
+hipError_t LaunchExpandRuns(const uint32_t* starts, int64_t nruns, int firstValue, int64_t nbits, uint64_t* bits, hipStream_t st);
+hipError_t LaunchTransitionCount(const uint64_t* bits, int64_t nbits, uint32_t* counts, hipStream_t st);
+hipError_t LaunchTransitionScatter(const uint64_t* bits, int64_t nbits, const int64_t* offsets, uint32_t* starts, hipStream_t st);
+hipError_t LaunchBitmapAndOr(const uint64_t* a, const uint64_t* b, int64_t nwords, int isOr, uint64_t* out, hipStream_t st);
+hipError_t LaunchWordPopcount(const uint64_t* bits, int64_t nwords, uint32_t* counts, hipStream_t st);
+hipError_t LaunchSequentialAnd(const uint64_t* self, int64_t nwords, const int64_t* ranks, const uint64_t* ext, int64_t extWords,
+                               uint64_t* out, hipStream_t st);
+// compareType: 1 LESS, 2 LESS_OR_EQUAL, 3 GREATER, 4 GREATER_OR_EQUAL (ECompareType of the reference)
+hipError_t LaunchPredicate(const PredicateKeys& keys, int64_t nrows, int compareType, uint64_t* bits, hipStream_t st);
+hipError_t LaunchBitmapTileCount(const uint64_t* bits, int64_t nwords, int64_t ntiles, uint32_t* counts, hipStream_t st);
+
 // ---- compute sharding of a result batch -------------------------------------------------------------
-constexpr int kMaxShardKeys = 8;
 constexpr uint32_t kMaxShards = 512;  // the partition kernels keep 16 x shards counters in LDS
 struct ShardKeyColumn {
     const void* values;       // fixed-width values, bit-packed booleans, or int32 offsets of a string column
