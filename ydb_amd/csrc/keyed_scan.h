@@ -391,6 +391,10 @@ __device__ __forceinline__ void ScanKeyedBody() {
         uint32_t toHash = 0;  // bit u: row u needs the hash
 #pragma unroll
         for (int u = 0; u < U; ++u) at[u] = 0;
+        // While every key so far has the same width in all rows of the wave (fixed-width keys, string columns whose
+        // strings of this slice all have one length) the packing positions are wave-uniform: kb.pos, shifts by a scalar.
+        // The first key that differs from row to row moves the positions into at[] (same bits, per-row shifts).
+        bool uniformPos = true;
         SSA_UNROLL_STATIC
         for (int k = 0; k < nkeys; ++k) {
             KeySpec ks;
@@ -405,7 +409,31 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 int32_t n[U];
                 uint64_t w[U];
                 m.WaitStringHeads();
-                m.StringKeyWords(ks.col, m.P, n, w);
+                const int len = m.UniformStringKeyWords(ks.col, w);
+                if (len > 0 && uniformPos) {
+                    if (kb.pos + 8 + 8 * len <= 128) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) kb.Append(u, uint64_t(len), 8);
+                        kb.pos += 8;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) kb.Append(u, w[u], 8 * len);
+                        kb.pos += 8 * len;
+                    } else {
+                        kb.pos = 128;  // does not fit: every row of the wave takes the hash
+                    }
+                    continue;
+                }
+                if (len > 0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) n[u] = len;
+                } else {
+                    m.StringKeyWords(ks.col, m.P, n, w);
+                }
+                if (uniformPos) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) at[u] = uint32_t(kb.pos);
+                    uniformPos = false;
+                }
                 // (no branches: the key words of rows that fail the predicate are never used, those of rows with a
                 // longer string are replaced by the hash below)
 #pragma unroll
@@ -425,10 +453,26 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 const bool isNull = ks.nullable && !((x.ok >> u) & 1u);
                 const uint64_t bits = isNull ? 0ull : (PayloadToStored(x.v[u], ks.type) & wmask);
                 if constexpr (hashed) {
-                    kb.AppendAt(u, bits, uint32_t(nbits), at[u]);
-                    if (ks.nullable) kb.AppendAt(u, isNull ? 1ull : 0ull, 1, at[u]);
+                    if (uniformPos) {
+                        if (kb.pos + nbits <= 128) kb.Append(u, bits, nbits);
+                    } else {
+                        kb.AppendAt(u, bits, uint32_t(nbits), at[u]);
+                        if (ks.nullable) kb.AppendAt(u, isNull ? 1ull : 0ull, 1, at[u]);
+                    }
                 } else {
                     kb.Append(u, bits, nbits);
+                }
+            }
+            if constexpr (hashed) {
+                if (uniformPos) {
+                    kb.pos += nbits;
+                    if (ks.nullable) {
+                        if (kb.pos < 128) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) kb.Append(u, ((x.ok >> u) & 1u) ? 0ull : 1ull, 1);
+                        }
+                        kb.pos += 1;
+                    }
                 }
             }
             if constexpr (!hashed) {
@@ -441,9 +485,13 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
         }
         if constexpr (hashed) {
+            if (uniformPos) {
+                if (kb.pos > 119) toHash = AllMask<U>();
+            } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (at[u] > 119) toHash |= 1u << u;
+                for (int u = 0; u < U; ++u) {
+                    if (at[u] > 119) toHash |= 1u << u;
+                }
             }
             toHash &= m.P;
             if (__any(toHash != 0)) {

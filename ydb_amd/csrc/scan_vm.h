@@ -190,6 +190,7 @@ struct Machine {
     const ScanArgs& a;   // kernel-argument segment (read once at kernel start)
     int64_t row0;        // row of u = 0 for this lane
     uint32_t act;        // bit u: Row(u) < nrows
+    bool tileFull;       // every row of the current tile is below nrows
     uint32_t P;          // bit u: row passes every Filter so far
     uint32_t err;        // ScanStatus bits raised by this lane
     Val<U> A;
@@ -312,6 +313,7 @@ struct Machine {
 #pragma unroll
         for (int u = 0; u < U; ++u) act |= (Row(u) < nrows ? 1u : 0u) << u;
         const bool full = (tileBase + kTile <= nrows);
+        tileFull = full;
         const int64_t slice0 = tileBase + waveBase;  // first row of the wave's slice
         // the wave's own LDS traffic of the previous tile (register stores included) has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -547,6 +549,66 @@ struct Machine {
             }
         }
         return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1ull));
+    }
+
+    // Group-by keys, the common case first: every string of the wave's slice has the same length L of 1..8 bytes (flags,
+    // codes, fixed-width identifiers).  Then row i of the slice starts at begin + L * i and its bytes sit at that same
+    // stride in the head area: for L = 1 a single byte read.  L is guessed without touching memory from the extent of the
+    // staged heads (first row's start to last row's start + 8), so the reads that verify it -- the slice's end offset
+    // and one 16-byte read of staged offsets per lane -- are issued together with the reads of the bytes: one LDS round
+    // trip.  Returns L with the rows' bytes in w (little-endian, zero above L bytes), or 0 (w undefined) when the slice
+    // is not like that (partial tile, heads not staged, lengths differ).  The decision is the same for the whole wave.
+    __device__ __forceinline__ int UniformStringKeyWords(int c, uint64_t* w) const {
+        constexpr uint32_t kRows = 64 * U;
+        const int off = int(ColOff(c));
+        const uint32_t endOff = ColEndOff(c);
+        const uint32_t area = ColCharsLds(c);
+        if (off < 0 || endOff == 0xFFFFFFFFu || area == 0xFFFFFFFFu || !tileFull) return 0;
+        const uint32_t begin = ReadLane32(tCharsBegin, c), staged = ReadLane32(tCharsBytes, c);
+        if (staged < 8u + (kRows - 1u)) return 0;
+        const uint32_t L = (staged - 8u) / (kRows - 1u);
+        if (L * (kRows - 1u) + 8u != staged || L > 8u) return 0;
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t base = area + ReadLane32(tCharsSkew, c);
+        const uint32_t last = *reinterpret_cast<const uint32_t*>(gLds + endOff);
+        // (any lane may check any offset: lane t takes offsets U * t .. U * t + U - 1 of the slice; the staged tiles start
+        // at multiples of 16 bytes)
+        const uint32_t* l = reinterpret_cast<const uint32_t*>(gLds + off) + waveBase + U * int(lane);
+        uint32_t o[U];
+        if constexpr (U == 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(l, 16));
+            o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) o[u] = l[u];
+        }
+        if (L == 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = gLds[base + uint32_t(u) * 64u + lane];
+        } else if (L <= 4) {
+            const uint32_t mask = L == 4 ? 0xFFFFFFFFu : ((1u << (8 * L)) - 1u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t addr = base + L * (uint32_t(u) * 64u + lane);
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(gLds + (addr & ~3u));
+                const uint32_t q0 = q[0], q1 = q[1];
+                w[u] = __builtin_amdgcn_alignbyte(q1, q0, addr & 3u) & mask;
+            }
+        } else {
+            const uint64_t mask = L == 8 ? ~0ull : ((1ull << (8 * L)) - 1ull);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t addr = base + L * (uint32_t(u) * 64u + lane);
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(gLds + (addr & ~3u));
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+                const uint32_t sh = addr & 3u;
+                w[u] = (uint64_t(__builtin_amdgcn_alignbyte(q1, q0, sh)) | (uint64_t(__builtin_amdgcn_alignbyte(q2, q1, sh)) << 32)) & mask;
+            }
+        }
+        uint32_t bad = last ^ (begin + L * kRows);
+#pragma unroll
+        for (int u = 0; u < U; ++u) bad |= o[u] ^ (begin + L * (uint32_t(U) * lane + uint32_t(u)));
+        return __all(bad == 0) ? int(L) : 0;
     }
 
     // Group-by keys: length and first 8 bytes (little-endian, zero past the end) of the strings of the lane's rows in
