@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """Scan-pushdown benchmark: rows/s of the SSA program executor over an HBM-resident lineitem.
 
-    python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q6] [--rows R]
+    python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q6|cb_*] [--rows R]
 
 One step = one pass of the program (TPC-H Q1 by default: filter, two computed columns, nine aggregates
 grouped by (l_returnflag, l_linestatus)) over this rank's SF100 lineitem shard, result on the host.  With
 N > 1 (one process per GPU, launched by torch.distributed.run) every rank scans its own SF100-sized
 row range and the partial aggregates are merged through one RCCL all-gather plus a merge program, all
 inside the timed region; `value` is the rows all ranks scanned divided by the slowest rank's time.
+
+The cb_* workloads are the ClickBench scan-aggregate programs over a synthetic 100 M-row `hits` (ydb_amd/clickbench.py);
+their high-cardinality group-bys leave the result table in HBM on one GPU (the row count is read back).
 
 Prints ONE JSON line on rank 0.
 """
@@ -22,6 +25,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+PMC_TRAFFIC_FILE = "r1_c_pmc_traffic.json"  # FETCH_SIZE passes of the scan kernels, as ratios to the algorithmic bytes
 
 
 def cpu_baseline(workload: str, seconds_target: float = 15.0):
@@ -33,15 +37,22 @@ def cpu_baseline(workload: str, seconds_target: float = 15.0):
     from ydb_amd import tpch
     import numpy as np
 
-    codes = workload == "q1_codes"
-    if workload == "q6":
-        prog, cols = tpch.q6_program(), tpch.Q6_COLUMNS
-    else:
-        prog, cols = tpch.q1_program(codes), (tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8)
     batch_rows = 1_000_000  # the reference hands the program batches of about this size
-    li = tpch.lineitem_host(0, batch_rows)
-    batch = {c: li[c] for c in cols}
-    orc = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog)
+    if workload.startswith("cb_"):
+        from ydb_amd import clickbench
+        prog, cols = clickbench.programs()[workload], clickbench.COLUMNS[workload][0]
+        batch = clickbench.DeviceHits(batch_rows, columns=cols).host(cols)
+        resolver = clickbench.HITS_RESOLVER
+    else:
+        codes = workload == "q1_codes"
+        if workload == "q6":
+            prog, cols = tpch.q6_program(), tpch.Q6_COLUMNS
+        else:
+            prog, cols = tpch.q1_program(codes), (tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8)
+        li = tpch.lineitem_host(0, batch_rows)
+        batch = {c: li[c] for c in cols}
+        resolver = tpch.LINEITEM_RESOLVER
+    orc = ssa_oracle.Oracle(resolver, prog)
     hb = orc.import_batch(batch)
     orc.apply_imported(hb)  # warm
     t0 = time.perf_counter()
@@ -53,7 +64,7 @@ def cpu_baseline(workload: str, seconds_target: float = 15.0):
         if dt >= seconds_target or n >= 400:
             break
     return {"value": n * batch_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": f"{n} x {batch_rows}-row batches of the same synthetic lineitem, {dt:.1f} s, one thread"}
+            "sample": f"{n} x {batch_rows}-row batches of the same synthetic table, {dt:.1f} s, one thread"}
 
 
 def main():
@@ -61,8 +72,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6"])
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: TPC-H SF100 lineitem)")
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6", "cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv",
+                                                         "cb_userid", "cb_phrase"])
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: TPC-H SF100 lineitem; ClickBench hits for cb_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses cuda:0 and the exchange runs over gloo (checks the N > 1 path on a 1-GPU box)")
@@ -97,7 +109,21 @@ def main():
 
     rows = args.rows or tpch.SF100_ROWS
     codes = args.workload == "q1_codes"
-    if args.workload == "q6":
+    clickbench_run = args.workload.startswith("cb_")
+    resolver = tpch.LINEITEM_RESOLVER
+    table = "SF100-sized lineitem shard"
+    if clickbench_run:
+        from ydb_amd import clickbench
+        rows = args.rows or clickbench.HITS_ROWS
+        prog = clickbench.programs()[args.workload]
+        cols, bpr = clickbench.COLUMNS[args.workload]
+        name = "ClickBench " + args.workload[3:]
+        resolver = clickbench.HITS_RESOLVER
+        table = "hits-sized shard"
+        li = clickbench.DeviceHits(rows, device=local_rank, row0=rank * rows, columns=cols)
+        if args.workload == "cb_phrase":
+            bpr = 4 + li.phrase_bytes / rows
+    elif args.workload == "q6":
         prog, cols, bpr = tpch.q6_program(), tpch.Q6_COLUMNS, tpch.Q6_BYTES_PER_ROW
         name = "TPC-H Q6"
     else:
@@ -105,10 +131,13 @@ def main():
         cols = tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8
         bpr = tpch.Q1_BYTES_PER_ROW_CODES if codes else tpch.Q1_BYTES_PER_ROW_UTF8
         name = "TPC-H Q1" + (" (1-byte flag codes)" if codes else " (utf8 flags)")
-    li = tpch.DeviceLineitem(rows, device=local_rank, row0=rank * rows,
-                             utf8_flags=(args.workload == "q1"), code_flags=codes)
-    scan = ShardedScan(prog, tpch.LINEITEM_RESOLVER, device=local_rank)
+    if not clickbench_run:
+        li = tpch.DeviceLineitem(rows, device=local_rank, row0=rank * rows,
+                                 utf8_flags=(args.workload == "q1"), code_flags=codes)
+    scan = ShardedScan(prog, resolver, device=local_rank)
     batch = li.batch(cols)
+    # a result of millions of groups stays in HBM on one GPU (its row count is read back)
+    on_device = args.workload in ("cb_userid", "cb_phrase") and world == 1
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -118,13 +147,13 @@ def main():
 
     result = None
     for _ in range(args.warmup):
-        result = scan.run(batch, gather_device=gather_dev)
+        result = scan.run(batch, gather_device=gather_dev, keep_on_device=on_device)
     scan.local.EnableProfile(True)
     scan.local.ReadProfile()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        result = scan.run(batch, gather_device=gather_dev)
+        result = scan.run(batch, gather_device=gather_dev, keep_on_device=on_device)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches, algo_bytes = scan.local.ReadProfile()
@@ -139,12 +168,14 @@ def main():
         # a ratio to the algorithmic bytes of the same launch; null when no such measurement is committed.
         traffic = None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c_pmc_traffic.json")) as f:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)) as f:
                 pmc = json.load(f).get(args.workload)
             if pmc and "note" not in pmc and launches:
                 traffic = pmc["ratio_to_algorithmic"] * (algo_bytes / launches)
         except OSError:
             pass
+        from ydb_amd.shard import last_group_by
+        keyed = bool(last_group_by(prog).keys)
         total_rows = rows * world * args.steps
         avg_kernel_s = (kernel_ms / 1e3) / max(1, launches)
         achieved = (algo_bytes / max(1, launches)) / avg_kernel_s / 1e9 if launches else 0.0
@@ -161,17 +192,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{name}, SF100-sized lineitem shard per GPU ({rows} rows), whole shard as one HBM-resident batch",
+            "config": {"workload": f"{name}, {table} per GPU ({rows} rows), whole shard as one HBM-resident batch",
                        "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr,
-                       "groups": len(next(iter(result.values())).valid) if result else 0,
+                       "groups": result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0),
                        "kernels_built_at_run_time": built, "kernel_build_ms_before_the_timed_steps": build_ms,
                        "parallelism": f"row-range shards x{world}, partial aggregates merged by RCCL all-gather + merge program"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          # the scan kernel built at run time for this program (same source as the generic
                          # ScanKeyedKernel / ScanNoKeyKernel, the program's tables as constants) when one ran
-                         "kernel": (("ssa_spec_keyed" if args.workload != "q6" else "ssa_spec_nokey") if spec_launches
-                                    else ("ScanKeyedKernel" if args.workload != "q6" else "ScanNoKeyKernel")),
+                         "kernel": (("ssa_spec_keyed" if keyed else "ssa_spec_nokey") if spec_launches
+                                    else ("ScanKeyedKernel" if keyed else "ScanNoKeyKernel")),
                          "avg_kernel_ms": 1e3 * avg_kernel_s, "launches": launches,
                          "algorithmic_bytes_per_launch": algo_bytes // max(1, launches)},
         }

@@ -77,3 +77,26 @@ def test_group_bys_above_the_pushdown(n):
     p = Program().group_by([Aggregate(108, AGG.COUNT, []), Aggregate(109, AGG.MIN, [6])], keys=[14])
     got, exp = both(p, batch)
     compare_batches(got, exp, key_names=["URL"])
+
+
+@pytest.mark.parametrize("name", ["cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv", "cb_userid", "cb_phrase"])
+def test_benchmark_workloads_on_the_device_generated_table(name):
+    """The programs bench.py times (ydb_amd/clickbench.py), over the table its generator leaves in HBM, against the
+    oracle on the same columns copied to the host."""
+    from oracle import ssa_oracle
+    from ydb_amd import clickbench
+    from ydb_amd.program import ProgramContainer
+    prog = clickbench.programs()[name]
+    cols = clickbench.COLUMNS[name][0]
+    table = clickbench.DeviceHits(150_000, columns=cols)
+    pc = ProgramContainer()
+    ok, err = pc.Init(clickbench.HITS_RESOLVER, prog)
+    assert ok, err
+    got = pc.Export(pc.ApplyDevice(table.batch(cols)))
+    exp = ssa_oracle.Oracle(clickbench.HITS_RESOLVER, prog).apply(table.host(cols))
+    keys = {"cb_adv": ["AdvEngineID"], "cb_userid": ["UserID"], "cb_phrase": ["SearchPhrase"]}.get(name)
+    compare_batches(got, exp, key_names=keys) if keys else compare_batches(got, exp)
+    if name == "cb_userid":
+        assert len(got["UserID"].valid) > 20_000       # a high-cardinality grouping, as the workload is meant to be
+    if name == "cb_phrase":
+        assert len(got["SearchPhrase"].valid) > 5_000

@@ -1339,7 +1339,9 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         allSimple = allSimple && !a.check_valid && ((a.kind == AGG_COUNT && a.reg == -1) || a.kind == AGG_SUM_F || a.kind == AGG_SUM_I);
     }
     int L = hint.LdsCap, R = 1;
-    if (L == 16) {
+    const bool hotOnly = L < 0;  // many groups: level 1 only for the first groups of each workgroup (a skewed key's heavy hitter)
+    if (hotOnly) L = 16;
+    if (L == 16 && !hotOnly) {
         if (allSimple && naggs <= kHotAggs) {
             L = 64;  // unreplicated accumulators are small: spend LDS on fewer first-probe collisions instead
         } else {
@@ -1376,6 +1378,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     sink.hashed = hashed;
     sink.lds_cap = L;
     sink.lds_rep = R;
+    sink.hot_only = (hotOnly && L >= 4) ? 1 : 0;
     for (int k = 0; k < kHotAggs && k < naggs; ++k) {
         const AggSpec& a = sink.aggs[k];
         if (a.check_valid) continue;
@@ -1463,19 +1466,22 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         cap = std::min<uint64_t>(cap * 16, maxCap);
     }
 
+    // groups per tile of table slots, scanned: where each tile's groups go in the output
+    const int64_t ntilesT = int64_t(cap / kTileRows);
+    BufferPtr tileCounts = Buffer::Alloc(size_t(ntilesT) * 4 + 64);
+    BufferPtr tileOffsets = Buffer::Alloc(size_t(ntilesT + 1 + (ntilesT + 4095) / 4096 + 2) * 8 + 64);
     BufferPtr counter = Buffer::Alloc(256);
-    if (!counter) return Status::Hip("out of device memory");
-    SSA_HIP(hipMemsetAsync(counter->Ptr, 0, 8, StreamHandle));
-    SSA_HIP(LaunchKeyedCount(sink.t_key_lo, cap, static_cast<unsigned long long*>(counter->Ptr), StreamHandle));
-    unsigned long long ngroupsU = 0;
-    SSA_HIP(hipMemcpyAsync(&ngroupsU, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    if (!tileCounts || !tileOffsets || !counter) return Status::Hip("out of device memory");
+    SSA_HIP(LaunchKeyedTileCount(sink.t_key_lo, cap, static_cast<uint32_t*>(tileCounts->Ptr), StreamHandle));
+    SSA_HIP(LaunchTileScan(static_cast<const uint32_t*>(tileCounts->Ptr), ntilesT, static_cast<int64_t*>(tileOffsets->Ptr),
+                           static_cast<int64_t*>(counter->Ptr), StreamHandle));
+    int64_t ngroups = 0;
+    SSA_HIP(hipMemcpyAsync(&ngroups, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
     SSA_HIP(hipStreamSynchronize(StreamHandle));
-    const int64_t ngroups = int64_t(ngroupsU);
-    SSA_HIP(hipMemsetAsync(counter->Ptr, 0, 8, StreamHandle));
 
     // next call on this step: size both table levels for what was seen
-    hint.TableCap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(ngroups) * 4), 1024), maxCap);
-    hint.LdsCap = ngroups <= 8 ? 16 : (ngroups <= 128 ? 256 : 0);
+    hint.TableCap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(ngroups) * 2), 1024), maxCap);  // load 0.25 .. 0.5
+    hint.LdsCap = ngroups <= 8 ? 16 : (ngroups <= 128 ? 256 : -1);
 
     KeyedFinalizeArgs fa{};
     fa.capacity = cap;
@@ -1483,7 +1489,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     fa.t_key_hi = sink.t_key_hi;
     fa.t_acc = sink.t_acc;
     fa.t_seen = sink.t_seen;
-    fa.counter = static_cast<unsigned long long*>(counter->Ptr);
+    fa.tile_offsets = static_cast<const int64_t*>(tileOffsets->Ptr);
     fa.t_rep_row = sink.t_rep_row;
     fa.naggs = naggsUser;
     fa.nkeys = nkeys;

@@ -10,22 +10,49 @@ namespace ssa {
 namespace {
 
 // ---- table -> output columns -------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void KeyedCountKernel(const uint64_t* tLo, uint64_t capacity, unsigned long long* count) {
-    unsigned long long c = 0;
-    for (uint64_t i = uint64_t(blockIdx.x) * kBlock + threadIdx.x; i < capacity; i += uint64_t(gridDim.x) * kBlock) {
-        c += tLo[i] != kEmpty ? 1u : 0u;
-    }
+// The groups leave the table in slot order: occupied slots are counted per tile of kTileRows slots, the counts are
+// scanned, and the emit pass places every group at tile offset + rank inside the tile.  (One shared output counter
+// would be hit once per wave -- a million same-address updates for a table of 64 M slots.)  The capacity is a power of
+// two of at least kTileRows slots.
+__global__ __launch_bounds__(kBlock) void KeyedTileCountKernel(const uint64_t* tLo, uint64_t capacity, uint32_t* tileCounts) {
+    __shared__ uint32_t waveCount[kBlock / 64];
+    const uint64_t ntiles = capacity / kTileRows;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t c = 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+        for (int u = 0; u < kRowsPerThread; ++u) c += uint32_t(__popcll(__ballot(tLo[tile * kTileRows + u * kBlock + threadIdx.x] != kEmpty)));
+        if ((threadIdx.x & 63) == 0) waveCount[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) tileCounts[tile] = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArgs) {
     const KeyedFinalizeArgs& f = KernArgsAs<KeyedFinalizeArgs>();
-    for (uint64_t i = uint64_t(blockIdx.x) * kBlock + threadIdx.x; i < f.capacity; i += uint64_t(gridDim.x) * kBlock) {
-        const uint64_t klo = f.t_key_lo[i];
+    __shared__ uint32_t wordCount[kTileRows / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t ntiles = f.capacity / kTileRows;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t tileFirst = f.tile_offsets[tile];
+        if (f.tile_offsets[tile + 1] == tileFirst) continue;  // (the same for the whole workgroup)
+        // word w of the tile = slots 64 w .. 64 w + 63; this wave owns words u * 4 + wave
+        uint64_t klos[kRowsPerThread], taken[kRowsPerThread];
+#pragma unroll
+        for (int u = 0; u < kRowsPerThread; ++u) {
+            klos[u] = f.t_key_lo[tile * kTileRows + u * kBlock + threadIdx.x];
+            taken[u] = __ballot(klos[u] != kEmpty);
+            if (lane == 0) wordCount[u * (kBlock / 64) + wave] = uint32_t(__popcll(taken[u]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kRowsPerThread; ++u) {
+        const uint64_t klo = klos[u];
+        const uint64_t i = tile * kTileRows + u * kBlock + threadIdx.x;
+        uint32_t before = 0;
+        for (int w = 0; w < u * (kBlock / 64) + wave; ++w) before += wordCount[w];
         if (klo == kEmpty) continue;
-        const int64_t g = int64_t(atomicAdd(f.counter, 1ull));  // output order is unspecified
+        const int64_t g = tileFirst + before + __popcll(taken[u] & ((1ull << lane) - 1ull));
         const uint32_t seen = f.t_seen[i];
         if (f.group_rep_row != nullptr) f.group_rep_row[g] = f.t_rep_row[i];
         for (int k = 0; k < f.naggs; ++k) {
@@ -70,6 +97,8 @@ __global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArg
                 }
             }
         }
+        }  // slots of this thread
+        __syncthreads();  // wordCount is rewritten for the next tile
     }
 }
 
@@ -165,13 +194,16 @@ hipError_t ConfigureKeyedKernels(int maxLdsBytes) {
     return e;
 }
 
-hipError_t LaunchKeyedCount(const uint64_t* tKeyLo, uint64_t capacity, unsigned long long* count, hipStream_t st) {
-    hipLaunchKernelGGL(KeyedCountKernel, dim3(GridFor(int64_t(capacity))), dim3(kBlock), 0, st, tKeyLo, capacity, count);
+hipError_t LaunchKeyedTileCount(const uint64_t* tKeyLo, uint64_t capacity, uint32_t* tileCounts, hipStream_t st) {
+    const uint64_t ntiles = capacity / kTileRows;
+    hipLaunchKernelGGL(KeyedTileCountKernel, dim3(uint32_t(ntiles < uint64_t(kMaxGrid) ? ntiles : uint64_t(kMaxGrid))), dim3(kBlock), 0, st,
+                       tKeyLo, capacity, tileCounts);
     return hipGetLastError();
 }
 
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(KeyedEmitKernel, dim3(GridFor(int64_t(a.capacity))), dim3(kBlock), 0, st, a);
+    const uint64_t ntiles = a.capacity / kTileRows;
+    hipLaunchKernelGGL(KeyedEmitKernel, dim3(uint32_t(ntiles < uint64_t(kMaxGrid) ? ntiles : uint64_t(kMaxGrid))), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
 

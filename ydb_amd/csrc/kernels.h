@@ -66,6 +66,11 @@ struct KeyedSink {
     uint64_t* t_rep_row;     // [cap] hashed keys: smallest representative row index seen for the group (~0 = none)
     int32_t hot_kind[kHotAggs];  // register path of accumulator k (HotKind)
     int32_t hot_off[kHotAggs];   // LDS byte offset of its 64-bit operand tile
+    // High-cardinality groupings: level 1 only takes the first few groups a workgroup meets (the register-held ones) and
+    // every other row goes straight to level 2.  What it buys is the heavy hitter of a skewed key (an empty search
+    // phrase, a default id): its rows add up in registers instead of queueing on one address in HBM.
+    int32_t hot_only;
+    int32_t reserved;
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.
@@ -127,7 +132,7 @@ struct KeyedFinalizeArgs {
     const uint64_t* t_acc;
     const uint32_t* t_seen;
     const uint64_t* t_rep_row;
-    unsigned long long* counter;      // zeroed; ends as the number of groups
+    const int64_t* tile_offsets;      // [capacity / kTileRows + 1] groups in the tiles before each tile of slots
     int32_t naggs;                    // output aggregates (the step's GroupBy list)
     int32_t nkeys;
     int32_t two_words;
@@ -146,7 +151,8 @@ struct KeyedFinalizeArgs {
 };
 uint64_t KeyedTableIdentity(int aggKind);  // initial value of a level-2 accumulator
 hipError_t ConfigureKeyedKernels(int maxLdsBytes);
-hipError_t LaunchKeyedCount(const uint64_t* t_key_lo, uint64_t capacity, unsigned long long* count, hipStream_t st);
+// tile_counts[t] = occupied slots among slots [t * kTileRows, (t + 1) * kTileRows); capacity is a multiple of kTileRows
+hipError_t LaunchKeyedTileCount(const uint64_t* t_key_lo, uint64_t capacity, uint32_t* tile_counts, hipStream_t st);
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st);
 // out[i] = (lo32[i] + (mid32[i] << 32) + (hi[i] << 64)) mod 2^128 as two little-endian 64-bit words.
 hipError_t LaunchCombineDecimal(const uint64_t* lo32, const uint64_t* mid32, const uint64_t* hi, int64_t n, uint64_t* out,

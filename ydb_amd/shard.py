@@ -273,15 +273,18 @@ class ShardedScan:
     # partial tables larger than this go through the hash-partitioned exchange
     ALL_TO_ALL_GROUPS = 65536
 
-    def run(self, batch, gather_device=None, exchange: str = "auto") -> Dict[str, ResultColumn]:
+    def run(self, batch, gather_device=None, exchange: str = "auto", keep_on_device: bool = False):
         """Local scan (HBM-resident `batch`), then -- when torch.distributed is initialised with more than one rank --
         the exchange of the partial tables and the merge program.  exchange = "allgather": every rank ends with the
         whole result; "alltoall": every rank ends with the groups whose key hash it owns (their union is the result);
         "auto": all-to-all once any rank's partial table exceeds ALL_TO_ALL_GROUPS rows."""
         import torch.distributed as dist
 
+        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if single and keep_on_device:
+            return self.local.ApplyDevice(batch)  # the result batch stays in HBM (one rank, nothing to exchange)
         partial = self.local.Export(self.local.ApplyDevice(batch))
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if single:
             return partial
         if self.merge is None:
             raise ValueError("sharded scan without aggregation: results stay on their shards")
