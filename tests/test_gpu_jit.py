@@ -125,3 +125,30 @@ def test_small_scans_and_ssa_jit_0_stay_on_the_generic_kernels(monkeypatch):
         got, exp = P.both(P.LI, p, batch)
         compare_batches(got, exp, float_sum_names=["130"])
         assert _stats() == before
+
+
+@pytest.mark.parametrize("n", [1, 4095, 4096, 4097, 16_385, 300_007])
+def test_narrow_keyless_aggregates_take_wide_tiles(forced, n):
+    """Key-less aggregates over a few narrow columns are built with 8 or 16 rows per thread (tiles of 2048 / 4096 rows):
+    sums, counts, min / max and a filter over int16 / int32 / int64 columns without nulls, against the oracle."""
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import AGG, YQL, Aggregate, Program
+    rng = np.random.default_rng(n)
+    batch = {"a": rng.integers(-3, 30, n).astype(np.int16), "w": rng.integers(0, 2000, n).astype(np.int16),
+             "d": rng.integers(15000, 16000, n).astype(np.int32), "u": rng.integers(-2**62, 2**62, n).astype(np.int64)}
+    resolver = [(1, "a"), (2, "w"), (3, "d"), (4, "u")]
+    progs = [
+        (Program(version=5).assign_const(10, "Int32", 0).assign_yql(11, YQL.NotEquals, [1, 10]).filter(11)
+         .group_by([Aggregate(12, AGG.COUNT, [])]).project([12]), ["a"]),                                   # 2 bytes per row: 16 rows per thread
+        (Program().group_by([Aggregate(10, AGG.SUM, [2]), Aggregate(11, AGG.COUNT, [2]), Aggregate(12, AGG.SUM, [1])]), ["a", "w"]),
+        (Program().group_by([Aggregate(10, AGG.MIN, [3]), Aggregate(11, AGG.MAX, [3])]), ["d"]),
+        (Program().group_by([Aggregate(10, AGG.SUM, [4]), Aggregate(11, AGG.MAX, [4]), Aggregate(12, AGG.MIN, [1])]), ["a", "u"]),  # 10 bytes: 8 rows
+        (Program().assign_func(10, 14, [1, 2]).group_by([Aggregate(11, AGG.SUM, [10]), Aggregate(12, AGG.COUNT, [])]), ["a", "w"]),  # a temporary: 8 rows
+    ]
+    for prog, cols in progs:
+        b = {c: batch[c] for c in cols}
+        pc = ProgramContainer()
+        ok, err = pc.Init(resolver, prog)
+        assert ok, err
+        compare_batches(pc.ApplyProgram(b), ssa_oracle.Oracle(resolver, prog).apply(b))

@@ -607,6 +607,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     if (const char* dbg = std::getenv("SSA_DEBUG_FLAGS")) args.debug_flags = std::atoi(dbg);
     algoBytes = 0;
     int lds = 0;
+    const int kTileRows = kBlock * ScanRowsPerThread;  // rows of one tile of the kernel these arguments are for
     for (int c = 0; c < args.ncols; ++c) {
         const Column& col = in.Cols[size_t(plan.SourceColumns[size_t(c)])];
         DevColumn& d = args.cols[c];
@@ -828,7 +829,8 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
         }
         return nullptr;
     }
-    const int64_t ntiles = (rows + kTileRows - 1) / kTileRows;
+    const int64_t tileRows = int64_t(kBlock) * ScanRowsPerThread;
+    const int64_t ntiles = (rows + tileRows - 1) / tileRows;
     // Three resident workgroups per CU have measured best for these kernels at SF100 (a grid of 4 x 256 workgroups --
     // tile strides of a power of two -- is the slowest choice, 5 x 256 again close to 3 x 256).
     int perCU = std::max(1, std::min(3, k.BlocksPerCU));
@@ -1009,6 +1011,24 @@ Status Executor::RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, Bu
     return Status::OK();
 }
 
+// Rows per thread of a kernel built for a key-less aggregation: 16 when the staged source columns add up to at most 8
+// bytes per row and the program keeps no temporaries, 8 up to 16 bytes per row, else the library's 4.  (The validity
+// bits of a temporary's rows share one byte per thread: 8 rows at most.)
+int Executor::WideRowsPerThread(const StepPlan& plan, const Batch& in) const {
+    if (std::getenv("SSA_NO_WIDE_TILES")) return kRowsPerThread;
+    int bytes = 0;
+    for (size_t c = 0; c < plan.SourceColumns.size(); ++c) {
+        const Column& col = in.Cols[size_t(plan.SourceColumns[c])];
+        if (IsStringLike(col.Field.Type) || col.Field.Type == T_DEC128 || col.Field.Type == T_BOOL || col.Validity) return kRowsPerThread;
+        bytes += StageWidth(col.Field.Type);
+    }
+    bytes += 8 * plan.NumRegsUsed;
+    if (bytes == 0) return kRowsPerThread;
+    if (bytes <= 8 && plan.NumRegsUsed == 0) return 16;
+    if (bytes <= 16) return 8;
+    return kRowsPerThread;
+}
+
 Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) {
     ScanArgs args;
     LaunchCfg cfg;
@@ -1024,8 +1044,33 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
     // a scan of many rows runs the kernel built for this step program, when that can be had
     hipFunction_t spec = nullptr;
     if (JitEnabled()) {
-        const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n";
-        spec = SpecializedKernel("nokey_scan.h", "ssa_spec_nokey", defines, args, &sink, sizeof(sink), in.Rows, cfg);
+        // Narrow rows: a tile of 1024 rows is a few KB and the per-tile work (staging, waits, loop) outweighs the rows'.
+        // The built kernel then takes 8 or 16 rows per thread; its LDS plan is made for that tile size.
+        const int wide = WideRowsPerThread(plan, in);
+        if (wide != kRowsPerThread) {
+            ScanArgs wargs;
+            LaunchCfg wcfg;
+            int64_t wbytes;
+            ScanRowsPerThread = wide;
+            if (FillScanArgs(plan, in, naggs * kBlock * 8, SCAN_NOKEY, wargs, wcfg, wbytes).ok()) {
+                NoKeySink wsink = sink;
+                for (int k = 0; k < naggs; ++k) {
+                    if (wsink.aggs[k].reg != -1) EncodeOperand(wargs, wsink.aggs[k].reg, wsink.aggs[k].fetch_kind, wsink.aggs[k].fetch_payload);
+                }
+                const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(wide) + "\n";
+                spec = SpecializedKernel("nokey_scan.h", "ssa_spec_nokey", defines, wargs, &wsink, sizeof(wsink), in.Rows, wcfg);
+                if (spec) {
+                    args = wargs;
+                    cfg = wcfg;
+                    sink = wsink;
+                }
+            }
+            ScanRowsPerThread = kRowsPerThread;
+        }
+        if (!spec) {
+            const std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n";
+            spec = SpecializedKernel("nokey_scan.h", "ssa_spec_nokey", defines, args, &sink, sizeof(sink), in.Rows, cfg);
+        }
     }
     BufferPtr partial = Buffer::Alloc(size_t(cfg.grid) * kMaxAggs * 8);
     BufferPtr seen = Buffer::Alloc(size_t(cfg.grid) * 4);

@@ -146,6 +146,7 @@ private:
                            int64_t& selected);
     Status FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLdsBytes, int kernelId, ScanArgs& args,
                         LaunchCfg& cfg, int64_t& algoBytes);
+    int WideRowsPerThread(const StepPlan& plan, const Batch& in) const;
     hipFunction_t SpecializedKernel(const char* header, const char* entry, const std::string& defines, const ScanArgs& args,
                                     const void* sinkImage, size_t sinkBytes, int64_t rows, LaunchCfg& cfg);
     hipError_t LaunchSpecialized(hipFunction_t fn, const ScanArgs& args, const void* sink, size_t sinkBytes, const LaunchCfg& cfg);
@@ -159,6 +160,7 @@ private:
     void ProfileEnd(const char* kernel, int64_t algoBytes);
 
     int Device;
+    int ScanRowsPerThread = kRowsPerThread;  // rows per thread of the kernel FillScanArgs / SpecializedKernel plan for
     hipStream_t StreamHandle = nullptr;
     hipEvent_t EvStart = nullptr, EvStop = nullptr;
     BufferPtr StatusWord;   // device uint32
