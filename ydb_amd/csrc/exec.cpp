@@ -745,7 +745,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     for (int c = 0; c < args.ncols && !noTuning; ++c) {
         if (!IsStringLike(args.cols[c].type) || args.lds_col_off[c] < 0) continue;
         if (reinterpret_cast<uintptr_t>(args.cols[c].chars) & 15) continue;  // chunks are copied from 16-byte aligned addresses
-        const int bytes = (kBlock / 64) * kCharsStageBytes;
+        const int bytes = (kBlock / 64) * CharsStageBytes(ScanRowsPerThread);
         if (kLdsPerCU / (lds + sinkLdsBytes + 1024) != kLdsPerCU / (lds + bytes + sinkLdsBytes + 1024)) continue;
         args.lds_chars_off[c] = lds;
         lds += bytes;
@@ -1404,44 +1404,73 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     if (L == 0) R = 1;
     const int sinkLds = L * 24 + 64 + naggs * L * R * 8 + L * 8 + 16;
 
+    // Scan arguments and sink description for a kernel that takes `rowsPerThread` rows per thread (the LDS plan, and with
+    // it every operand offset in the sink, belongs to one tile size).
+    int64_t algoBytes = 0;
+    auto describe = [&](int rowsPerThread, ScanArgs& args, LaunchCfg& cfg, KeyedSink& sink) -> Status {
+        ScanRowsPerThread = rowsPerThread;
+        Status st = FillScanArgs(plan, in, sinkLds, hashed ? SCAN_KEYED_HASHED : SCAN_KEYED_EXACT, args, cfg, algoBytes);
+        ScanRowsPerThread = kRowsPerThread;
+        if (!st.ok()) return st;
+        sink = KeyedSink{};
+        sink.naggs = naggs;
+        sink.nkeys = nkeys;
+        for (int k = 0; k < naggs; ++k) {
+            sink.aggs[k] = phys[size_t(k)];
+            if (sink.aggs[k].reg != -1) EncodeOperand(args, sink.aggs[k].reg, sink.aggs[k].fetch_kind, sink.aggs[k].fetch_payload);
+        }
+        for (int k = 0; k < nkeys; ++k) {
+            sink.keys[k] = plan.Keys[size_t(k)].Spec;
+            if (sink.keys[k].col < 0) EncodeOperand(args, sink.keys[k].reg, sink.keys[k].fetch_kind, sink.keys[k].fetch_payload);
+        }
+        sink.two_words = twoWords;
+        sink.hashed = hashed;
+        sink.lds_cap = L;
+        sink.lds_rep = R;
+        sink.hot_only = (hotOnly && L >= 4) ? 1 : 0;
+        for (int k = 0; k < kHotAggs && k < naggs; ++k) {
+            const AggSpec& a = sink.aggs[k];
+            if (a.check_valid) continue;
+            if (a.kind == AGG_COUNT && a.reg == -1) {
+                sink.hot_kind[k] = HOT_ROWS;
+                continue;
+            }
+            if (a.kind != AGG_SUM_F && a.kind != AGG_SUM_I) continue;
+            int off = -1;
+            if (a.reg >= 0) {
+                off = args.lds_reg_offs[a.reg];  // R registers hold 64-bit payloads
+            } else if (a.reg <= -2 && (a.fetch_kind & 0x7F) == FK_LDS_64) {
+                const int t = args.cols[-2 - a.reg].type;
+                if ((a.kind == AGG_SUM_F) == (t == T_F64)) off = int(a.fetch_payload & 0xFFFFFFu);
+            }
+            if (off < 0) continue;
+            sink.hot_kind[k] = a.kind == AGG_SUM_F ? HOT_SUM_F64 : HOT_SUM_I64;
+            sink.hot_off[k] = off;
+        }
+
+        return Status::OK();
+    };
     ScanArgs args;
     LaunchCfg cfg;
-    int64_t algoBytes = 0;
-    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, sinkLds, hashed ? SCAN_KEYED_HASHED : SCAN_KEYED_EXACT, args, cfg, algoBytes));
     KeyedSink sink{};
-    sink.naggs = naggs;
-    sink.nkeys = nkeys;
-    for (int k = 0; k < naggs; ++k) {
-        sink.aggs[k] = phys[size_t(k)];
-        if (sink.aggs[k].reg != -1) EncodeOperand(args, sink.aggs[k].reg, sink.aggs[k].fetch_kind, sink.aggs[k].fetch_payload);
-    }
-    for (int k = 0; k < nkeys; ++k) {
-        sink.keys[k] = plan.Keys[size_t(k)].Spec;
-        if (sink.keys[k].col < 0) EncodeOperand(args, sink.keys[k].reg, sink.keys[k].fetch_kind, sink.keys[k].fetch_payload);
-    }
-    sink.two_words = twoWords;
-    sink.hashed = hashed;
-    sink.lds_cap = L;
-    sink.lds_rep = R;
-    sink.hot_only = (hotOnly && L >= 4) ? 1 : 0;
-    for (int k = 0; k < kHotAggs && k < naggs; ++k) {
-        const AggSpec& a = sink.aggs[k];
-        if (a.check_valid) continue;
-        if (a.kind == AGG_COUNT && a.reg == -1) {
-            sink.hot_kind[k] = HOT_ROWS;
-            continue;
+    SSA_RETURN_NOT_OK(describe(kRowsPerThread, args, cfg, sink));
+    // The kernel built for this step program may take another number of rows per thread (experiments: SSA_KEYED_U; with
+    // string keys 2 rows per thread measured 20 % slower than 4 on TPC-H Q1 -- the per-tile work outweighs the occupancy).
+    int specRows = kRowsPerThread;
+    if (const char* env = std::getenv("SSA_KEYED_U")) specRows = std::atoi(env);
+    if (specRows != 1 && specRows != 2 && specRows != 4 && specRows != 8) specRows = kRowsPerThread;
+    ScanArgs sargs = args;
+    LaunchCfg scfg = cfg;
+    KeyedSink ssink = sink;
+    if (specRows != kRowsPerThread && JitEnabled()) {
+        if (!describe(specRows, sargs, scfg, ssink).ok()) {
+            specRows = kRowsPerThread;
+            sargs = args;
+            scfg = cfg;
+            ssink = sink;
         }
-        if (a.kind != AGG_SUM_F && a.kind != AGG_SUM_I) continue;
-        int off = -1;
-        if (a.reg >= 0) {
-            off = args.lds_reg_offs[a.reg];  // R registers hold 64-bit payloads
-        } else if (a.reg <= -2 && (a.fetch_kind & 0x7F) == FK_LDS_64) {
-            const int t = args.cols[-2 - a.reg].type;
-            if ((a.kind == AGG_SUM_F) == (t == T_F64)) off = int(a.fetch_payload & 0xFFFFFFu);
-        }
-        if (off < 0) continue;
-        sink.hot_kind[k] = a.kind == AGG_SUM_F ? HOT_SUM_F64 : HOT_SUM_I64;
-        sink.hot_off[k] = off;
+    } else {
+        specRows = kRowsPerThread;
     }
 
     if (std::getenv("SSA_DEBUG_PLAN")) {
@@ -1467,30 +1496,34 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             if (ident == 0) SSA_HIP(hipMemsetAsync(base, 0, cap * 8, StreamHandle));
             else SSA_HIP(LaunchFill(base, 8, ident, int64_t(cap), StreamHandle));
         }
-        sink.table_mask = cap - 1;
-        sink.t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
-        sink.t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
-        sink.t_acc = static_cast<uint64_t*>(tAcc->Ptr);
-        sink.t_seen = static_cast<uint32_t*>(tSeen->Ptr);
-        sink.t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
+        for (KeyedSink* k : {&sink, &ssink}) {
+            k->table_mask = cap - 1;
+            k->t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
+            k->t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
+            k->t_acc = static_cast<uint64_t*>(tAcc->Ptr);
+            k->t_seen = static_cast<uint32_t*>(tSeen->Ptr);
+            k->t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
+        }
         if (in.Rows > 0) {
             // a scan of many rows runs the kernel built for this step program, when that can be had
             hipFunction_t spec = nullptr;
-            LaunchCfg specCfg = cfg;
+            LaunchCfg specCfg = scfg;
             if (JitEnabled()) {
-                KeyedSink image = sink;
+                KeyedSink image = ssink;
                 image.t_key_lo = image.t_key_hi = image.t_acc = nullptr;
                 image.t_seen = nullptr;
                 image.t_rep_row = nullptr;
                 image.table_mask = 0;
-                std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(kRowsPerThread) + "\n#define SSA_SPEC_HASHED " +
+                std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(specRows) + "\n#define SSA_SPEC_HASHED " +
                                       (hashed ? "1" : "0") + "\n";
                 if (std::getenv("SSA_PHASE_TIMING")) defines += "#define SSA_PHASE_TIMING 1\n";  // diagnostics
-                spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, args, &image, sizeof(image), in.Rows, specCfg);
+                ScanRowsPerThread = specRows;
+                spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, sargs, &image, sizeof(image), in.Rows, specCfg);
+                ScanRowsPerThread = kRowsPerThread;
             }
             ProfileBegin();
             if (spec) {
-                SSA_HIP(LaunchSpecialized(spec, args, &sink, sizeof(sink), specCfg));
+                SSA_HIP(LaunchSpecialized(spec, sargs, &ssink, sizeof(ssink), specCfg));
             } else {
                 SSA_HIP(LaunchScanKeyed(args, sink, cfg));
             }

@@ -246,7 +246,7 @@ struct Machine {
         tConstValid = uint32_t(a.consts[k].valid);
         tColStageW = uint32_t(StageWidth(a.cols[c].type));
         tColCharsLds = a.lds_chars_off[c] < 0 ? 0xFFFFFFFFu
-                                              : uint32_t(a.lds_chars_off[c]) + (threadIdx.x >> 6) * uint32_t(kCharsStageBytes);
+                                              : uint32_t(a.lds_chars_off[c]) + (threadIdx.x >> 6) * uint32_t(CharsStageBytes(U));
         tColEndOff = a.lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(a.lds_end_off[c]) + (threadIdx.x >> 6) * 16u;
         boundsFirst = boundsLast = 0;
         boundsTile = -1;
@@ -284,7 +284,7 @@ struct Machine {
     }
     __device__ __forceinline__ uint32_t ColCharsLds(int c) const {
         if (!kStatic) return ReadLane32(tColCharsLds, c);
-        return S().lds_chars_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_chars_off[c]) + uint32_t(waveBase / (64 * U)) * uint32_t(kCharsStageBytes);
+        return S().lds_chars_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_chars_off[c]) + uint32_t(waveBase / (64 * U)) * uint32_t(CharsStageBytes(U));
     }
     __device__ __forceinline__ uint32_t ColEndOff(int c) const {
         if (!kStatic) return ReadLane32(tColEndOff, c);
@@ -392,7 +392,7 @@ struct Machine {
                 if (endb > limit) endb = limit;
                 skew = uint32_t(reinterpret_cast<uintptr_t>(chars + b0) & 15u);
                 // the copy moves whole 16-byte chunks: it must fit the area and stay inside the chars buffer
-                if (endb > b0 && endb - b0 + skew <= uint32_t(kCharsStageBytes - 16) &&
+                if (endb > b0 && endb - b0 + skew <= uint32_t(CharsStageBytes(U) - 16) &&
                     uint64_t(b0 - skew) + ((uint64_t(endb - b0 + skew) + 15u) & ~15ull) <= uint64_t(limit)) {
                     begin = b0;
                     bytes = endb - b0;

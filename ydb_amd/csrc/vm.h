@@ -83,7 +83,8 @@ SSA_HD int TypeWidth(int t) {  // bytes of one fixed-width value, 0 for bit-pack
 
 // Bytes of string data a wave can stage per string column and tile: its rows' strings from the first row's start to
 // 8 bytes past the last row's start (enough for every string of up to 8 bytes when the average is 8), plus alignment slack.
-constexpr int kCharsStageBytes = 64 * 4 * 8 + 32;
+// Head area of one wave and string column: 8 bytes for each of its 64 x U rows, the copy's alignment skew and slack.
+SSA_HD constexpr int CharsStageBytes(int rowsPerThread) { return 64 * rowsPerThread * 8 + 32; }
 
 // Bytes per row of the buffer a scan stages into LDS: the values of a fixed-width column, the int32 offsets of a
 // string column (0: nothing to stage).
@@ -277,7 +278,7 @@ struct ScanArgs {
     uint32_t* status;        // device word, OR-ed with ScanStatus bits
     // LDS plan of one workgroup (byte offsets into dynamic shared memory)
     int32_t lds_col_off[kMaxCols];  // staged tile of column c, or -1: read from global memory on demand
-    int32_t lds_chars_off[kMaxCols]; // string column c: staging area of the heads of its strings (kCharsStageBytes per wave), or -1
+    int32_t lds_chars_off[kMaxCols]; // string column c: staging area of the heads of its strings (CharsStageBytes(U) per wave), or -1
     int32_t lds_reg_offs[kMaxRegs]; // R register r: tile rows x 8 bytes at this offset (may reuse a dead staged column)
     int32_t lds_regok_off;          // R register validity: nregs x lanes bytes
     int32_t nregs;
