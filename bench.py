@@ -25,7 +25,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
-PMC_TRAFFIC_FILE = "r1_c_pmc_traffic.json"  # FETCH_SIZE passes of the scan kernels, as ratios to the algorithmic bytes
+PMC_TRAFFIC_FILE = "r1_d_pmc_traffic.json"  # FETCH_SIZE passes of the scan kernels, as ratios to the algorithmic bytes
 
 
 def cpu_baseline(workload: str, seconds_target: float = 15.0):
