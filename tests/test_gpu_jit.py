@@ -152,3 +152,24 @@ def test_narrow_keyless_aggregates_take_wide_tiles(forced, n):
         ok, err = pc.Init(resolver, prog)
         assert ok, err
         compare_batches(pc.ApplyProgram(b), ssa_oracle.Oracle(resolver, prog).apply(b))
+
+
+@pytest.mark.parametrize("n", [1, 2047, 2049, 250_003])
+def test_narrow_group_by_takes_wide_tiles(forced, n):
+    """A filter and a small integer key over narrow columns: the keyed kernel is built with 8 rows per thread."""
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import AGG, YQL, Aggregate, Program
+    rng = np.random.default_rng(n + 3)
+    batch = {"a": np.where(rng.random(n) < 0.9, 0, rng.integers(1, 31, n)).astype(np.int16), "w": rng.integers(0, 2000, n).astype(np.int16)}
+    resolver = [(1, "a"), (2, "w")]
+    progs = [
+        Program().assign_const(10, "Int32", 0).assign_yql(11, YQL.NotEquals, [1, 10]).filter(11).group_by([Aggregate(12, AGG.COUNT, [])], keys=[1]),
+        Program().group_by([Aggregate(12, AGG.COUNT, []), Aggregate(13, AGG.SUM, [2]), Aggregate(14, AGG.MAX, [2])], keys=[1]),
+        Program().group_by([Aggregate(12, AGG.COUNT, []), Aggregate(13, AGG.MIN, [1])], keys=[2]),   # 2000 groups
+    ]
+    for prog, key in zip(progs, ("a", "a", "w")):
+        pc = ProgramContainer()
+        ok, err = pc.Init(resolver, prog)
+        assert ok, err
+        compare_batches(pc.ApplyProgram(batch), ssa_oracle.Oracle(resolver, prog).apply(batch), key_names=[key])

@@ -1,0 +1,7 @@
+run() { python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e9,1),'Grows/s', round(d['roofline']['achieved']),'GB/s', round(d['roofline']['avg_kernel_ms'],3),'ms')"; }
+for u in 4 8; do for b in 3 4; do
+  echo "== cb_adv U=$u blocks $b"; SSA_KEYED_U=$u SSA_SPEC_BLOCKS_PER_CU=$b timeout -k 10 200 python -u bench.py --workload cb_adv --rows 1000000000 --no-cpu-baseline --steps 5 2>gpurun_out/adv.err | run || { tail -3 gpurun_out/adv.err; exit 1; }
+done; done
+for u in 8; do
+  echo "== q1_codes U=$u"; SSA_KEYED_U=$u timeout -k 10 200 python -u bench.py --workload q1_codes --no-cpu-baseline --steps 5 2>gpurun_out/adv.err | run || { tail -3 gpurun_out/adv.err; exit 1; }
+done

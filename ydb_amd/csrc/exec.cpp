@@ -1457,8 +1457,10 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     // The kernel built for this step program may take another number of rows per thread (experiments: SSA_KEYED_U; with
     // string keys 2 rows per thread measured 20 % slower than 4 on TPC-H Q1 -- the per-tile work outweighs the occupancy).
     int specRows = kRowsPerThread;
+    // narrow rows with exact keys (a filter and a small integer key): 8 rows per thread, as the key-less kernels do
+    if (!hashed && plan.NumRegsUsed == 0 && WideRowsPerThread(plan, in) >= 8) specRows = 8;
     if (const char* env = std::getenv("SSA_KEYED_U")) specRows = std::atoi(env);
-    if (specRows != 1 && specRows != 2 && specRows != 4 && specRows != 8) specRows = kRowsPerThread;
+    if (specRows != 1 && specRows != 2 && specRows != 4 && specRows != 8 && specRows != 16) specRows = kRowsPerThread;
     ScanArgs sargs = args;
     LaunchCfg scfg = cfg;
     KeyedSink ssink = sink;

@@ -558,30 +558,41 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
             if (id >= 0 && useHot) slot[u] = id; else pending |= 1u << u;
         }
-        if (__any(pending != 0)) {
-        // rows of other groups (and of the first groups until their keys are known): one at a time through the tables
+        // Rows of other groups (and of the first groups until their keys are known) go through the tables.  Every trip
+        // of the loop takes each lane's next pending row, whichever of its U rows that is: behind a selective filter
+        // most lanes have none and the rest one, so the wave makes one or two trips instead of U.
+        while (__any(pending != 0)) {
+            const bool has = pending != 0;
+            const int pu = has ? __ffs(int(pending)) - 1 : 0;
+            pending &= pending - 1u;
+            uint64_t klo = kb.lo[0], khi = kb.hi[0];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!((pending >> u) & 1u)) continue;
-            const uint32_t h = Fold32(kb.lo[u], kb.hi[u]);
-            int64_t sl = -1;
-            if (L > 0 && !(hotOnly && hotKnown == kHotGroups)) {
-                sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, kb.lo[u], kb.hi[u], twoWords,
-                                    uint64_t(m.Row(u)), ldsProbes, hotOnly ? uint32_t(kHotGroups) : uint32_t(L));
+            for (int u = 1; u < U; ++u) {
+                klo = pu == u ? kb.lo[u] : klo;
+                khi = pu == u ? kb.hi[u] : khi;
             }
-            if (sl < 0) {
-                const int64_t g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, kb.lo[u], kb.hi[u], twoWords, 4096u);
-                if (g < 0) {
-                    m.err |= SCAN_TABLE_FULL;
-                    m.P &= ~(1u << u);
-                } else {
-                    sl = -2 - g;
-                    if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(m.Row(u)));
+            int64_t sl = -1;
+            if (has) {
+                const uint64_t row = uint64_t(m.Row(0)) + uint64_t(pu) * 64u;
+                const uint32_t h = Fold32(klo, khi);
+                if (L > 0 && !(hotOnly && hotKnown == kHotGroups)) {
+                    sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes,
+                                        hotOnly ? uint32_t(kHotGroups) : uint32_t(L));
+                }
+                if (sl < 0) {
+                    const int64_t g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, klo, khi, twoWords, 4096u);
+                    if (g < 0) {
+                        m.err |= SCAN_TABLE_FULL;
+                        m.P &= ~(1u << pu);
+                    } else {
+                        sl = -2 - g;
+                        if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(row));
+                    }
                 }
             }
-            slot[u] = sl;
+#pragma unroll
+            for (int u = 0; u < U; ++u) slot[u] = (has && pu == u) ? sl : slot[u];
         }
-        }  // pending rows
 
         SSA_T(3);
         // membership of the lane's rows in the register-held groups: bit u of hit[g]; as 0.0 / 1.0 factors for the
