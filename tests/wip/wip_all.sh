@@ -1,0 +1,7 @@
+run() { python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e9,1),'Grows/s', round(d['roofline']['achieved']),'GB/s', round(d['roofline']['avg_kernel_ms'],3),'ms')"; }
+for w in cb_q1 cb_q2 cb_q3 cb_q6 cb_adv; do
+  echo "== $w 1g"; timeout -k 10 200 python -u bench.py --workload $w --rows 1000000000 --no-cpu-baseline --steps 5 2>gpurun_out/adv.err | run || { tail -3 gpurun_out/adv.err; exit 1; }
+done
+for w in q6 q1_codes q1; do
+  echo "== $w"; timeout -k 10 200 python -u bench.py --workload $w --no-cpu-baseline --steps 10 2>gpurun_out/adv.err | run || { tail -3 gpurun_out/adv.err; exit 1; }
+done

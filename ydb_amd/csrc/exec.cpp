@@ -833,7 +833,15 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
     const int64_t ntiles = (rows + tileRows - 1) / tileRows;
     // Three resident workgroups per CU have measured best for these kernels at SF100 (a grid of 4 x 256 workgroups --
     // tile strides of a power of two -- is the slowest choice, 5 x 256 again close to 3 x 256).
-    int perCU = std::max(1, std::min(3, k.BlocksPerCU));
+    // Kernels whose tile is only a few KB (narrow rows) need more of them in flight: up to six workgroups so that a CU
+    // has about 48 KB of staged columns outstanding (ClickBench Q1, 2 B/row: 4.8 TB/s at three, 5.5 TB/s at six).
+    int64_t tileBytes = 0;
+    for (int c = 0; c < args.ncols; ++c) {
+        if (args.lds_col_off[c] >= 0) tileBytes += tileRows * StageWidth(args.cols[c].type);
+    }
+    int want = 3;
+    if (tileBytes > 0) want = int(std::max<int64_t>(3, std::min<int64_t>(6, (48 * 1024 + tileBytes - 1) / tileBytes)));
+    int perCU = std::max(1, std::min(want, k.BlocksPerCU));
     if (const char* pc = std::getenv("SSA_SPEC_BLOCKS_PER_CU")) perCU = std::max(1, std::min(8, std::atoi(pc)));  // experiments
     cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU));
     if (const char* g = std::getenv("SSA_SPEC_GRID")) cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), std::atoi(g)));  // experiments
