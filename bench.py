@@ -63,8 +63,35 @@ def cpu_baseline(workload: str, seconds_target: float = 15.0):
         dt = time.perf_counter() - t0
         if dt >= seconds_target or n >= 400:
             break
-    return {"value": n * batch_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": f"{n} x {batch_rows}-row batches of the same synthetic table, {dt:.1f} s, one thread"}
+    out = {"value": n * batch_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": f"{n} x {batch_rows}-row batches of the same synthetic table, {dt:.1f} s, one thread"}
+    # The reference runs one batch per Conveyor worker thread: the same loop on every core of this box's CPU share
+    # (the oracle is called through ctypes, which releases the interpreter lock), each thread with its own program.
+    import threading
+    cores = max(1, min(16, os.cpu_count() or 1))
+    per_thread = max(1, int(n * min(1.0, 8.0 / max(dt, 1e-3))))
+    workers = []
+    for _ in range(cores):
+        o = ssa_oracle.Oracle(resolver, prog)
+        workers.append((o, o.import_batch(batch)))
+    start = threading.Barrier(cores + 1)
+
+    def loop(o, h):
+        start.wait()
+        for _ in range(per_thread):
+            o.apply_imported(h)
+
+    threads = [threading.Thread(target=loop, args=w) for w in workers]
+    for t in threads:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in threads:
+        t.join()
+    pdt = time.perf_counter() - t0
+    out["all_cores"] = {"value": cores * per_thread * batch_rows / pdt, "unit": "rows/s", "cores": cores,
+                        "sample": f"{cores} threads x {per_thread} batches, {pdt:.1f} s"}
+    return out
 
 
 def main():
@@ -176,6 +203,7 @@ def main():
             pass
         from ydb_amd.shard import last_group_by
         keyed = bool(last_group_by(prog).keys)
+        groups = result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0)
         total_rows = rows * world * args.steps
         avg_kernel_s = (kernel_ms / 1e3) / max(1, launches)
         achieved = (algo_bytes / max(1, launches)) / avg_kernel_s / 1e9 if launches else 0.0
@@ -194,9 +222,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{name}, {table} per GPU ({rows} rows), whole shard as one HBM-resident batch",
                        "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr,
-                       "groups": result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0),
+                       "groups": groups,
                        "kernels_built_at_run_time": built, "kernel_build_ms_before_the_timed_steps": build_ms,
-                       "parallelism": f"row-range shards x{world}, partial aggregates merged by RCCL all-gather + merge program"},
+                       "parallelism": f"row-range shards x{world}, partial aggregates merged by " +
+                                      ("hash-partitioned point-to-point exchange" if world > 1 and groups > ShardedScan.ALL_TO_ALL_GROUPS
+                                       else "RCCL all-gather") + " + merge program"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          # the scan kernel built at run time for this program (same source as the generic
