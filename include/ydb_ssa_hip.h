@@ -103,7 +103,9 @@ int ssa_program_build_filter(ssa_program_t* program, size_t step_index, const st
 int ssa_batch_import(ssa_program_t* program, const struct ArrowArray* in, const struct ArrowSchema* in_schema,
                      ssa_batch_t** out, char** err);
 
-/* Column already in device memory (not copied, not owned; must outlive the batch). */
+/* Column already in device memory (not copied, not owned; must outlive the batch).  The library reads it on its own
+ * HIP stream: whatever produced the column (a copy, a kernel on another stream) must have completed before the batch is
+ * used. */
 struct ssa_device_column {
     const char* name;
     int32_t type;          /* enum ssa_type */

@@ -309,3 +309,58 @@ def test_filter_from_program_equals_build_filter(pc):
     ok, err = p3.Init([(1, "a"), (2, "b")], Program().project([2]))
     assert ok, err
     assert ColumnFilter.FromProgram(p3, p3.Import({"b": np.arange(4.0)}), 0) is None   # a step without a Filter command
+
+
+def test_full_size_properties_of_the_filter_algebra():
+    """600 M rows (TPC-H SF100 lineitem's row count): size-independent properties -- De Morgan through the counts,
+    And / Or against the program's own filters, CombineSequentialAnd against And on the same rows, Apply's row count,
+    the run-length form of a sorted key's range filter."""
+    import torch
+    from ydb_amd import tpch
+    from ydb_amd.column_filter import ColumnFilter
+    from ydb_amd.program import ProgramContainer, device_batch
+    n = tpch.SF100_ROWS
+    li = tpch.DeviceLineitem(n, utf8_flags=False, code_flags=False)
+    batch = li.batch(["l_shipdate", "l_quantity", "l_discount"])
+
+    ship = {name: cid for cid, name in tpch.LINEITEM_RESOLVER}
+
+    def program_filter(build):
+        prog = build(Program())
+        prog.project([tpch.LINEITEM_RESOLVER[0][0]])
+        pc = ProgramContainer()
+        ok, err = pc.Init(tpch.LINEITEM_RESOLVER, prog)
+        assert ok, err
+        return pc, ColumnFilter.FromProgram(pc, batch, 0)
+
+    pc, a = program_filter(lambda p: p.assign_const(900, "Int32", 9131).assign_func(901, F.CMP_GREATER_EQUAL, [Column(id=ship["l_shipdate"]), Column(id=900)]).filter(901))
+    _, b = program_filter(lambda p: p.assign_const(900, "Double", 25.0).assign_func(901, F.CMP_LESS, [Column(id=ship["l_quantity"]), Column(id=900)]).filter(901))
+    _, both_in_one = program_filter(lambda p: p.assign_const(900, "Int32", 9131).assign_func(901, F.CMP_GREATER_EQUAL, [Column(id=ship["l_shipdate"]), Column(id=900)]).filter(901)
+                                    .assign_const(902, "Double", 25.0).assign_func(903, F.CMP_LESS, [Column(id=ship["l_quantity"]), Column(id=902)]).filter(903))
+    na, nb = a.GetFilteredCount(), b.GetFilteredCount()
+    n_and, n_or = a.And(b).GetFilteredCount(), a.Or(b).GetFilteredCount()
+    assert a.Size() == n and 0 < na < n and 0 < nb < n
+    assert n_and + n_or == na + nb                                     # inclusion-exclusion
+    assert n_and == both_in_one.GetFilteredCount()                     # the step's own AND of its filters
+    # the same selection in two stages: b on the rows a keeps
+    stage = a.Apply(batch)
+    assert stage.rows == na
+    prog = Program().assign_const(900, "Double", 25.0).assign_func(901, F.CMP_LESS, [Column(id=ship["l_quantity"]), Column(id=900)]).filter(901)
+    prog.project([tpch.LINEITEM_RESOLVER[0][0]])
+    pc2 = ProgramContainer()
+    ok, err = pc2.Init(tpch.LINEITEM_RESOLVER, prog)
+    assert ok, err
+    b_on_a = ColumnFilter.FromProgram(pc2, stage, 0)
+    seq = a.CombineSequentialAnd(b_on_a)
+    assert seq.Size() == n and seq.GetFilteredCount() == n_and
+    assert seq.Or(a.And(b)).GetFilteredCount() == n_and and seq.And(a.And(b)).GetFilteredCount() == n_and   # the same bits
+    assert seq.Apply(batch).rows == n_and
+    # a sorted key: the range [lo, hi) is one run of kept rows between two runs of dropped ones
+    dev = torch.device("cuda", 0)
+    pk = torch.arange(n, dtype=torch.int64, device=dev) // 7
+    torch.cuda.synchronize(dev)  # torch fills the column on its own stream; the library reads it on another
+    keys = device_batch([("pk", 5, pk.data_ptr(), 0, 0, 0, 0)], n, keep=pk)
+    lo = ColumnFilter.MakePredicateFilter(pc, keys, {"pk": np.array([1000], dtype=np.int64)}, 4)
+    hi = ColumnFilter.MakePredicateFilter(pc, keys, {"pk": np.array([50_000_000], dtype=np.int64)}, 1)
+    runs, last = lo.And(hi).Runs()
+    assert runs.tolist() == [7000, 7 * (50_000_000 - 1000), n - 7 * 50_000_000] and last is False
