@@ -1496,16 +1496,6 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         tSeen = Buffer::Alloc(cap * 4);
         tRep = Buffer::Alloc(hashed ? cap * 8 : 64);
         if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
-        if (hashed) SSA_HIP(hipMemsetAsync(tRep->Ptr, 0xFF, cap * 8, StreamHandle));
-        SSA_HIP(hipMemsetAsync(tLo->Ptr, 0xFF, cap * 8, StreamHandle));
-        if (twoWords) SSA_HIP(hipMemsetAsync(tHi->Ptr, 0xFF, cap * 8, StreamHandle));
-        SSA_HIP(hipMemsetAsync(tSeen->Ptr, 0, cap * 4, StreamHandle));
-        for (int k = 0; k < naggs; ++k) {
-            uint64_t* base = static_cast<uint64_t*>(tAcc->Ptr) + size_t(k) * cap;
-            const uint64_t ident = KeyedTableIdentity(sink.aggs[k].kind);
-            if (ident == 0) SSA_HIP(hipMemsetAsync(base, 0, cap * 8, StreamHandle));
-            else SSA_HIP(LaunchFill(base, 8, ident, int64_t(cap), StreamHandle));
-        }
         for (KeyedSink* k : {&sink, &ssink}) {
             k->table_mask = cap - 1;
             k->t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
@@ -1514,6 +1504,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             k->t_seen = static_cast<uint32_t*>(tSeen->Ptr);
             k->t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
         }
+        SSA_HIP(LaunchKeyedTableInit(sink, twoWords != 0, hashed, StreamHandle));
         if (in.Rows > 0) {
             // a scan of many rows runs the kernel built for this step program, when that can be had
             hipFunction_t spec = nullptr;

@@ -9,6 +9,29 @@ namespace ssa {
 
 namespace {
 
+// ---- level-2 table set-up ----------------------------------------------------------------------------
+// Every array of the table in one launch: keys free, hi words unpublished, accumulators at their identities, seen
+// flags clear, representative rows none.
+struct KeyedTableInitArgs {
+    uint64_t capacity;
+    uint64_t* t_key_lo;
+    uint64_t* t_key_hi;   // nullptr: one-word keys
+    uint64_t* t_acc;
+    uint32_t* t_seen;
+    uint64_t* t_rep_row;  // nullptr: exact keys
+    int32_t naggs;
+    uint64_t ident[kMaxAggs];
+};
+__global__ __launch_bounds__(kBlock) void KeyedTableInitKernel(const KeyedTableInitArgs a) {
+    for (uint64_t i = uint64_t(blockIdx.x) * kBlock + threadIdx.x; i < a.capacity; i += uint64_t(gridDim.x) * kBlock) {
+        a.t_key_lo[i] = kEmpty;
+        if (a.t_key_hi != nullptr) a.t_key_hi[i] = kUnpublished;
+        if (a.t_rep_row != nullptr) a.t_rep_row[i] = ~0ull;
+        a.t_seen[i] = 0;
+        for (int k = 0; k < a.naggs; ++k) a.t_acc[uint64_t(k) * a.capacity + i] = a.ident[k];
+    }
+}
+
 // ---- table -> output columns -------------------------------------------------------------------------
 // The groups leave the table in slot order: occupied slots are counted per tile of kTileRows slots, the counts are
 // scanned, and the emit pass places every group at tile offset + rank inside the tile.  (One shared output counter
@@ -192,6 +215,20 @@ hipError_t ConfigureKeyedKernels(int maxLdsBytes) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ScanKeyedKernel<kRowsPerThread, false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
     return e;
+}
+
+hipError_t LaunchKeyedTableInit(const KeyedSink& sink, bool twoWords, bool hashed, hipStream_t st) {
+    KeyedTableInitArgs a{};
+    a.capacity = sink.table_mask + 1;
+    a.t_key_lo = sink.t_key_lo;
+    a.t_key_hi = twoWords ? sink.t_key_hi : nullptr;
+    a.t_acc = sink.t_acc;
+    a.t_seen = sink.t_seen;
+    a.t_rep_row = hashed ? sink.t_rep_row : nullptr;
+    a.naggs = sink.naggs;
+    for (int k = 0; k < sink.naggs; ++k) a.ident[k] = TableIdentity(sink.aggs[k].kind);
+    hipLaunchKernelGGL(KeyedTableInitKernel, dim3(GridFor(int64_t(a.capacity))), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t LaunchKeyedTileCount(const uint64_t* tKeyLo, uint64_t capacity, uint32_t* tileCounts, hipStream_t st) {

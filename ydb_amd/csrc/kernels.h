@@ -151,6 +151,8 @@ struct KeyedFinalizeArgs {
 };
 uint64_t KeyedTableIdentity(int aggKind);  // initial value of a level-2 accumulator
 hipError_t ConfigureKeyedKernels(int maxLdsBytes);
+// Free keys, identity accumulators, clear flags: every array of the level-2 table `sink` points at, in one launch.
+hipError_t LaunchKeyedTableInit(const KeyedSink& sink, bool two_words, bool hashed, hipStream_t st);
 // tile_counts[t] = occupied slots among slots [t * kTileRows, (t + 1) * kTileRows); capacity is a multiple of kTileRows
 hipError_t LaunchKeyedTileCount(const uint64_t* t_key_lo, uint64_t capacity, uint32_t* tile_counts, hipStream_t st);
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st);

@@ -101,6 +101,43 @@ __global__ __launch_bounds__(kBlock) void ScanOfBlockSumsKernel(int64_t* blockSu
     if (threadIdx.x == 0 && total != nullptr) *total = carry;
 }
 
+// Short inputs (one chunk): sums, scan and total in a single launch.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(kBlock) void ScanSingleChunkKernel(const TIn* in, int64_t n, TOut* out, int64_t* total, int appendTotal) {
+    __shared__ int64_t waveSums[kWaves];
+    const int64_t base = int64_t(threadIdx.x) * kScanItems;
+    int64_t vals[kScanItems];
+    int64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        vals[i] = base + i < n ? int64_t(in[base + i]) : 0;
+        sum += vals[i];
+    }
+    int64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int64_t t = int64_t(__shfl_up(static_cast<unsigned long long>(incl), off, 64));
+        if (LaneId() >= off) incl += t;
+    }
+    if (LaneId() == 63) waveSums[WaveId()] = incl;
+    __syncthreads();
+    int64_t waveOff = 0, all = 0;
+    for (int w = 0; w < kWaves; ++w) {
+        if (w < WaveId()) waveOff += waveSums[w];
+        all += waveSums[w];
+    }
+    int64_t run = waveOff + incl - sum;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) out[base + i] = TOut(run);
+        run += vals[i];
+    }
+    if (threadIdx.x == 0) {
+        if (total != nullptr) *total = all;
+        if (appendTotal) out[n] = TOut(all);
+    }
+}
+
 // out[i] = blockOffset + exclusive prefix inside the chunk.  When `appendTotal` is set out[n] = total.
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock) void ScanApplyKernel(const TIn* in, int64_t n, const int64_t* blockOffsets, TOut* out,
@@ -310,6 +347,10 @@ static hipError_t ExclusiveScan(const TIn* in, TOut* out, int64_t n, int64_t* bl
         return hipGetLastError();
     }
     const int64_t nblocks = (n + kScanChunk - 1) / kScanChunk;
+    if (nblocks == 1) {
+        hipLaunchKernelGGL((ScanSingleChunkKernel<TIn, TOut>), dim3(1), dim3(kBlock), 0, st, in, n, out, total, appendTotal ? 1 : 0);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((ScanBlockSumsKernel<TIn>), dim3(uint32_t(nblocks)), dim3(kBlock), 0, st, in, n, blockTmp);
     hipLaunchKernelGGL(ScanOfBlockSumsKernel, dim3(1), dim3(kBlock), 0, st, blockTmp, nblocks, total);
     hipLaunchKernelGGL((ScanApplyKernel<TIn, TOut>), dim3(uint32_t(nblocks)), dim3(kBlock), 0, st, in, n, blockTmp, out, total,
