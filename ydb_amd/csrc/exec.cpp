@@ -1535,8 +1535,8 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             SSA_HIP(hipStreamSynchronize(StreamHandle));
             SSA_HIP(hipMemcpy(t, static_cast<char*>(StatusWord->Ptr) + 64, 64, hipMemcpyDeviceToHost));
             SSA_HIP(hipMemset(static_cast<char*>(StatusWord->Ptr) + 64, 0, 64));
-            std::fprintf(stderr, "phases: stage %llu vm %llu keys %llu upsert %llu hot %llu table %llu loop %llu\n", t[0], t[1], t[2], t[3],
-                         t[4], t[5], t[7]);
+            std::fprintf(stderr, "phases: stage %llu vm %llu keys %llu (exact packing %llu) upsert %llu hot %llu table %llu loop %llu\n", t[0], t[1],
+                         t[2] + t[6], t[6], t[3], t[4], t[5], t[7]);
         }
         bool tableFull = false;
         SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull));

@@ -162,15 +162,18 @@ __device__ __forceinline__ void AbsorbWord(HashPair& h, uint64_t w) {
     h.hi = (h.hi + w) * 0xC2B2AE3D27D4EB4Full;
     h.hi ^= h.hi >> 31;
 }
-__device__ __noinline__ HashPair AbsorbString(HashPair h, const uint8_t* p, int32_t n) {
-    AbsorbWord(h, uint64_t(uint32_t(n)));
-    for (int32_t i = 0; i < n; i += 8) {
-        uint64_t w = 0;
-        const int32_t m = (n - i) < 8 ? (n - i) : 8;
-        for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[i + j]) << (8 * j);
-        AbsorbWord(h, w);
+// The next (up to) 8 bytes of a string as a little-endian word, zero above its `left` remaining bytes.  `avail`: bytes
+// of the column's chars buffer from `p` on -- an 8-byte load is used when it stays inside the buffer.
+__device__ __forceinline__ uint64_t LoadStringWord(const uint8_t* p, int32_t left, int64_t avail) {
+    uint64_t w = 0;
+    const int32_t m = left < 8 ? left : 8;
+    if (avail >= 8) {
+        __builtin_memcpy(&w, p, 8);
+        if (m < 8) w &= (1ull << (8 * m)) - 1ull;
+    } else {
+        for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[j]) << (8 * j);
     }
-    return h;
+    return w;
 }
 
 // ---- key construction ---------------------------------------------------------------------------------
@@ -488,6 +491,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 }
             }
         }
+        SSA_T(6);
         if constexpr (hashed) {
             if (uniformPos) {
                 if (kb.pos > 119) toHash = AllMask<U>();
@@ -499,31 +503,70 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
             toHash &= m.P;
             if (__any(toHash != 0)) {
-                // the rare rows: long strings or more than 119 key bits
+                // the rows that need the hash: long strings or more than 119 key bits.  The first 32 bytes of the
+                // strings of all the lane's rows are loaded before any is absorbed (independent loads in flight
+                // together); longer tails are read word by word.
+                HashPair hh[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!((toHash >> u) & 1u)) continue;
-                    HashPair h{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
-                    SSA_UNROLL_STATIC
-                    for (int k = 0; k < nkeys; ++k) {
-                        const int col = int32_t(SSA_ROW(tKeyCol, s.keys[k].col, k));
-                        if (col >= 0) {
-                            const uint8_t* p;
-                            int32_t n;
-                            m.StringAt(col, u, p, n);
-                            h = AbsorbString(h, p, n);
-                        } else {
-                            Val<U> x;
-                            m.FetchOperand(SSA_ROW(tKeyFk, s.keys[k].fetch_kind, k), SSA_ROW(tKeyPayload, s.keys[k].fetch_payload, k), x);
-                            const int type = int32_t(SSA_ROW(tKeyType, s.keys[k].type, k));
-                            const bool nullable = SSA_ROW(tKeyNullable, s.keys[k].nullable, k) != 0;
+                for (int u = 0; u < U; ++u) hh[u] = HashPair{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+                SSA_UNROLL_STATIC
+                for (int k = 0; k < nkeys; ++k) {
+                    const int col = int32_t(SSA_ROW(tKeyCol, s.keys[k].col, k));
+                    if (col >= 0) {
+                        constexpr int kAhead = 4;  // 8-byte words read ahead per row
+                        const uint8_t* sp[U];
+                        int32_t sn[U];
+                        int64_t sav[U];
+                        uint64_t sw[U][kAhead];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            sp[u] = nullptr;
+                            sn[u] = 0;
+                            sav[u] = 0;
+                            if ((toHash >> u) & 1u) {
+                                m.StringAt(col, u, sp[u], sn[u]);
+                                sav[u] = m.CharsAvailable(col, sp[u]);
+                                if (sn[u] < 0 || int64_t(sn[u]) > sav[u]) sn[u] = 0;  // offsets outside the buffer: never dereferenced
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+#pragma unroll
+                            for (int j = 0; j < kAhead; ++j) {
+                                sw[u][j] = 0;
+                                if (8 * j < sn[u]) sw[u][j] = LoadStringWord(sp[u] + 8 * j, sn[u] - 8 * j, sav[u] - 8 * j);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (!((toHash >> u) & 1u)) continue;
+                            AbsorbWord(hh[u], uint64_t(uint32_t(sn[u])));
+#pragma unroll
+                            for (int j = 0; j < kAhead; ++j) {
+                                if (8 * j < sn[u]) AbsorbWord(hh[u], sw[u][j]);
+                            }
+                            for (int32_t i = 8 * kAhead; i < sn[u]; i += 8) AbsorbWord(hh[u], LoadStringWord(sp[u] + i, sn[u] - i, sav[u] - i));
+                        }
+                    } else {
+                        Val<U> x;
+                        m.FetchOperand(SSA_ROW(tKeyFk, s.keys[k].fetch_kind, k), SSA_ROW(tKeyPayload, s.keys[k].fetch_payload, k), x);
+                        const int type = int32_t(SSA_ROW(tKeyType, s.keys[k].type, k));
+                        const bool nullable = SSA_ROW(tKeyNullable, s.keys[k].nullable, k) != 0;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (!((toHash >> u) & 1u)) continue;
                             const bool isNull = nullable && !((x.ok >> u) & 1u);
-                            AbsorbWord(h, isNull ? 0ull : (PayloadToStored(x.v[u], type) & WidthMask(8 * TypeWidth(type))));
-                            if (nullable) AbsorbWord(h, isNull ? 1ull : 0ull);
+                            AbsorbWord(hh[u], isNull ? 0ull : (PayloadToStored(x.v[u], type) & WidthMask(8 * TypeWidth(type))));
+                            if (nullable) AbsorbWord(hh[u], isNull ? 1ull : 0ull);
                         }
                     }
-                    kb.lo[u] = h.lo;
-                    kb.hi[u] = h.hi;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if ((toHash >> u) & 1u) {
+                        kb.lo[u] = hh[u].lo;
+                        kb.hi[u] = hh[u].hi;
+                    }
                 }
             }
         }

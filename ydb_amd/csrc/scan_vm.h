@@ -520,6 +520,14 @@ struct Machine {
         n = e - b;
     }
 
+    // Bytes of column c's chars buffer from address `p` on (0 when `p` lies outside the buffer).
+    __device__ __forceinline__ int64_t CharsAvailable(int c, const uint8_t* p) const {
+        const uint8_t* chars = reinterpret_cast<const uint8_t*>(ReadLane64(tColChars, c));
+        const int64_t off = p - chars;
+        const int64_t limit = int64_t(ReadLane32(tColCharsBytes, c));
+        return (off < 0 || off > limit) ? 0 : limit - off;
+    }
+
     // Up to the first 8 bytes of a string (little-endian in the result, bytes past the string's end are zero).  From
     // the wave's head area when the bytes are there (three aligned LDS words and a byte shift, no branches on the
     // length); else one unaligned 8-byte load when that stays inside the column's chars buffer, byte loads next to its
