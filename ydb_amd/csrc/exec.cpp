@@ -1392,9 +1392,10 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         allSimple = allSimple && !a.check_valid && ((a.kind == AGG_COUNT && a.reg == -1) || a.kind == AGG_SUM_F || a.kind == AGG_SUM_I);
     }
     int L = hint.LdsCap, R = 1;
-    const bool hotOnly = L < 0;  // many groups: level 1 only for the first groups of each workgroup (a skewed key's heavy hitter)
-    if (hotOnly) L = 16;
-    if (L == 16 && !hotOnly) {
+    if (const char* env = std::getenv("SSA_KEYED_MANY")) {  // experiments: level-1 slots of groupings with many groups
+        if (hint.ManyGroups && std::atoi(env) >= 16) L = std::atoi(env);
+    }
+    if (L == 16) {
         if (allSimple && naggs <= kHotAggs) {
             L = 64;  // unreplicated accumulators are small: spend LDS on fewer first-probe collisions instead
         } else {
@@ -1435,8 +1436,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         sink.hashed = hashed;
         sink.lds_cap = L;
         sink.lds_rep = R;
-        sink.hot_only = (hotOnly && L >= 4) ? 1 : 0;
-        for (int k = 0; k < kHotAggs && k < naggs; ++k) {
+            for (int k = 0; k < kHotAggs && k < naggs; ++k) {
             const AggSpec& a = sink.aggs[k];
             if (a.check_valid) continue;
             if (a.kind == AGG_COUNT && a.reg == -1) {
@@ -1560,7 +1560,11 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
 
     // next call on this step: size both table levels for what was seen
     hint.TableCap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(ngroups) * 2), 1024), maxCap);  // load 0.25 .. 0.5
-    hint.LdsCap = ngroups <= 8 ? 16 : (ngroups <= 128 ? 256 : -1);
+    // Groupings of many groups keep a level-1 table too: it fills with the first 256 groups each workgroup meets, and
+    // those include the heavy hitters of a skewed key (an empty search phrase, the busiest users), whose rows would
+    // otherwise queue on single addresses in HBM (ClickBench SearchPhrase: 1046 ms without level 1, 3.6 ms with it).
+    hint.LdsCap = ngroups <= 8 ? 16 : 256;
+    hint.ManyGroups = ngroups > 128;
 
     KeyedFinalizeArgs fa{};
     fa.capacity = cap;

@@ -167,6 +167,7 @@ private:
     // Sizing of the two hash-table levels of a keyed step, learnt from its previous run (performance only).
     struct KeyedHint {
         int LdsCap = 16;
+        bool ManyGroups = false;
         uint64_t TableCap = 4096;
     };
     std::map<const TProgramStep*, KeyedHint> KeyedHints;

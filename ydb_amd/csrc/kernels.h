@@ -66,11 +66,6 @@ struct KeyedSink {
     uint64_t* t_rep_row;     // [cap] hashed keys: smallest representative row index seen for the group (~0 = none)
     int32_t hot_kind[kHotAggs];  // register path of accumulator k (HotKind)
     int32_t hot_off[kHotAggs];   // LDS byte offset of its 64-bit operand tile
-    // High-cardinality groupings: level 1 only takes the first few groups a workgroup meets (the register-held ones) and
-    // every other row goes straight to level 2.  What it buys is the heavy hitter of a skewed key (an empty search
-    // phrase, a default id): its rows add up in registers instead of queueing on one address in HBM.
-    int32_t hot_only;
-    int32_t reserved;
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.

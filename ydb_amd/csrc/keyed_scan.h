@@ -246,15 +246,12 @@ constexpr int kHotGroups = 4;               // groups whose SUM / COUNT accumula
 // indexed by dense id, so the first kHotGroups groups of a workgroup are the ones kept in registers.
 __device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint64_t* lRep, uint32_t* lDense, uint32_t* lCount,
                                               uint64_t* lHotKey, uint32_t mask, uint64_t start, uint64_t lo, uint64_t hi, bool twoWords,
-                                              uint64_t row, uint32_t maxProbes, uint32_t maxGroups) {
+                                              uint64_t row, uint32_t maxProbes) {
     uint32_t s = uint32_t(start) & mask;
     uint32_t probes = 0;
     while (probes < maxProbes) {
         uint64_t cur = __hip_atomic_load(lLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == kEmpty) {
-            // level 1 takes no more groups (a few lanes may get past this together; their groups are then level-1 groups
-            // like any other: partial sums of one key in both levels meet in the merge at the end)
-            if (__hip_atomic_load(lCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= maxGroups) return -1;
             cur = atomicCAS(reinterpret_cast<unsigned long long*>(lLo + s), static_cast<unsigned long long>(kEmpty),
                             static_cast<unsigned long long>(lo));
             if (cur == kEmpty) {
@@ -354,7 +351,6 @@ __device__ __forceinline__ void ScanKeyedBody() {
         for (int k = 0; k < kHotAggs; ++k) hot[g][k] = 0;
     }
     const bool useHot = L >= kHotGroups && !(m.S().debug_flags & 8);
-    const bool hotOnly = s.hot_only != 0 && useHot;
     // keys of the register-held groups as this wave knows them (a free marker never equals a key)
     uint64_t hotLo[kHotGroups], hotHi[kHotGroups];
 #pragma unroll
@@ -618,10 +614,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
             if (has) {
                 const uint64_t row = uint64_t(m.Row(0)) + uint64_t(pu) * 64u;
                 const uint32_t h = Fold32(klo, khi);
-                if (L > 0 && !(hotOnly && hotKnown == kHotGroups)) {
-                    sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes,
-                                        hotOnly ? uint32_t(kHotGroups) : uint32_t(L));
-                }
+                if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes);
                 if (sl < 0) {
                     const int64_t g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, klo, khi, twoWords, 4096u);
                     if (g < 0) {
