@@ -117,84 +117,95 @@ __global__ __launch_bounds__(kBlock) void SequentialAndKernel(const uint64_t* se
 
 // Rows against a border tuple, key after key while the row still equals the border (arrow_filter.cpp:30-50): numbers
 // by < and > (a NaN is neither: the next key decides), strings by memcmp then length, validity never looked at.
+__device__ __forceinline__ int CompareKey(const PredicateKey& c, int64_t row) {
+    switch (c.kind) {
+        case PK_SIGNED: {
+            int64_t v;
+            switch (c.width) {
+                case 1: v = static_cast<const int8_t*>(c.values)[row]; break;
+                case 2: v = static_cast<const int16_t*>(c.values)[row]; break;
+                case 4: v = static_cast<const int32_t*>(c.values)[row]; break;
+                default: v = static_cast<const int64_t*>(c.values)[row]; break;
+            }
+            const int64_t b = int64_t(c.border);
+            return v < b ? -1 : (v > b ? 1 : 0);
+        }
+        case PK_UNSIGNED: {
+            uint64_t v;
+            switch (c.width) {
+                case 1: v = static_cast<const uint8_t*>(c.values)[row]; break;
+                case 2: v = static_cast<const uint16_t*>(c.values)[row]; break;
+                case 4: v = static_cast<const uint32_t*>(c.values)[row]; break;
+                default: v = static_cast<const uint64_t*>(c.values)[row]; break;
+            }
+            return v < c.border ? -1 : (v > c.border ? 1 : 0);
+        }
+        case PK_F32: {
+            const float v = static_cast<const float*>(c.values)[row];
+            const float b = __uint_as_float(uint32_t(c.border));
+            return v < b ? -1 : (v > b ? 1 : 0);
+        }
+        case PK_F64: {
+            const double v = static_cast<const double*>(c.values)[row];
+            const double b = __longlong_as_double(static_cast<long long>(c.border));
+            return v < b ? -1 : (v > b ? 1 : 0);
+        }
+        case PK_BOOL: {
+            const int64_t bit = row + c.val_bit_off;
+            const uint32_t v = (static_cast<const uint8_t*>(c.values)[bit >> 3] >> (bit & 7)) & 1u;
+            const uint32_t b = uint32_t(c.border) & 1u;
+            return v < b ? -1 : (v > b ? 1 : 0);
+        }
+        default: {  // PK_STRING
+            const int32_t* offs = static_cast<const int32_t*>(c.values);
+            const int32_t s = offs[row], n = offs[row + 1] - s;
+            const int32_t bn = int32_t(c.border);
+            const int32_t m = n < bn ? n : bn;
+            const uint8_t* p = c.chars + s;
+            int res = 0;
+            for (int32_t i = 0; i < m && res == 0; ++i) {
+                const uint8_t x = p[i], y = c.border_chars[i];
+                res = x < y ? -1 : (x > y ? 1 : 0);
+            }
+            if (res == 0) res = n < bn ? -1 : (n > bn ? 1 : 0);
+            return res;
+        }
+    }
+}
+
+// A wave takes kPredRows words of 64 rows per trip: the first key of all of them is compared before any later key is
+// looked at, so that a wave has that many independent loads in flight (the later keys only matter for the rows that
+// equal the border so far -- few, and usually none).
+constexpr int kPredRows = 4;
 __global__ __launch_bounds__(kBlock) void PredicateKernel(const PredicateKeys keys, int64_t nrows, int compareType, uint64_t* bits) {
     const int lane = threadIdx.x & 63;
     const int64_t nwords = (nrows + 63) >> 6;
+    const int64_t ngroups = (nwords + kPredRows - 1) / kPredRows;
     const int64_t wavesTotal = int64_t(gridDim.x) * (kBlock / 64);
-    for (int64_t w = int64_t(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6); w < nwords; w += wavesTotal) {
-        const int64_t row = w * 64 + lane;
-        int res = 0;
-        if (row < nrows) {
-            for (int k = 0; k < keys.nkeys && res == 0; ++k) {
-                const PredicateKey& c = keys.cols[k];
-                switch (c.kind) {
-                    case PK_SIGNED: {
-                        int64_t v;
-                        switch (c.width) {
-                            case 1: v = static_cast<const int8_t*>(c.values)[row]; break;
-                            case 2: v = static_cast<const int16_t*>(c.values)[row]; break;
-                            case 4: v = static_cast<const int32_t*>(c.values)[row]; break;
-                            default: v = static_cast<const int64_t*>(c.values)[row]; break;
-                        }
-                        const int64_t b = int64_t(c.border);
-                        res = v < b ? -1 : (v > b ? 1 : 0);
-                        break;
-                    }
-                    case PK_UNSIGNED: {
-                        uint64_t v;
-                        switch (c.width) {
-                            case 1: v = static_cast<const uint8_t*>(c.values)[row]; break;
-                            case 2: v = static_cast<const uint16_t*>(c.values)[row]; break;
-                            case 4: v = static_cast<const uint32_t*>(c.values)[row]; break;
-                            default: v = static_cast<const uint64_t*>(c.values)[row]; break;
-                        }
-                        res = v < c.border ? -1 : (v > c.border ? 1 : 0);
-                        break;
-                    }
-                    case PK_F32: {
-                        const float v = static_cast<const float*>(c.values)[row];
-                        const float b = __uint_as_float(uint32_t(c.border));
-                        res = v < b ? -1 : (v > b ? 1 : 0);
-                        break;
-                    }
-                    case PK_F64: {
-                        const double v = static_cast<const double*>(c.values)[row];
-                        const double b = __longlong_as_double(static_cast<long long>(c.border));
-                        res = v < b ? -1 : (v > b ? 1 : 0);
-                        break;
-                    }
-                    case PK_BOOL: {
-                        const int64_t bit = row + c.val_bit_off;
-                        const uint32_t v = (static_cast<const uint8_t*>(c.values)[bit >> 3] >> (bit & 7)) & 1u;
-                        const uint32_t b = uint32_t(c.border) & 1u;
-                        res = v < b ? -1 : (v > b ? 1 : 0);
-                        break;
-                    }
-                    default: {  // PK_STRING
-                        const int32_t* offs = static_cast<const int32_t*>(c.values);
-                        const int32_t s = offs[row], n = offs[row + 1] - s;
-                        const int32_t bn = int32_t(c.border);
-                        const int32_t m = n < bn ? n : bn;
-                        const uint8_t* p = c.chars + s;
-                        for (int32_t i = 0; i < m && res == 0; ++i) {
-                            const uint8_t x = p[i], y = c.border_chars[i];
-                            res = x < y ? -1 : (x > y ? 1 : 0);
-                        }
-                        if (res == 0) res = n < bn ? -1 : (n > bn ? 1 : 0);
-                        break;
-                    }
-                }
+    for (int64_t g = int64_t(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6); g < ngroups; g += wavesTotal) {
+        int res[kPredRows];
+#pragma unroll
+        for (int u = 0; u < kPredRows; ++u) {
+            const int64_t row = (g * kPredRows + u) * 64 + lane;
+            res[u] = row < nrows ? CompareKey(keys.cols[0], row) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPredRows; ++u) {
+            const int64_t w = g * kPredRows + u;
+            const int64_t row = w * 64 + lane;
+            if (row < nrows) {
+                for (int k = 1; k < keys.nkeys && res[u] == 0; ++k) res[u] = CompareKey(keys.cols[k], row);
             }
+            bool keep;
+            switch (compareType) {
+                case 1: keep = res[u] < 0; break;   // ECompareType::LESS
+                case 2: keep = res[u] <= 0; break;  // LESS_OR_EQUAL
+                case 3: keep = res[u] > 0; break;   // GREATER
+                default: keep = res[u] >= 0; break; // GREATER_OR_EQUAL
+            }
+            const uint64_t word = __ballot(keep && row < nrows);
+            if (lane == 0 && w < nwords) bits[w] = word;
         }
-        bool keep;
-        switch (compareType) {
-            case 1: keep = res < 0; break;   // ECompareType::LESS
-            case 2: keep = res <= 0; break;  // LESS_OR_EQUAL
-            case 3: keep = res > 0; break;   // GREATER
-            default: keep = res >= 0; break; // GREATER_OR_EQUAL
-        }
-        const uint64_t word = __ballot(keep && row < nrows);
-        if (lane == 0) bits[w] = word;
     }
 }
 
@@ -248,7 +259,8 @@ hipError_t LaunchSequentialAnd(const uint64_t* self, int64_t nwords, const int64
 }
 hipError_t LaunchPredicate(const PredicateKeys& keys, int64_t nrows, int compareType, uint64_t* bits, hipStream_t st) {
     const int64_t nwords = (nrows + 63) >> 6;
-    hipLaunchKernelGGL(PredicateKernel, dim3(GridForItems(nwords * 64)), dim3(kBlock), 0, st, keys, nrows, compareType, bits);
+    hipLaunchKernelGGL(PredicateKernel, dim3(GridForItems((nwords + kPredRows - 1) / kPredRows * 64)), dim3(kBlock), 0, st, keys, nrows, compareType,
+                       bits);
     return hipGetLastError();
 }
 hipError_t LaunchBitmapTileCount(const uint64_t* bits, int64_t nwords, int64_t ntiles, uint32_t* counts, hipStream_t st) {
