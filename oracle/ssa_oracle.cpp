@@ -695,13 +695,65 @@ static DatumPtr StringMatch(int kind, bool icase, const DatumPtr& a, std::string
 }
 
 // match_like: Arrow rewrites '%lit%' / 'lit%' / '%lit' (no other wildcard, no escape) to the plain matchers
-// (compute/kernels/scalar_string.cc: MatchLike); other patterns go through RE2, which this restatement does not carry.
+// (compute/kernels/scalar_string.cc: MatchLike); other patterns go through RE2: LikeRegexMatch below.
 static bool SimplifyLike(const std::string& p, int& kind, std::string& lit) {
     auto plain = [](const std::string& s) { return s.find_first_of("%_\\") == std::string::npos; };
     if (p.size() >= 2 && p.front() == '%' && p.back() == '%' && plain(p.substr(1, p.size() - 2))) { kind = 0; lit = p.substr(1, p.size() - 2); return true; }
     if (!p.empty() && p.back() == '%' && plain(p.substr(0, p.size() - 1))) { kind = 1; lit = p.substr(0, p.size() - 1); return true; }
     if (!p.empty() && p.front() == '%' && plain(p.substr(1))) { kind = 2; lit = p.substr(1); return true; }
     return false;
+}
+
+// The patterns Arrow does not rewrite become the regular expression "(?s:^...$)" with '%' -> ".*", '_' -> ".", a
+// backslash making the next character literal (MakeLikeRegex, compute/kernels/scalar_string.cc:739-778), matched by
+// RE2 in UTF-8 mode: '.' is one UTF-8 encoded code point up to U+10FFFF.  Restated without a regex engine: the
+// pattern as a token list, and the set of text positions reachable after each token.
+static size_t Utf8Len(const std::string& s, size_t i) {
+    const auto b = [&](size_t k) { return uint8_t(s[k]); };
+    const auto cont = [&](size_t k) { return k < s.size() && (b(k) & 0xC0) == 0x80; };
+    if (i >= s.size()) return 0;
+    const uint8_t c = b(i);
+    if (c < 0x80) return 1;
+    if (c >= 0xC2 && c <= 0xDF) return cont(i + 1) ? 2 : 0;
+    if (c == 0xE0) return (cont(i + 1) && b(i + 1) >= 0xA0 && cont(i + 2)) ? 3 : 0;
+    if (c >= 0xE1 && c <= 0xEF) return (cont(i + 1) && cont(i + 2)) ? 3 : 0;
+    if (c == 0xF0) return (cont(i + 1) && b(i + 1) >= 0x90 && cont(i + 2) && cont(i + 3)) ? 4 : 0;
+    if (c >= 0xF1 && c <= 0xF3) return (cont(i + 1) && cont(i + 2) && cont(i + 3)) ? 4 : 0;
+    if (c == 0xF4) return (cont(i + 1) && b(i + 1) <= 0x8F && cont(i + 2) && cont(i + 3)) ? 4 : 0;
+    return 0;
+}
+static bool LikeRegexMatch(const std::string& s, const std::string& pattern) {
+    struct Token { int kind; char lit; };  // 0 literal, 1 any one character, 2 any run of characters
+    std::vector<Token> tokens;
+    bool escaped = false;
+    for (const char c : pattern) {
+        if (!escaped && c == '%') tokens.push_back({2, 0});
+        else if (!escaped && c == '_') tokens.push_back({1, 0});
+        else if (!escaped && c == '\\') escaped = true;
+        else { tokens.push_back({0, c}); escaped = false; }
+    }
+    std::vector<char> at(s.size() + 1, 0), next;
+    at[0] = 1;
+    for (const Token& t : tokens) {
+        next.assign(s.size() + 1, 0);
+        for (size_t i = 0; i <= s.size(); ++i) {
+            if (!at[i]) continue;
+            if (t.kind == 0) {
+                if (i < s.size() && s[i] == t.lit) next[i + 1] = 1;
+            } else if (t.kind == 1) {
+                if (const size_t l = Utf8Len(s, i)) next[i + l] = 1;
+            } else {
+                for (size_t j = i;;) {
+                    next[j] = 1;
+                    const size_t l = Utf8Len(s, j);
+                    if (!l) break;
+                    j += l;
+                }
+            }
+        }
+        at.swap(next);
+    }
+    return at[s.size()] != 0;
 }
 
 // ---- YQL block kernels (selected by YqlOperationId, ydb/library/yql/core/arrow_kernels/request/request.h:19-42) ----
@@ -919,7 +971,17 @@ static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
             if (!a.hasPattern) throw Error("MatchSubstringOptions required");
             int kind = a.op == OP_MATCH ? 0 : a.op == OP_STARTS ? 1 : 2;
             std::string pat = a.pattern;
-            if (a.op == OP_MATCH_LIKE && !SimplifyLike(a.pattern, kind, pat)) throw Error("Unsupported: general LIKE pattern");
+            if (a.op == OP_MATCH_LIKE && !SimplifyLike(a.pattern, kind, pat)) {
+                if (a.ignoreCase) throw Error("Unsupported: case-insensitive general LIKE pattern");
+                if (!IsStr(args[0]->ty)) throw Error("Function has no kernel matching input types");
+                const int64_t n = args[0]->scalar ? 1 : args[0]->n;
+                auto out = NewArray(BOOL, n);
+                out->scalar = args[0]->scalar;
+                out->n = args[0]->n;
+                out->ok = args[0]->ok;
+                for (int64_t r = 0; r < n; ++r) out->u[r] = LikeRegexMatch(args[0]->s[r], a.pattern);
+                return out;
+            }
             return StringMatch(kind, a.ignoreCase, args[0], pat, true, BOOL);
         }
         case OP_CAST: {

@@ -173,3 +173,7 @@ def test_narrow_group_by_takes_wide_tiles(forced, n):
         ok, err = pc.Init(resolver, prog)
         assert ok, err
         compare_batches(pc.ApplyProgram(batch), ssa_oracle.Oracle(resolver, prog).apply(batch), key_names=[key])
+
+
+def test_general_like_patterns(forced):
+    P.test_general_like_patterns()

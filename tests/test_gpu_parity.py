@@ -420,3 +420,28 @@ def test_decimal128_sum(n, nulls):
         sel = ok & (key == k)
         want = sum(v for v, o in zip(vals, sel) if o) if sel.any() else None
         assert s == want, (k, s, want)
+
+
+def test_general_like_patterns():
+    """match_like with patterns outside the three plain forms (wildcards in the middle, '_', escapes, UTF-8 text):
+    GPU against the oracle and against the regular expression the reference builds for the pattern; as a computed
+    column, as a filter, and with nulls."""
+    import like_cases
+    from ydb_amd.ssa_pb import F
+    rng = np.random.default_rng(17)
+    values = like_cases.strings(rng, 5000) + ["abc", "a\nc", "ab%c", "ab_cd", "\\", "a", "日本", "x日本y", "aébc"]
+    valid = rng.random(len(values)) > 0.15
+    for pattern in like_cases.PATTERNS:
+        prog = (Program().assign_const(Column(name="pat"), "Bytes", pattern.encode())
+                .assign_func(Column(name="res"), F.STR_MATCH_LIKE, [1, "pat"]).project(["res"]))
+        got, exp = both([(1, "x")], prog, {"x": Col(values, type="string")})
+        compare_batches(got, exp)
+        assert [bool(v) for v in got["res"].to_pylist()] == like_cases.expected(values, pattern), pattern
+        got, exp = both([(1, "x")], prog, {"x": Col(values, type="string", valid=valid)})
+        compare_batches(got, exp)
+        flt = (Program().assign_const(Column(name="pat"), "Bytes", pattern.encode())
+               .assign_func(Column(name="res"), F.STR_MATCH_LIKE, [1, "pat"]).filter("res")
+               .group_by([Aggregate(Column(name="n"), AGG.COUNT, [])]).project(["n"]))
+        got, exp = both([(1, "x")], flt, {"x": Col(values, type="string")})
+        compare_batches(got, exp)
+        assert int(got["n"].to_pylist()[0]) == sum(like_cases.expected(values, pattern)), pattern

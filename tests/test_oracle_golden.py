@@ -36,3 +36,21 @@ def test_oracle_decimal128_sum_matches_python_integers():
         assert s == sum(v for v, ok, kk in zip(vals, valid, key) if ok and kk == k)
     allnull = {"d": Col(words, valid=np.zeros(n, dtype=bool), decimal=(38, 0)), "k": key}
     assert oracle_run(res, Program().group_by([Aggregate(10, AGG.SUM, [1])]), allnull)["10"].to_pylist() == [None]
+
+
+def test_general_like_patterns_against_the_reference_regex():
+    """match_like with patterns Arrow hands to RE2: the oracle's token matcher against Python's `re` evaluating the
+    regular expression the reference builds for the pattern (tests/like_cases.py)."""
+    import numpy as np
+    import like_cases
+    from oracle import ssa_oracle
+    from ydb_amd.arrow_c import Col
+    from ydb_amd.ssa_pb import F, Column, Program
+    rng = np.random.default_rng(3)
+    values = like_cases.strings(rng, 4000) + ["abc", "a\nc", "ab%c", "ab_cd", "\\", "a", "日本", "x日本y", "aébc"]
+    for pattern in like_cases.PATTERNS:
+        prog = (Program().assign_const(Column(name="pat"), "Bytes", pattern.encode())
+                .assign_func(Column(name="res"), F.STR_MATCH_LIKE, [1, "pat"]).project(["res"]))
+        out = ssa_oracle.Oracle([(1, "x")], prog).apply({"x": Col(values, type="string")})
+        got = [bool(v) for v in out["res"].to_pylist()]
+        assert got == like_cases.expected(values, pattern), pattern

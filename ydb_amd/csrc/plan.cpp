@@ -475,7 +475,12 @@ struct Compiler {
                 if (!IsStringLike(args[0]->Type)) return Status::Invalid(NoKernel(fn, args[0]->Type, T_NONE));
                 int kind;
                 std::string lit;
-                if (!SimplifyLike(a.Pattern, kind, lit)) return Status::Unsupported("general LIKE pattern");
+                if (!SimplifyLike(a.Pattern, kind, lit)) {
+                    // Arrow hands every other pattern to RE2 (MakeLikeRegex); case-insensitive matching there folds
+                    // Unicode, which this path does not do (the program builder never asks for it with LIKE)
+                    if (a.IgnoreCase) return Status::Unsupported("case-insensitive general LIKE pattern");
+                    return StrMatchNode(STR_LIKE, false, args[0], a.Pattern, true, T_BOOL, out);
+                }
                 return StrMatchNode(kind, a.IgnoreCase, args[0], lit, true, T_BOOL, out);
             }
             default:

@@ -120,7 +120,7 @@ enum Dialect : int32_t {
 
 enum SrcKind : int32_t { SRC_NONE = 0, SRC_COL = 1, SRC_CONST = 2, SRC_REG = 3 };
 
-enum StrMatchKind : int32_t { STR_CONTAINS = 0, STR_STARTS = 1, STR_ENDS = 2 };
+enum StrMatchKind : int32_t { STR_CONTAINS = 0, STR_STARTS = 1, STR_ENDS = 2, STR_LIKE = 3 /* the pattern is a whole SQL LIKE pattern */ };
 
 enum OpCode : int32_t {
     OP_END = 0,

@@ -189,9 +189,80 @@ SSA_HD bool CompareVals(int cmp, int cls, uint64_t a, uint64_t b) {
 
 SSA_HD uint8_t AsciiLower(uint8_t c) { return (c >= 'A' && c <= 'Z') ? uint8_t(c + 32) : c; }
 
+// Length of the UTF-8 sequence that starts at s (n bytes left), 0 when the bytes there are not one: the sequences
+// RE2's `.` accepts in its UTF-8 mode (shortest forms only, up to U+10FFFF).
+SSA_HD int32_t Utf8CharLen(const uint8_t* s, int32_t n) {
+    if (n <= 0) return 0;
+    const uint8_t c = s[0];
+    if (c < 0x80) return 1;
+    auto cont = [](uint8_t b) { return (b & 0xC0) == 0x80; };
+    if (c >= 0xC2 && c <= 0xDF) return (n >= 2 && cont(s[1])) ? 2 : 0;
+    if (c >= 0xE0 && c <= 0xEF) {
+        if (n < 3 || !cont(s[1]) || !cont(s[2])) return 0;
+        return (c == 0xE0 && s[1] < 0xA0) ? 0 : 3;
+    }
+    if (c >= 0xF0 && c <= 0xF4) {
+        if (n < 4 || !cont(s[1]) || !cont(s[2]) || !cont(s[3])) return 0;
+        if (c == 0xF0 && s[1] < 0x90) return 0;
+        if (c == 0xF4 && s[1] > 0x8F) return 0;
+        return 4;
+    }
+    return 0;
+}
+
+// SQL LIKE as Arrow 5 evaluates a pattern it cannot turn into a plain search (compute/kernels/scalar_string.cc:739-778,
+// MakeLikeRegex): the whole string must match; an unescaped '%' is any run of characters, an unescaped '_' one
+// character (a UTF-8 sequence: the regular expression runs in UTF-8 mode with "dot matches newline"), a backslash
+// makes the next byte literal and a trailing lone backslash stands for nothing.  One '%' is remembered to come back to;
+// it gives up one more character on every mismatch.
+SSA_HD bool LikeMatch(const uint8_t* s, int32_t n, const uint8_t* p, int32_t m) {
+    int32_t si = 0, pi = 0, starP = -1, starS = 0;
+    for (;;) {
+        bool ok = false;
+        if (pi < m) {
+            const uint8_t c = p[pi];
+            if (c == '%') {
+                starP = ++pi;
+                starS = si;
+                continue;
+            }
+            if (c == '\\' && pi + 1 >= m) {  // lone backslash at the end
+                ++pi;
+                continue;
+            }
+            if (c == '_') {
+                const int32_t l = Utf8CharLen(s + si, n - si);
+                if (l > 0) {
+                    si += l;
+                    ++pi;
+                    ok = true;
+                }
+            } else {
+                const bool escaped = c == '\\';
+                const uint8_t lit = escaped ? p[pi + 1] : c;
+                if (si < n && s[si] == lit) {
+                    ++si;
+                    pi += escaped ? 2 : 1;
+                    ok = true;
+                }
+            }
+        } else if (si == n) {
+            return true;
+        }
+        if (ok) continue;
+        if (starP < 0) return false;
+        const int32_t l = Utf8CharLen(s + starS, n - starS);
+        if (l == 0) return false;  // nothing (or no character) left for the '%' to take
+        starS += l;
+        si = starS;
+        pi = starP;
+    }
+}
+
 // Byte-wise substring / prefix / suffix test (std::string_view semantics; an empty pattern
 // matches everything).  ignore_case folds ASCII letters only.
 SSA_HD bool StrMatch(int kind, bool icase, const uint8_t* s, int32_t n, const uint8_t* p, int32_t m) {
+    if (kind == STR_LIKE) return LikeMatch(s, n, p, m);
     if (m > n) return false;
     if (m == 0) return true;
     int32_t first = 0, last = 0;
