@@ -44,11 +44,16 @@ DevPool& DevPool::Instance() {
     return pool;
 }
 
-void* DevPool::Alloc(size_t bytes) {
+// Free blocks are kept per device: a block handed out again must live on the device of the caller (the one current
+// on the calling thread -- every executor entry point sets its own).
+void* DevPool::Alloc(size_t bytes, int* device) {
     const size_t b = BucketSize(bytes ? bytes : 1);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (device) *device = dev;
     {
         std::lock_guard<std::mutex> g(Lock);
-        auto it = FreeLists.find(b);
+        auto it = FreeLists.find({dev, b});
         if (it != FreeLists.end() && !it->second.empty()) {
             void* p = it->second.back();
             it->second.pop_back();
@@ -66,29 +71,29 @@ void* DevPool::Alloc(size_t bytes) {
     return p;
 }
 
-void DevPool::Free(void* p, size_t bytes) {
+void DevPool::Free(void* p, size_t bytes, int device) {
     if (!p) return;
     const size_t b = BucketSize(bytes ? bytes : 1);
     std::lock_guard<std::mutex> g(Lock);
     InUse -= b;
-    FreeLists[b].push_back(p);
+    FreeLists[{device, b}].push_back(p);
 }
 
 void DevPool::Trim() {
     std::lock_guard<std::mutex> g(Lock);
     for (auto& kv : FreeLists) {
-        for (void* p : kv.second) (void)hipFree(p);
+        for (void* p : kv.second) (void)hipFree(p);  // (hipFree finds the owning device from the address)
         kv.second.clear();
     }
 }
 
 Buffer::~Buffer() {
-    if (Owned) DevPool::Instance().Free(Ptr, Size);
+    if (Owned) DevPool::Instance().Free(Ptr, Size, Device);
 }
 
 BufferPtr Buffer::Alloc(size_t bytes) {
     auto b = std::make_shared<Buffer>();
-    b->Ptr = DevPool::Instance().Alloc(bytes);
+    b->Ptr = DevPool::Instance().Alloc(bytes, &b->Device);
     b->Size = bytes;
     b->Owned = true;
     if (!b->Ptr) return nullptr;

@@ -25,14 +25,14 @@ namespace ssa {
 class DevPool {
 public:
     static DevPool& Instance();
-    void* Alloc(size_t bytes);
-    void Free(void* p, size_t bytes);
+    void* Alloc(size_t bytes, int* device);
+    void Free(void* p, size_t bytes, int device);
     void Trim();
     size_t BytesInUse() const { return InUse; }
 
 private:
     std::mutex Lock;
-    std::map<size_t, std::vector<void*>> FreeLists;
+    std::map<std::pair<int, size_t>, std::vector<void*>> FreeLists;  // (device, block size) -> free blocks
     size_t InUse = 0;
 };
 
@@ -40,6 +40,7 @@ struct Buffer {
     void* Ptr = nullptr;
     size_t Size = 0;
     bool Owned = false;  // allocated from DevPool (else: caller-owned device memory that outlives the batch)
+    int Device = 0;      // owned blocks: the device they live on
     ~Buffer();
     static std::shared_ptr<Buffer> Alloc(size_t bytes);
     static std::shared_ptr<Buffer> Wrap(void* p, size_t bytes);
