@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6", "cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv",
-                                                         "cb_userid", "cb_phrase"])
+                                                         "cb_userid", "cb_phrase", "cb_q20"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: TPC-H SF100 lineitem; ClickBench hits for cb_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -150,6 +150,8 @@ def main():
         li = clickbench.DeviceHits(rows, device=local_rank, row0=rank * rows, columns=cols)
         if args.workload == "cb_phrase":
             bpr = 4 + li.phrase_bytes / rows
+        if args.workload == "cb_q20":
+            bpr = 4 + li.url_bytes / rows
     elif args.workload == "q6":
         prog, cols, bpr = tpch.q6_program(), tpch.Q6_COLUMNS, tpch.Q6_BYTES_PER_ROW
         name = "TPC-H Q6"

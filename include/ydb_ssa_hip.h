@@ -112,7 +112,8 @@ struct ssa_device_column {
     int32_t reserved;
     const void* values;    /* fixed width: values; BOOL: bitmap; STRING/BINARY: int32 offsets (rows + 1) */
     const uint8_t* validity; /* bitmap, NULL = no nulls */
-    const uint8_t* chars;  /* STRING/BINARY bytes */
+    const uint8_t* chars;  /* STRING/BINARY bytes; the allocation must be readable for 16 bytes past chars_size (the
+                            * scans read strings in 16-byte pieces) */
     int64_t chars_size;
     int64_t null_count;    /* -1 = unknown */
 };

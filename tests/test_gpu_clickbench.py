@@ -79,7 +79,7 @@ def test_group_bys_above_the_pushdown(n):
     compare_batches(got, exp, key_names=["URL"])
 
 
-@pytest.mark.parametrize("name", ["cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv", "cb_userid", "cb_phrase"])
+@pytest.mark.parametrize("name", ["cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_q20", "cb_adv", "cb_userid", "cb_phrase"])
 def test_benchmark_workloads_on_the_device_generated_table(name):
     """The programs bench.py times (ydb_amd/clickbench.py), over the table its generator leaves in HBM, against the
     oracle on the same columns copied to the host."""
@@ -100,3 +100,5 @@ def test_benchmark_workloads_on_the_device_generated_table(name):
         assert len(got["UserID"].valid) > 20_000       # a high-cardinality grouping, as the workload is meant to be
     if name == "cb_phrase":
         assert len(got["SearchPhrase"].valid) > 5_000
+    if name == "cb_q20":
+        assert 1_000 < int(got["108"].to_pylist()[0]) < 4_000   # about one URL in 64 carries the word

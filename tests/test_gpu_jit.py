@@ -177,3 +177,7 @@ def test_narrow_group_by_takes_wide_tiles(forced, n):
 
 def test_general_like_patterns(forced):
     P.test_general_like_patterns()
+
+
+def test_substring_search_over_whole_tiles(forced):
+    P.test_substring_search_over_whole_tiles(4096 + 17)

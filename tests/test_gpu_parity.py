@@ -445,3 +445,35 @@ def test_general_like_patterns():
         got, exp = both([(1, "x")], flt, {"x": Col(values, type="string")})
         compare_batches(got, exp)
         assert int(got["n"].to_pylist()[0]) == sum(like_cases.expected(values, pattern)), pattern
+
+
+@pytest.mark.parametrize("n", [1024, 4096 + 17, 30_000])
+def test_substring_search_over_whole_tiles(n):
+    """match_substring over full tiles takes the wave-wide search (16 bytes per lane, hits mapped back to rows): a small
+    alphabet so that matches are frequent, straddle row boundaries and 16-byte pieces, empty and one-byte strings, patterns
+    of 1..16 bytes and longer (per-row path), with and without ASCII case folding, on utf8 and binary columns."""
+    from ydb_amd.ssa_pb import F
+    rng = np.random.default_rng(n)
+    letters = np.array(list("abAB"))
+    lens = rng.choice([0, 0, 1, 2, 3, 5, 8, 15, 16, 17, 31, 40], n)
+    values = ["".join(rng.choice(letters, k)) for k in lens]
+    valid = rng.random(n) > 0.1
+    patterns = ["a", "ab", "aba", "abab", "bbbbbbb", "abababab", "aabbaabba", "ababababababab", "aaaaaaaaaaaaaaaa", "abababababababababab",
+                "B", "Ab", "ABAB"]
+    for pattern in patterns:
+        for fid in (F.STR_MATCH, F.STR_MATCH_IGNORE_CASE):
+            for typ in ("string", "binary"):
+                col = [v if typ == "string" else v.encode() for v in values]
+                prog = (Program().assign_const(Column(name="pat"), "Bytes", pattern.encode())
+                        .assign_func(Column(name="res"), fid, [1, "pat"]).project(["res"]))
+                got, exp = both([(1, "x")], prog, {"x": Col(col, type=typ, valid=valid)})
+                compare_batches(got, exp)
+                want = [(pattern.lower() in v.lower()) if fid == F.STR_MATCH_IGNORE_CASE else (pattern in v) for v in values]
+                res = got["res"].to_pylist()
+                assert [bool(r) for r, ok in zip(res, valid) if ok] == [w for w, ok in zip(want, valid) if ok], (pattern, fid, typ)
+    # as a filter feeding a count (the ClickBench Q20 shape, YQL kernel)
+    prog = (Program(version=5).assign_const(106, "Bytes", b"abba").assign_yql(107, YQL.StringContains, [1, 106]).filter(107)
+            .group_by([Aggregate(108, AGG.COUNT, [])]).project([108]))
+    got, exp = both([(1, "x")], prog, {"x": Col(values, type="string")})
+    compare_batches(got, exp)
+    assert int(got["108"].to_pylist()[0]) == sum("abba" in v for v in values)

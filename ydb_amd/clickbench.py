@@ -18,7 +18,8 @@ from typing import Dict, List, Tuple
 from .ssa_pb import AGG, YQL, Aggregate, Program
 
 HITS_ROWS = 99_997_497
-HITS_RESOLVER: List[Tuple[int, str]] = [(6, "EventDate"), (10, "UserID"), (21, "ResolutionWidth"), (40, "SearchPhrase"), (41, "AdvEngineID")]
+HITS_RESOLVER: List[Tuple[int, str]] = [(6, "EventDate"), (10, "UserID"), (14, "URL"), (21, "ResolutionWidth"), (40, "SearchPhrase"),
+                                        (41, "AdvEngineID")]
 
 
 def programs() -> Dict[str, Program]:
@@ -33,6 +34,9 @@ def programs() -> Dict[str, Program]:
     p["cb_q3"] = Program(version=5).group_by([Aggregate(106, AGG.SUM, [10]), Aggregate(107, AGG.COUNT, [10])]).project([107, 106])
     # Q6: SELECT MIN(EventDate), MAX(EventDate)
     p["cb_q6"] = Program(version=5).group_by([Aggregate(106, AGG.MAX, [6]), Aggregate(107, AGG.MIN, [6])]).project([106, 107])
+    # Q20: SELECT COUNT(*) FROM hits WHERE URL LIKE '%google%'
+    p["cb_q20"] = (Program(version=5).assign_const(106, "Bytes", b"google").assign_yql(107, YQL.StringContains, [14, 106]).filter(107)
+                   .group_by([Aggregate(108, AGG.COUNT, [])]).project([108]))
     # Q7: SELECT AdvEngineID, COUNT(*) WHERE AdvEngineID <> 0 GROUP BY AdvEngineID
     p["cb_adv"] = (Program().assign_const(106, "Int32", 0).assign_yql(107, YQL.NotEquals, [41, 106]).filter(107)
                    .group_by([Aggregate(108, AGG.COUNT, [])], keys=[41]))
@@ -48,6 +52,7 @@ def programs() -> Dict[str, Program]:
 COLUMNS = {
     "cb_q1": (["AdvEngineID"], 2), "cb_q2": (["ResolutionWidth", "AdvEngineID"], 4), "cb_q3": (["UserID"], 8),
     "cb_q6": (["EventDate"], 4), "cb_adv": (["AdvEngineID"], 2), "cb_userid": (["UserID"], 8), "cb_phrase": (["SearchPhrase"], 4),
+    "cb_q20": (["URL"], 4),
 }
 
 
@@ -61,7 +66,7 @@ class DeviceHits:
         g.manual_seed(seed + row0)
         self.nrows = nrows
         self.t = {}
-        want = set(columns) if columns is not None else {"EventDate", "UserID", "ResolutionWidth", "SearchPhrase", "AdvEngineID"}
+        want = set(columns) if columns is not None else {"EventDate", "UserID", "ResolutionWidth", "SearchPhrase", "AdvEngineID", "URL"}
         if "AdvEngineID" in want:
             u = torch.rand(nrows, device=dev, generator=g)
             adv = torch.randint(1, 31, (nrows,), device=dev, generator=g, dtype=torch.int16)
@@ -100,6 +105,26 @@ class DeviceHits:
             self.t["SearchPhrase_chars"] = torch.cat([chars, torch.zeros(16, dtype=torch.uint8, device=dev)])
             self.phrase_bytes = total
             del row_of, pos, h, chars, offsets, lens, ids, empty
+        if "URL" in want:
+            # 20..119 bytes (mean about 70) of lower-case letters, '/', '.'; one URL in 64 carries "google" somewhere
+            lens = 20 + torch.randint(0, 100, (nrows,), device=dev, generator=g)
+            offsets = torch.zeros(nrows + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(lens, 0, out=offsets[1:])
+            total = int(offsets[-1].item())
+            if total >= 2**31:
+                raise ValueError("URL bytes exceed int32 offsets: use fewer rows per batch")
+            chars = torch.randint(0, 28, (total + 16,), device=dev, generator=g, dtype=torch.uint8)
+            chars = torch.where(chars < 26, chars + 97, torch.where(chars == 26, torch.full_like(chars, 47), torch.full_like(chars, 46)))
+            chars[total:] = 0
+            marked = torch.nonzero(torch.randint(0, 64, (nrows,), device=dev, generator=g) == 0).flatten()
+            at = offsets[marked] + (torch.randint(0, 2**30, (len(marked),), device=dev, generator=g) % (lens[marked] - 6))
+            word = torch.tensor(list(b"google"), dtype=torch.uint8, device=dev)
+            for j in range(6):
+                chars[at + j] = word[j]
+            self.t["URL_offsets"] = offsets.to(torch.int32)
+            self.t["URL_chars"] = chars
+            self.url_bytes = total
+            del lens, offsets, marked, at
         torch.cuda.synchronize(dev)
 
     def batch(self, columns):
@@ -116,6 +141,8 @@ class DeviceHits:
             elif name == "SearchPhrase":
                 desc.append((name, T["string"], self.t["SearchPhrase_offsets"].data_ptr(), 0, self.t["SearchPhrase_chars"].data_ptr(),
                              self.phrase_bytes, 0))
+            elif name == "URL":
+                desc.append((name, T["string"], self.t["URL_offsets"].data_ptr(), 0, self.t["URL_chars"].data_ptr(), self.url_bytes, 0))
             else:
                 raise KeyError(name)
         return device_batch(desc, self.nrows, keep=self)
@@ -125,9 +152,9 @@ class DeviceHits:
         import numpy as np
         out = {}
         for name in columns:
-            if name == "SearchPhrase":
-                offs = self.t["SearchPhrase_offsets"].cpu().numpy()
-                chars = self.t["SearchPhrase_chars"].cpu().numpy().tobytes()
+            if name in ("SearchPhrase", "URL"):
+                offs = self.t[name + "_offsets"].cpu().numpy()
+                chars = self.t[name + "_chars"].cpu().numpy().tobytes()
                 out[name] = [chars[offs[i]:offs[i + 1]].decode() for i in range(self.nrows)]
             else:
                 out[name] = np.ascontiguousarray(self.t[name].cpu().numpy())

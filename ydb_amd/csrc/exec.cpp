@@ -632,7 +632,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
             lds += kTileRows * sw;
             if (IsStringLike(col.Field.Type)) {  // per-wave slots for the end offset of each wave's last row
                 args.lds_end_off[c] = lds;
-                lds += (kBlock / 64) * 16;
+                lds += (kBlock / 64) * kEndSlotBytes;
             }
         }
         // algorithmic bytes: every referenced source column once
@@ -729,7 +729,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
             lds += kTileRows * StageWidth(args.cols[c].type);
             if (args.lds_end_off[c] >= 0) {
                 args.lds_end_off[c] = lds;
-                lds += (kBlock / 64) * 16;
+                lds += (kBlock / 64) * kEndSlotBytes;
             }
         }
     }

@@ -247,7 +247,7 @@ struct Machine {
         tColStageW = uint32_t(StageWidth(a.cols[c].type));
         tColCharsLds = a.lds_chars_off[c] < 0 ? 0xFFFFFFFFu
                                               : uint32_t(a.lds_chars_off[c]) + (threadIdx.x >> 6) * uint32_t(CharsStageBytes(U));
-        tColEndOff = a.lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(a.lds_end_off[c]) + (threadIdx.x >> 6) * 16u;
+        tColEndOff = a.lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(a.lds_end_off[c]) + (threadIdx.x >> 6) * uint32_t(kEndSlotBytes);
         boundsFirst = boundsLast = 0;
         boundsTile = -1;
         tCharsBegin = tCharsBytes = tCharsSkew = 0;
@@ -288,7 +288,7 @@ struct Machine {
     }
     __device__ __forceinline__ uint32_t ColEndOff(int c) const {
         if (!kStatic) return ReadLane32(tColEndOff, c);
-        return S().lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_end_off[c]) + uint32_t(waveBase / (64 * U)) * 16u;
+        return S().lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_end_off[c]) + uint32_t(waveBase / (64 * U)) * uint32_t(kEndSlotBytes);
     }
     __device__ __forceinline__ uint32_t RegOff(int r) const { return kStatic ? uint32_t(S().lds_reg_offs[r]) : ReadLane32(tRegOff, r); }
     __device__ __forceinline__ uint64_t ConstBits(int k) const { return kStatic ? S().consts[k].bits : ReadLane64(tConstBits, k); }
@@ -526,6 +526,94 @@ struct Machine {
         const int64_t off = p - chars;
         const int64_t limit = int64_t(ReadLane32(tColCharsBytes, c));
         return (off < 0 || off > limit) ? 0 : limit - off;
+    }
+
+    // Substring search over the wave's whole slice at once.  The strings of the slice are one contiguous run of bytes:
+    // the wave streams it in 1 KB pieces -- every lane loads 16 consecutive bytes (coalesced) while the previous piece
+    // is searched -- and tests the pattern at each of its 16 start positions on 64-bit windows assembled from its own
+    // and the next lane's bytes.  A hit (rare for a selective pattern) is mapped to its row by a binary search of the
+    // staged offsets and, when the match lies inside that row, recorded in the wave's match words in LDS.  Patterns of
+    // 1..16 bytes; `icase` folds ASCII letters as the per-row matcher does.  Needs the column's offsets staged, a full
+    // tile and a 16-byte aligned chars buffer; returns false (nothing written) otherwise.
+    __device__ __forceinline__ bool WaveSubstringSearch(int c, const uint8_t* pp, int32_t pn, bool icase, uint64_t* out) {
+        const int off = int(ColOff(c));
+        const uint32_t endOff = ColEndOff(c);
+        const uint64_t charsAddr = ReadLane64(tColChars, c);
+        if (off < 0 || endOff == 0xFFFFFFFFu || !tileFull || pn < 1 || pn > 16 || (charsAddr & 15u) != 0 || U > 16) return false;
+        const uint8_t* chars = reinterpret_cast<const uint8_t*>(charsAddr);
+        const uint32_t limit = ReadLane32(tColCharsBytes, c) & ~15u;  // whole 16-byte pieces of the buffer
+        const uint32_t* l = reinterpret_cast<const uint32_t*>(gLds + off) + waveBase;
+        const uint32_t b0 = uint32_t(__builtin_amdgcn_readfirstlane(int(l[0])));
+        const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int32_t*>(gLds + endOff)));
+        const uint32_t lane = threadIdx.x & 63;
+        uint64_t* words = reinterpret_cast<uint64_t*>(gLds + endOff + 16);
+        if (lane < uint32_t(U)) words[lane] = 0;
+        if (e < b0 || e > limit) {  // offsets that do not describe this buffer (or its last, partial piece): the per-row path
+            return false;
+        }
+        // the pattern as two 64-bit words with their byte masks
+        uint64_t pw[2] = {0, 0};
+        for (int32_t i = 0; i < pn; ++i) {
+            const uint8_t ch = icase ? AsciiLower(pp[i]) : pp[i];
+            pw[i >> 3] |= uint64_t(ch) << (8 * (i & 7));
+        }
+        const uint64_t m0 = pn >= 8 ? ~0ull : ((1ull << (8 * pn)) - 1ull);
+        const uint64_t m1 = pn <= 8 ? 0ull : (pn >= 16 ? ~0ull : ((1ull << (8 * (pn - 8))) - 1ull));
+        auto lower4 = [](uint32_t x) {  // ASCII upper-case bytes get bit 5
+            const uint32_t t = x & 0x7F7F7F7Fu;
+            const uint32_t up = ((t + 0x3F3F3F3Fu) & ~(t + 0x25252525u)) & ~x & 0x80808080u;
+            return x | (up >> 2);
+        };
+        auto piece = [&](uint32_t at) {  // the lane's 16 bytes of the piece that starts at `at` (zero past the slice)
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const uint32_t my = at + lane * 16u;
+            if (my < e) v = *reinterpret_cast<const uint4*>(chars + my);
+            if (icase) v = make_uint4(lower4(v.x), lower4(v.y), lower4(v.z), lower4(v.w));
+            return v;
+        };
+        const uint32_t first = b0 & ~15u;
+        uint4 cur = piece(first);
+        for (uint32_t base = first; base < e; base += 1024u) {
+            const uint4 nxt = piece(base + 1024u);  // in flight while `cur` is searched
+            uint32_t d[8];
+            d[0] = cur.x, d[1] = cur.y, d[2] = cur.z, d[3] = cur.w;
+            // the 16 bytes behind mine: the next lane's, for the last lane the first lane's of the next piece
+            const uint4 nb = make_uint4(__shfl_down(cur.x, 1, 64), __shfl_down(cur.y, 1, 64), __shfl_down(cur.z, 1, 64), __shfl_down(cur.w, 1, 64));
+            const uint4 n0 = make_uint4(__shfl(nxt.x, 0, 64), __shfl(nxt.y, 0, 64), __shfl(nxt.z, 0, 64), __shfl(nxt.w, 0, 64));
+            d[4] = lane == 63 ? n0.x : nb.x, d[5] = lane == 63 ? n0.y : nb.y, d[6] = lane == 63 ? n0.z : nb.z, d[7] = lane == 63 ? n0.w : nb.w;
+            uint32_t hits = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int q = j >> 2;
+                const uint32_t sh = uint32_t(j & 3);
+                const uint64_t lo = uint64_t(__builtin_amdgcn_alignbyte(d[q + 1], d[q], sh)) |
+                                    (uint64_t(__builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], sh)) << 32);
+                bool h = ((lo ^ pw[0]) & m0) == 0;
+                if (pn > 8) {
+                    const uint64_t hi = uint64_t(__builtin_amdgcn_alignbyte(d[q + 3], d[q + 2], sh)) |
+                                        (uint64_t(__builtin_amdgcn_alignbyte(d[q + 4], d[q + 3], sh)) << 32);
+                    h = h && ((hi ^ pw[1]) & m1) == 0;
+                }
+                hits |= (h ? 1u : 0u) << j;
+            }
+            const uint32_t my = base + lane * 16u;
+            while (hits != 0) {
+                const uint32_t pos = my + uint32_t(__ffs(int(hits)) - 1);
+                hits &= hits - 1u;
+                if (pos < b0 || pos + uint32_t(pn) > e) continue;
+                int lo = 0, hi = 64 * U - 1;  // the last row that starts at or before pos (empty rows before it share its start)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (l[mid] <= pos) lo = mid; else hi = mid - 1;
+                }
+                const uint32_t rowEnd = lo + 1 < 64 * U ? l[lo + 1] : e;
+                if (pos + uint32_t(pn) <= rowEnd) atomicOr(reinterpret_cast<unsigned long long*>(words + (lo >> 6)), 1ull << (lo & 63));
+            }
+            cur = nxt;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) out[u] = (words[u] >> lane) & 1ull;
+        return true;
     }
 
     // Up to the first 8 bytes of a string (little-endian in the result, bytes past the string's end are zero).  From
@@ -985,6 +1073,7 @@ struct Machine {
             const uint8_t* pp = S().pattern + uint32_t(pat >> 32);
             const int32_t pn = int32_t(uint32_t(pat));
             A.ok = ValidityOf(si) & (ConstValid(fa) ? AllMask<U>() : 0u);
+            if ((fb & 15) == STR_CONTAINS && WaveSubstringSearch(si, pp, pn, (fb & 16) != 0, A.v)) break;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint64_t m = 0;

@@ -83,6 +83,9 @@ SSA_HD int TypeWidth(int t) {  // bytes of one fixed-width value, 0 for bit-pack
 
 // Bytes of string data a wave can stage per string column and tile: its rows' strings from the first row's start to
 // 8 bytes past the last row's start (enough for every string of up to 8 bytes when the average is 8), plus alignment slack.
+// Per-wave slot of a staged string column: the end offset of the wave's last row in its first 4 bytes, and from byte 16
+// on one 64-bit word per tile row of the lanes (bit t: the string of lane t's row matched) for the wave-wide search.
+constexpr int kEndSlotBytes = 16 + 16 * 8;
 // Head area of one wave and string column: 8 bytes for each of its 64 x U rows, the copy's alignment skew and slack.
 SSA_HD constexpr int CharsStageBytes(int rowsPerThread) { return 64 * rowsPerThread * 8 + 32; }
 
@@ -283,7 +286,7 @@ struct ScanArgs {
     int32_t lds_regok_off;          // R register validity: nregs x lanes bytes
     int32_t nregs;
     int32_t lds_sink_off;           // first byte available to the sink (group-by table)
-    int32_t lds_end_off[kMaxCols];  // staged string column c: one 16-byte slot per wave for the end offset of the wave's last row, or -1
+    int32_t lds_end_off[kMaxCols];  // staged string column c: one kEndSlotBytes slot per wave (end offset of the wave's last row; match words), or -1
     int32_t debug_flags;            // diagnostics only: 1 = skip staging, 2 = skip evaluation (timing experiments)
 };
 
