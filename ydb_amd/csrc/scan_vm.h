@@ -557,8 +557,8 @@ struct Machine {
             const uint8_t ch = icase ? AsciiLower(pp[i]) : pp[i];
             pw[i >> 3] |= uint64_t(ch) << (8 * (i & 7));
         }
-        const uint64_t m0 = pn >= 8 ? ~0ull : ((1ull << (8 * pn)) - 1ull);
-        const uint64_t m1 = pn <= 8 ? 0ull : (pn >= 16 ? ~0ull : ((1ull << (8 * (pn - 8))) - 1ull));
+        const uint32_t p32 = uint32_t(pw[0]);
+        const uint32_t m32 = pn >= 4 ? ~0u : ((1u << (8 * pn)) - 1u);
         auto lower4 = [](uint32_t x) {  // ASCII upper-case bytes get bit 5
             const uint32_t t = x & 0x7F7F7F7Fu;
             const uint32_t up = ((t + 0x3F3F3F3Fu) & ~(t + 0x25252525u)) & ~x & 0x80808080u;
@@ -573,34 +573,35 @@ struct Machine {
         };
         const uint32_t first = b0 & ~15u;
         uint4 cur = piece(first);
+        uint4 nxt = piece(first + 1024u);
         for (uint32_t base = first; base < e; base += 1024u) {
-            const uint4 nxt = piece(base + 1024u);  // in flight while `cur` is searched
+            const uint4 ahead = piece(base + 2048u);  // two pieces are in flight while `cur` is searched
             uint32_t d[8];
             d[0] = cur.x, d[1] = cur.y, d[2] = cur.z, d[3] = cur.w;
             // the 16 bytes behind mine: the next lane's, for the last lane the first lane's of the next piece
             const uint4 nb = make_uint4(__shfl_down(cur.x, 1, 64), __shfl_down(cur.y, 1, 64), __shfl_down(cur.z, 1, 64), __shfl_down(cur.w, 1, 64));
             const uint4 n0 = make_uint4(__shfl(nxt.x, 0, 64), __shfl(nxt.y, 0, 64), __shfl(nxt.z, 0, 64), __shfl(nxt.w, 0, 64));
             d[4] = lane == 63 ? n0.x : nb.x, d[5] = lane == 63 ? n0.y : nb.y, d[6] = lane == 63 ? n0.z : nb.z, d[7] = lane == 63 ? n0.w : nb.w;
+            // the pattern's first (up to) four bytes at each of the 16 start positions; the rest of a longer pattern is
+            // compared for the few hits only
             uint32_t hits = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int q = j >> 2;
-                const uint32_t sh = uint32_t(j & 3);
-                const uint64_t lo = uint64_t(__builtin_amdgcn_alignbyte(d[q + 1], d[q], sh)) |
-                                    (uint64_t(__builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], sh)) << 32);
-                bool h = ((lo ^ pw[0]) & m0) == 0;
-                if (pn > 8) {
-                    const uint64_t hi = uint64_t(__builtin_amdgcn_alignbyte(d[q + 3], d[q + 2], sh)) |
-                                        (uint64_t(__builtin_amdgcn_alignbyte(d[q + 4], d[q + 3], sh)) << 32);
-                    h = h && ((hi ^ pw[1]) & m1) == 0;
-                }
-                hits |= (h ? 1u : 0u) << j;
+                const uint32_t window = __builtin_amdgcn_alignbyte(d[q + 1], d[q], uint32_t(j & 3));
+                hits |= (((window ^ p32) & m32) == 0 ? 1u : 0u) << j;
             }
             const uint32_t my = base + lane * 16u;
             while (hits != 0) {
                 const uint32_t pos = my + uint32_t(__ffs(int(hits)) - 1);
                 hits &= hits - 1u;
                 if (pos < b0 || pos + uint32_t(pn) > e) continue;
+                bool rest = true;
+                for (int32_t i = 4; i < pn && rest; ++i) {
+                    const uint8_t ch = chars[pos + uint32_t(i)];
+                    rest = (icase ? AsciiLower(ch) : ch) == uint8_t(pw[i >> 3] >> (8 * (i & 7)));
+                }
+                if (!rest) continue;
                 int lo = 0, hi = 64 * U - 1;  // the last row that starts at or before pos (empty rows before it share its start)
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
@@ -610,6 +611,7 @@ struct Machine {
                 if (pos + uint32_t(pn) <= rowEnd) atomicOr(reinterpret_cast<unsigned long long*>(words + (lo >> 6)), 1ull << (lo & 63));
             }
             cur = nxt;
+            nxt = ahead;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) out[u] = (words[u] >> lane) & 1ull;
