@@ -181,3 +181,29 @@ def test_general_like_patterns(forced):
 
 def test_substring_search_over_whole_tiles(forced):
     P.test_substring_search_over_whole_tiles(4096 + 17)
+
+
+def test_built_kernel_is_the_specialised_one(monkeypatch):
+    """A kernel built for a step program must be that program's straight-line code, not the interpreter compiled once
+    more (what a too-small unrolling limit of the run-time compiler silently leaves behind): at 32 M rows the built
+    TPC-H Q1 kernel has measured 2.5-3x faster than the generic one; anything under 1.5x means the specialisation is lost."""
+    from ydb_amd import tpch
+    from ydb_amd.program import ProgramContainer
+    n = 32_000_000
+    li = tpch.DeviceLineitem(n, utf8_flags=True, code_flags=False)
+    times = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SSA_JIT", mode)
+        pc = ProgramContainer()
+        ok, err = pc.Init(tpch.LINEITEM_RESOLVER, tpch.q1_program(False))
+        assert ok, err
+        batch = li.batch(tpch.Q1_COLUMNS_UTF8)
+        for _ in range(2):
+            pc.ApplyDevice(batch)
+        pc.EnableProfile(True)
+        pc.ReadProfile()
+        for _ in range(5):
+            pc.ApplyDevice(batch)
+        ms, launches, _ = pc.ReadProfile()
+        times[mode] = ms / launches
+    assert times["1"] * 1.5 < times["0"], times

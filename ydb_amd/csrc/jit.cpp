@@ -180,7 +180,11 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
             }
             const auto t0 = std::chrono::steady_clock::now();
             const std::string archOpt = "--offload-arch=" + arch;
-            const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm"};
+            // The step program's loops are unrolled by pragma with the whole interpreter inlined in their bodies: the
+            // default size limit of pragma-forced unrolling (16 K instructions before folding) is too small for that
+            // and, once exceeded, silently leaves the generic interpreter in the built kernel.
+            const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm", "-mllvm",
+                                  "-pragma-unroll-threshold=1048576"};
             const hiprtcResult rc = st.R.CompileProgram(prog, int(sizeof(opts) / sizeof(opts[0])), opts);
             if (rc != HIPRTC_SUCCESS) {
                 size_t n = 0;

@@ -162,18 +162,23 @@ __device__ __forceinline__ void AbsorbWord(HashPair& h, uint64_t w) {
     h.hi = (h.hi + w) * 0xC2B2AE3D27D4EB4Full;
     h.hi ^= h.hi >> 31;
 }
-// The next (up to) 8 bytes of a string as a little-endian word, zero above its `left` remaining bytes.  `avail`: bytes
-// of the column's chars buffer from `p` on -- an 8-byte load is used when it stays inside the buffer.
-__device__ __forceinline__ uint64_t LoadStringWord(const uint8_t* p, int32_t left, int64_t avail) {
-    uint64_t w = 0;
-    const int32_t m = left < 8 ? left : 8;
-    if (avail >= 8) {
-        __builtin_memcpy(&w, p, 8);
-        if (m < 8) w &= (1ull << (8 * m)) - 1ull;
-    } else {
-        for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[j]) << (8 * j);
+// `avail`: bytes of the column's chars buffer from `p` on (8-byte loads stay inside it; a string whose offsets point
+// outside the buffer hashes as empty and is never dereferenced).
+__device__ __noinline__ HashPair AbsorbString(HashPair h, const uint8_t* p, int32_t n, int64_t avail) {
+    if (n < 0 || int64_t(n) > avail) n = 0;
+    AbsorbWord(h, uint64_t(uint32_t(n)));
+    for (int32_t i = 0; i < n; i += 8) {
+        uint64_t w = 0;
+        const int32_t m = (n - i) < 8 ? (n - i) : 8;
+        if (int64_t(i) + 8 <= avail) {
+            __builtin_memcpy(&w, p + i, 8);  // unaligned 8-byte load
+            if (m < 8) w &= (1ull << (8 * m)) - 1ull;
+        } else {
+            for (int32_t j = 0; j < m; ++j) w |= uint64_t(p[i + j]) << (8 * j);
+        }
+        AbsorbWord(h, w);
     }
-    return w;
+    return h;
 }
 
 // ---- key construction ---------------------------------------------------------------------------------
@@ -499,70 +504,31 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
             toHash &= m.P;
             if (__any(toHash != 0)) {
-                // the rows that need the hash: long strings or more than 119 key bits.  The first 32 bytes of the
-                // strings of all the lane's rows are loaded before any is absorbed (independent loads in flight
-                // together); longer tails are read word by word.
-                HashPair hh[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) hh[u] = HashPair{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
-                SSA_UNROLL_STATIC
-                for (int k = 0; k < nkeys; ++k) {
-                    const int col = int32_t(SSA_ROW(tKeyCol, s.keys[k].col, k));
-                    if (col >= 0) {
-                        constexpr int kAhead = 4;  // 8-byte words read ahead per row
-                        const uint8_t* sp[U];
-                        int32_t sn[U];
-                        int64_t sav[U];
-                        uint64_t sw[U][kAhead];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            sp[u] = nullptr;
-                            sn[u] = 0;
-                            sav[u] = 0;
-                            if ((toHash >> u) & 1u) {
-                                m.StringAt(col, u, sp[u], sn[u]);
-                                sav[u] = m.CharsAvailable(col, sp[u]);
-                                if (sn[u] < 0 || int64_t(sn[u]) > sav[u]) sn[u] = 0;  // offsets outside the buffer: never dereferenced
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-#pragma unroll
-                            for (int j = 0; j < kAhead; ++j) {
-                                sw[u][j] = 0;
-                                if (8 * j < sn[u]) sw[u][j] = LoadStringWord(sp[u] + 8 * j, sn[u] - 8 * j, sav[u] - 8 * j);
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if (!((toHash >> u) & 1u)) continue;
-                            AbsorbWord(hh[u], uint64_t(uint32_t(sn[u])));
-#pragma unroll
-                            for (int j = 0; j < kAhead; ++j) {
-                                if (8 * j < sn[u]) AbsorbWord(hh[u], sw[u][j]);
-                            }
-                            for (int32_t i = 8 * kAhead; i < sn[u]; i += 8) AbsorbWord(hh[u], LoadStringWord(sp[u] + i, sn[u] - i, sav[u] - i));
-                        }
-                    } else {
-                        Val<U> x;
-                        m.FetchOperand(SSA_ROW(tKeyFk, s.keys[k].fetch_kind, k), SSA_ROW(tKeyPayload, s.keys[k].fetch_payload, k), x);
-                        const int type = int32_t(SSA_ROW(tKeyType, s.keys[k].type, k));
-                        const bool nullable = SSA_ROW(tKeyNullable, s.keys[k].nullable, k) != 0;
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if (!((toHash >> u) & 1u)) continue;
-                            const bool isNull = nullable && !((x.ok >> u) & 1u);
-                            AbsorbWord(hh[u], isNull ? 0ull : (PayloadToStored(x.v[u], type) & WidthMask(8 * TypeWidth(type))));
-                            if (nullable) AbsorbWord(hh[u], isNull ? 1ull : 0ull);
-                        }
-                    }
-                }
+                // the rare rows: long strings or more than 119 key bits
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if ((toHash >> u) & 1u) {
-                        kb.lo[u] = hh[u].lo;
-                        kb.hi[u] = hh[u].hi;
+                    if (!((toHash >> u) & 1u)) continue;
+                    HashPair h{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+                    SSA_UNROLL_STATIC
+                    for (int k = 0; k < nkeys; ++k) {
+                        const int col = int32_t(SSA_ROW(tKeyCol, s.keys[k].col, k));
+                        if (col >= 0) {
+                            const uint8_t* p;
+                            int32_t n;
+                            m.StringAt(col, u, p, n);
+                            h = AbsorbString(h, p, n, m.CharsAvailable(col, p));
+                        } else {
+                            Val<U> x;
+                            m.FetchOperand(SSA_ROW(tKeyFk, s.keys[k].fetch_kind, k), SSA_ROW(tKeyPayload, s.keys[k].fetch_payload, k), x);
+                            const int type = int32_t(SSA_ROW(tKeyType, s.keys[k].type, k));
+                            const bool nullable = SSA_ROW(tKeyNullable, s.keys[k].nullable, k) != 0;
+                            const bool isNull = nullable && !((x.ok >> u) & 1u);
+                            AbsorbWord(h, isNull ? 0ull : (PayloadToStored(x.v[u], type) & WidthMask(8 * TypeWidth(type))));
+                            if (nullable) AbsorbWord(h, isNull ? 1ull : 0ull);
+                        }
                     }
+                    kb.lo[u] = h.lo;
+                    kb.hi[u] = h.hi;
                 }
             }
         }
