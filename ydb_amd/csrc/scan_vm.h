@@ -1075,7 +1075,11 @@ struct Machine {
             const uint8_t* pp = S().pattern + uint32_t(pat >> 32);
             const int32_t pn = int32_t(uint32_t(pat));
             A.ok = ValidityOf(si) & (ConstValid(fa) ? AllMask<U>() : 0u);
+#ifdef SSA_SPEC
+            // (only in kernels built for a program: inlined into the generic interpreter the search costs every program
+            // some twenty registers -- Q6 on the generic kernel 3.5 -> 2.9 TB/s)
             if ((fb & 15) == STR_CONTAINS && WaveSubstringSearch(si, pp, pn, (fb & 16) != 0, A.v)) break;
+#endif
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint64_t m = 0;
