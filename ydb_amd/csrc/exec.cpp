@@ -138,6 +138,8 @@ Executor::Executor(int device) : Device(device) {
     (void)hipSetDevice(device);
     (void)hipStreamCreateWithFlags(&StreamHandle, hipStreamNonBlocking);
     (void)hipEventCreate(&EvStart);
+    (void)hipEventCreate(&EvTuneA);
+    (void)hipEventCreate(&EvTuneB);
     (void)hipEventCreate(&EvStop);
     // dynamic LDS the scan kernels may ask for: everything but 1 KiB kept for their static arrays
     const hipError_t cfgErr = ConfigureScanKernels(160 * 1024 - 1024);
@@ -150,6 +152,8 @@ Executor::~Executor() {
     if (StreamHandle) (void)hipStreamSynchronize(StreamHandle);
     if (EvStart) (void)hipEventDestroy(EvStart);
     if (EvStop) (void)hipEventDestroy(EvStop);
+    if (EvTuneA) (void)hipEventDestroy(EvTuneA);
+    if (EvTuneB) (void)hipEventDestroy(EvTuneB);
     if (StreamHandle) (void)hipStreamDestroy(StreamHandle);
 }
 
@@ -1427,6 +1431,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         ScanRowsPerThread = kRowsPerThread;
         if (!st.ok()) return st;
         sink = KeyedSink{};
+        sink.use_hot = 1;
         sink.naggs = naggs;
         sink.nkeys = nkeys;
         for (int k = 0; k < naggs; ++k) {
@@ -1510,11 +1515,19 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             k->t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
         }
         SSA_HIP(LaunchKeyedTableInit(sink, twoWords != 0, hashed, StreamHandle));
+        bool timedRun = false;
+        int hotMode = 1;
         if (in.Rows > 0) {
             // a scan of many rows runs the kernel built for this step program, when that can be had
             hipFunction_t spec = nullptr;
             LaunchCfg specCfg = scfg;
             if (JitEnabled()) {
+                // register-held groups on or off: as decided, else the way not yet timed
+                if (const char* env = std::getenv("SSA_KEYED_HOT")) hint.HotChoice = std::atoi(env) != 0 ? 1 : 0;
+                hotMode = hint.HotChoice >= 0 ? hint.HotChoice : (hint.MsPerRowOn == 0 ? 1 : 0);
+                timedRun = hint.HotChoice < 0 && in.Rows >= (int64_t(1) << 22);
+                if (hint.HotChoice < 0 && !timedRun) hotMode = 1;
+                ssink.use_hot = hotMode;
                 KeyedSink image = ssink;
                 image.t_key_lo = image.t_key_hi = image.t_acc = nullptr;
                 image.t_seen = nullptr;
@@ -1527,9 +1540,12 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
                 spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, sargs, &image, sizeof(image), in.Rows, specCfg);
                 ScanRowsPerThread = kRowsPerThread;
             }
+            timedRun = timedRun && spec != nullptr;
             ProfileBegin();
             if (spec) {
+                if (timedRun) SSA_HIP(hipEventRecord(EvTuneA, StreamHandle));
                 SSA_HIP(LaunchSpecialized(spec, sargs, &ssink, sizeof(ssink), specCfg));
+                if (timedRun) SSA_HIP(hipEventRecord(EvTuneB, StreamHandle));
             } else {
                 SSA_HIP(LaunchScanKeyed(args, sink, cfg));
             }
@@ -1545,6 +1561,13 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         }
         bool tableFull = false;
         SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull));
+        if (timedRun && !tableFull) {  // (the stream has been synchronised by the status check)
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, EvTuneA, EvTuneB) == hipSuccess && ms > 0) {
+                (hotMode ? hint.MsPerRowOn : hint.MsPerRowOff) = double(ms) / double(in.Rows);
+                if (hint.MsPerRowOn > 0 && hint.MsPerRowOff > 0) hint.HotChoice = hint.MsPerRowOn <= hint.MsPerRowOff ? 1 : 0;
+            }
+        }
         if (!tableFull) break;
         if (cap >= maxCap) return Status::Invalid("internal: group-by table overflow");
         cap = std::min<uint64_t>(cap * 16, maxCap);

@@ -164,12 +164,18 @@ private:
     int ScanRowsPerThread = kRowsPerThread;  // rows per thread of the kernel FillScanArgs / SpecializedKernel plan for
     hipStream_t StreamHandle = nullptr;
     hipEvent_t EvStart = nullptr, EvStop = nullptr;
+    hipEvent_t EvTuneA = nullptr, EvTuneB = nullptr;
     BufferPtr StatusWord;   // device uint32
     // Sizing of the two hash-table levels of a keyed step, learnt from its previous run (performance only).
     struct KeyedHint {
         int LdsCap = 16;
         bool ManyGroups = false;
         uint64_t TableCap = 4096;
+        // The register-held groups pay when a few groups take most rows (TPC-H Q1: 2.7x) and cost registers and per-row
+        // work when they do not (a selective filter in front of thirty groups: 0.6x).  A kernel built for the step is
+        // timed once each way on its first large scans and the faster way is kept.
+        int HotChoice = -1;      // -1 undecided, 0 off, 1 on
+        double MsPerRowOn = 0, MsPerRowOff = 0;
     };
     std::map<const TProgramStep*, KeyedHint> KeyedHints;
 };

@@ -66,6 +66,8 @@ struct KeyedSink {
     uint64_t* t_rep_row;     // [cap] hashed keys: smallest representative row index seen for the group (~0 = none)
     int32_t hot_kind[kHotAggs];  // register path of accumulator k (HotKind)
     int32_t hot_off[kHotAggs];   // LDS byte offset of its 64-bit operand tile
+    int32_t use_hot;             // keep the first groups of a workgroup in registers (else every row goes through the tables)
+    int32_t reserved;
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.

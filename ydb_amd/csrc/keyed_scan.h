@@ -355,7 +355,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
 #pragma unroll
         for (int k = 0; k < kHotAggs; ++k) hot[g][k] = 0;
     }
-    const bool useHot = L >= kHotGroups && !(m.S().debug_flags & 8);
+    const bool useHot = L >= kHotGroups && s.use_hot != 0 && !(m.S().debug_flags & 8);
     // keys of the register-held groups as this wave knows them (a free marker never equals a key)
     uint64_t hotLo[kHotGroups], hotHi[kHotGroups];
 #pragma unroll
