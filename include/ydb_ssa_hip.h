@@ -43,6 +43,8 @@ enum ssa_type {
     SSA_T_STRING = 14, SSA_T_BINARY = 15, SSA_T_DECIMAL128 = 16
 };
 
+enum { SSA_PROGRAM_OLAP_WRAPPER = 1, SSA_PROGRAM_DIRECT_OPERATIONS = 2, SSA_DIRECT_OPERATION_BASE = 1000 };
+
 /* Library / device set-up.  Returns the number of visible HIP devices or a negative ssa_status. */
 int ssa_device_count(void);
 const char* ssa_version(void);
@@ -51,8 +53,13 @@ void ssa_free_string(char* s);
 
 /*
  * Parse a program.  Replaces NOlap::TProgramContainer::Init (ydb/core/tx/program/program.cpp:481-551):
- *  - `program` / `program_size`: serialized NKikimrSSA::TOlapProgram when `olap_wrapper` != 0
+ *  - `program` / `program_size`: serialized NKikimrSSA::TOlapProgram when bit 0 of `olap_wrapper` is set
  *    (EOlapProgramType::OLAP_PROGRAM_SSA_PROGRAM_WITH_PARAMETERS), else a bare NKikimrSSA::TProgram.
+ *    With SSA_PROGRAM_DIRECT_OPERATIONS or-ed into `olap_wrapper`, a TFunction.Id of
+ *    SSA_DIRECT_OPERATION_BASE + NKikimr::NKernels::EOperation (ydb/library/arrow_kernels/operations.h:5-84) stands
+ *    for TAssign(column, operation, arguments) (ydb/core/formats/arrow/program.h:139-147): the operations the
+ *    protobuf has no id for (gcd lcm mod modOrZero abs negate is_valid round roundBankers roundToExp2 floor ceil
+ *    trunc sqrt e pi) reach a step only through such objects (ut/ut_program_step.cpp:30-41).
  *  - `col_ids` / `col_names` / `ncols`: the IColumnResolver (ydb/core/tx/program/program.h:17-25); the
  *    first entry doubles as GetDefaultColumn() for `SELECT count(*)`.
  *  - `params` / `params_schema` (may be NULL): the deserialized TOlapProgram.Parameters batch (one row).

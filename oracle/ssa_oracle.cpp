@@ -167,7 +167,10 @@ static PColumn ReadColumn(Wire w) {
 // ---------------------------------------------------------------------------------------------------
 enum Op {
     OP_NONE, OP_CONST, OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_ISNULL, OP_STRLEN, OP_MATCH, OP_MATCH_LIKE,
-    OP_STARTS, OP_ENDS, OP_NOT, OP_AND, OP_OR, OP_XOR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_CAST, OP_YQL
+    OP_STARTS, OP_ENDS, OP_NOT, OP_AND, OP_OR, OP_XOR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_CAST, OP_YQL,
+    // operations without a protobuf id (TAssign objects built in code)
+    OP_ISVALID, OP_ABS, OP_NEGATE, OP_GCD, OP_LCM, OP_MODULO, OP_MODZ, OP_ROUND, OP_ROUNDBANKERS, OP_ROUNDEXP2,
+    OP_FLOOR, OP_CEIL, OP_TRUNC, OP_SQRT, OP_E, OP_PI
 };
 enum Agg { AG_NONE = 0, AG_SOME = 1, AG_COUNT = 2, AG_MIN = 3, AG_MAX = 4, AG_SUM = 5 };
 
@@ -195,6 +198,7 @@ struct Step {
 
 struct Program {
     std::vector<Step> steps;
+    bool directOperations = false;  // TFunction ids of 1000 + NKernels::EOperation are accepted
     std::map<uint32_t, std::string> resolver;       // column id -> table column name
     std::map<std::string, uint32_t> byName;
     std::vector<std::pair<uint32_t, std::string>> sources;  // in first-use order
@@ -285,6 +289,33 @@ static void ReadFunction(Program& prog, Wire w, Assign& a) {
         a.args.pop_back();
     };
     static const int castTypes[] = {BOOL, I8, I16, I32, I64, U8, U16, U32, U64, F32, F64};
+    if (prog.directOperations && id >= 1000) {
+        // TAssign(column, EOperation, arguments): the enumerators of ydb/library/arrow_kernels/operations.h:5-84 by
+        // position; ValidateOperation (ydb/core/formats/arrow/program.cpp:303-389) checks the arity of the first group only
+        size_t want = 1;
+        switch (id - 1000) {
+            case 17: a.op = OP_ISVALID; break;
+            case 33: a.op = OP_ABS; break;
+            case 34: a.op = OP_NEGATE; break;
+            case 35: a.op = OP_GCD; want = 2; break;
+            case 36: a.op = OP_LCM; want = 2; break;
+            case 37: a.op = OP_MODULO; want = 2; break;
+            case 38: a.op = OP_MODZ; want = 2; break;
+            case 52: a.op = OP_E; want = 0; break;
+            case 60: a.op = OP_PI; want = 0; break;
+            case 62: a.op = OP_SQRT; break;
+            case 64: a.op = OP_FLOOR; break;
+            case 65: a.op = OP_CEIL; break;
+            case 66: a.op = OP_TRUNC; break;
+            case 67: a.op = OP_ROUND; break;
+            case 68: a.op = OP_ROUNDBANKERS; break;
+            case 69: a.op = OP_ROUNDEXP2; break;
+            default: throw Error("Unsupported function");
+        }
+        const bool checked = (id - 1000) <= 47;
+        if (a.args.size() != want) throw Error(checked ? "Wrong arguments count for function" : "Function accepts another number of arguments");
+        return;
+    }
     switch (id) {
         case 1: a.op = OP_EQ; break;
         case 2: a.op = OP_NE; break;
@@ -935,6 +966,181 @@ struct Batch {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------
+// custom-registry kernels (ydb/core/formats/arrow/custom_registry.cpp:47-58) and Arrow's abs / negate / floor / ceil /
+// trunc, each on the C type of the column like the reference's templates
+// ---------------------------------------------------------------------------------------------------
+template <class T> static T GetAs(const Datum& d, int64_t r) {
+    switch (StoreOf(d.ty)) {
+        case S_I: return T(d.I(r));
+        case S_U: return T(d.U(r));
+        default: return T(d.F(r));
+    }
+}
+template <class T> static void PutAs(Datum& d, int64_t r, T v) {
+    switch (StoreOf(d.ty)) {
+        case S_I: d.i[r] = int64_t(v); break;
+        case S_U: d.u[r] = uint64_t(v); break;
+        default: d.f[r] = double(v); break;
+    }
+}
+template <class F> static void WithCType(int ty, F&& f) {
+    switch (ty) {
+        case I8: f(int8_t()); break;
+        case I16: f(int16_t()); break;
+        case I32: f(int32_t()); break;
+        case I64: f(int64_t()); break;
+        case U8: f(uint8_t()); break;
+        case U16: f(uint16_t()); break;
+        case U32: f(uint32_t()); break;
+        case U64: f(uint64_t()); break;
+        case F32: f(float()); break;
+        case F64: f(double()); break;
+        default: throw Error("Function has no kernel matching input types");
+    }
+}
+
+// lhs % rhs in T; the one undefined case (MIN % -1) is given its mathematical value
+template <class T> static T RemT(T lhs, T rhs) {
+    if constexpr (std::is_signed_v<T>) { if (rhs == T(-1)) return 0; }
+    return T(lhs % rhs);
+}
+// func_gcd.h:20-36
+template <class T> static T GcdT(T lhs, T rhs) {
+    while (rhs != 0) {
+        lhs = RemT(lhs, rhs);
+        std::swap(lhs, rhs);
+    }
+    return lhs;
+}
+// func_mul.h:16-53: the product wraps in T
+template <class T> static T MulWrapT(T a, T b) {
+    using UT = std::make_unsigned_t<T>;
+    return T(UT(uint64_t(UT(a)) * uint64_t(UT(b))));
+}
+// func_lcm.h:6-22
+template <class T> static T LcmT(T lhs, T rhs) {
+    const T g = GcdT(lhs, rhs);
+    if (g == 0) throw Error("divide by zero");
+    const T m = MulWrapT(lhs, rhs);
+    if constexpr (std::is_signed_v<T>) {
+        if (g == T(-1)) { using UT = std::make_unsigned_t<T>; return T(UT(0) - UT(m)); }
+    }
+    return T(m / g);
+}
+// func_modulo.h:6-30, func_modulo_or_zero.h:6-28: floats go through int64
+template <class T> static T ModT(T lhs, T rhs, bool orZero) {
+    if constexpr (std::is_floating_point_v<T>) {
+        const int64_t x = int64_t(lhs), y = int64_t(rhs);
+        if (y == 0) { if (orZero) return 0; throw Error("divide by zero"); }
+        return T(RemT<int64_t>(x, y));
+    } else {
+        if (rhs == 0) { if (orZero) return 0; throw Error("divide by zero"); }
+        return RemT(lhs, rhs);
+    }
+}
+
+static DatumPtr CustomBinary(int op, const char* name, DatumPtr a, DatumPtr b) {
+    const bool intsOnly = (op == OP_GCD || op == OP_LCM);
+    int common = (a->ty == b->ty && IsNum(a->ty)) ? a->ty : CommonNumeric(a->ty, b->ty);
+    if (common == NONE || (intsOnly && !IsInt(common)))
+        throw Error(std::string("Function '") + name + "' has no kernel matching input types (" + TyName(a->ty) + ", " + TyName(b->ty) + ")");
+    a = CastTo(a, common, true);
+    b = CastTo(b, common, true);
+    const int64_t n = OutLen(*a, *b);
+    auto out = NewArray(common, n);
+    out->scalar = a->scalar && b->scalar;
+    out->n = out->scalar ? 1 : n;
+    MergeValidity(*a, *b, n, *out);
+    // the applicator visits every slot, null ones too (compute/kernels/codegen_internal.h ScalarBinary::ArrayArray)
+    WithCType(common, [&](auto tag) {
+        using T = decltype(tag);
+        for (int64_t r = 0; r < n; ++r) {
+            const T x = GetAs<T>(*a, r), y = GetAs<T>(*b, r);
+            T v;
+            if constexpr (std::is_floating_point_v<T>) {
+                v = ModT(x, y, op == OP_MODZ);
+            } else {
+                v = op == OP_GCD ? GcdT(x, y) : op == OP_LCM ? LcmT(x, y) : ModT(x, y, op == OP_MODZ);
+            }
+            PutAs<T>(*out, r, v);
+        }
+    });
+    return out;
+}
+
+// func_round.h:23-76 and scalar_arithmetic.cc:81-96,362-378,820-838
+template <class T> static T UnaryT(int op, T x) {
+    using UT = std::conditional_t<std::is_integral_v<T>, std::make_unsigned<T>, std::enable_if<true, T>>;
+    switch (op) {
+        case OP_ABS:
+            if constexpr (std::is_floating_point_v<T>) return std::fabs(x);
+            else if constexpr (std::is_signed_v<T>) return x < 0 ? T(typename UT::type(0) - typename UT::type(x)) : x;
+            else return x;
+        case OP_NEGATE:
+            if constexpr (std::is_floating_point_v<T>) return -x;
+            else return T(typename UT::type(0) - typename UT::type(x));
+        case OP_ROUND: case OP_ROUNDBANKERS: {
+            if constexpr (std::is_floating_point_v<T>) return op == OP_ROUND ? std::round(x) : std::rint(x);
+            else {
+                const double d = op == OP_ROUND ? std::round(double(x)) : std::rint(double(x));
+                // conversions beyond the type's range are undefined in the reference; pinned here to what x86-64 gives
+                if constexpr (std::is_signed_v<T>) return T(d >= 9223372036854775808.0 ? INT64_MIN : int64_t(d));
+                else return T(d >= 18446744073709551616.0 ? uint64_t(0) : uint64_t(d));
+            }
+        }
+        case OP_ROUNDEXP2:
+            if constexpr (std::is_same_v<T, double>) {
+                uint64_t bits; std::memcpy(&bits, &x, 8); bits &= ~((uint64_t(1) << 52) - 1); double r; std::memcpy(&r, &bits, 8); return r;
+            } else if constexpr (std::is_same_v<T, float>) {
+                uint32_t bits; std::memcpy(&bits, &x, 4); bits &= ~((uint32_t(1) << 23) - 1); float r; std::memcpy(&r, &bits, 4); return r;
+            } else if constexpr (sizeof(T) <= 4) {
+                return x <= 0 ? T(0) : T(T(1) << (31 - __builtin_clz(uint32_t(x))));
+            } else {
+                return x <= 0 ? T(0) : T(T(1) << (63 - __builtin_clzll(uint64_t(x))));
+            }
+        default: return x;
+    }
+}
+
+static DatumPtr UnaryLike(const DatumPtr& in, int outTy) {
+    const int64_t n = in->scalar ? 1 : in->n;
+    auto out = NewArray(outTy, n);
+    out->scalar = in->scalar;
+    out->n = in->n;
+    out->ok = in->ok;
+    return out;
+}
+
+static DatumPtr CustomUnary(int op, const char* name, DatumPtr a) {
+    if (!IsNum(a->ty)) throw Error(std::string("Function '") + name + "' has no kernel matching input types (" + TyName(a->ty) + ")");
+    if (op == OP_FLOOR || op == OP_CEIL || op == OP_TRUNC) {
+        if (IsInt(a->ty)) a = CastTo(a, F64, true);  // DispatchBest of the floating-point functions
+        auto out = UnaryLike(a, a->ty);
+        for (size_t r = 0; r < out->f.size(); ++r) {
+            const double x = a->f[r];
+            out->f[r] = op == OP_FLOOR ? std::floor(x) : op == OP_CEIL ? std::ceil(x) : std::trunc(x);
+        }
+        return out;
+    }
+    if (op == OP_SQRT) {  // func_math.h:152-160 through MathUnaryExec: double out, computed in the argument's C type
+        auto out = UnaryLike(a, F64);
+        WithCType(a->ty, [&](auto tag) {
+            using T = decltype(tag);
+            for (size_t r = 0; r < out->f.size(); ++r) out->f[r] = double(std::sqrt(GetAs<T>(*a, int64_t(r))));
+        });
+        return out;
+    }
+    auto out = UnaryLike(a, a->ty);
+    const int64_t n = a->scalar ? 1 : a->n;
+    WithCType(a->ty, [&](auto tag) {
+        using T = decltype(tag);
+        for (int64_t r = 0; r < n; ++r) PutAs<T>(*out, r, UnaryT<T>(op, GetAs<T>(*a, r)));
+    });
+    return out;
+}
+
 static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
     if (a.op == OP_CONST) return a.constant;
     std::vector<DatumPtr> args;
@@ -957,6 +1163,29 @@ static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
             for (int64_t r = 0; r < n; ++r) out->u[r] = !args[0]->Valid(r);
             return out;
         }
+        case OP_ISVALID: {
+            const int64_t n = args[0]->scalar ? 1 : args[0]->n;
+            auto out = NewArray(BOOL, n);
+            out->scalar = args[0]->scalar;
+            out->n = args[0]->n;
+            for (int64_t r = 0; r < n; ++r) out->u[r] = args[0]->Valid(r);
+            return out;
+        }
+        case OP_GCD: return CustomBinary(a.op, "gcd", args[0], args[1]);
+        case OP_LCM: return CustomBinary(a.op, "lcm", args[0], args[1]);
+        case OP_MODULO: return CustomBinary(a.op, "mod", args[0], args[1]);
+        case OP_MODZ: return CustomBinary(a.op, "modOrZero", args[0], args[1]);
+        case OP_ABS: return CustomUnary(a.op, "abs", args[0]);
+        case OP_NEGATE: return CustomUnary(a.op, "negate", args[0]);
+        case OP_ROUND: return CustomUnary(a.op, "round", args[0]);
+        case OP_ROUNDBANKERS: return CustomUnary(a.op, "roundBankers", args[0]);
+        case OP_ROUNDEXP2: return CustomUnary(a.op, "roundToExp2", args[0]);
+        case OP_FLOOR: return CustomUnary(a.op, "floor", args[0]);
+        case OP_CEIL: return CustomUnary(a.op, "ceil", args[0]);
+        case OP_TRUNC: return CustomUnary(a.op, "trunc", args[0]);
+        case OP_SQRT: return CustomUnary(a.op, "sqrt", args[0]);
+        case OP_E: return ScalarF(F64, 2.7182818284590452353602874713526624977572470);   // func_math.h:47-56
+        case OP_PI: return ScalarF(F64, 3.1415926535897932384626433832795028841971693);  // func_math.h:131-140
         case OP_STRLEN: {  // binary_length -> int32 for utf8/binary (compute/kernels/scalar_string.cc:3285-3299)
             if (!IsStr(args[0]->ty)) throw Error("Function 'binary_length' has no kernel matching input types");
             const int64_t n = args[0]->scalar ? 1 : args[0]->n;
@@ -1482,6 +1711,8 @@ void* orc_program_create(const uint8_t* pb, size_t n, int olap_wrapper, const ui
                          size_t ncols, const orc_col* params, size_t nparams, char** err) {
     try {
         auto prog = std::make_unique<Program>();
+        prog->directOperations = (olap_wrapper & 2) != 0;
+        olap_wrapper &= 1;
         for (size_t i = 0; i < ncols; ++i) { prog->resolver[ids[i]] = names[i]; prog->byName[names[i]] = ids[i]; }
         if (ncols) { prog->defaultId = ids[0]; prog->defaultName = names[0]; }
         for (size_t i = 0; i < nparams; ++i) {

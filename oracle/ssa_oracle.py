@@ -208,6 +208,7 @@ class Oracle:
     def __init__(self, resolver: Sequence[Tuple[int, str]], program, parameters: Optional[Dict[str, object]] = None,
                  olap_wrapper: Optional[bool] = None):
         self._lib = load()
+        direct = False
         if hasattr(program, "encode") and not isinstance(program, (bytes, bytearray)):
             body = program.encode()
             n = len(body)
@@ -220,6 +221,7 @@ class Oracle:
                     break
             data = b"\x0a" + bytes(varint) + body  # TOlapProgram { bytes Program = 1 }
             wrapper = True
+            direct = bool(getattr(program, "direct", False))
         else:
             data = bytes(program)
             wrapper = True if olap_wrapper is None else olap_wrapper
@@ -229,7 +231,7 @@ class Oracle:
         pcols, keep = self._columns(parameters or {})
         err = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(data, len(data))
-        self._h = self._lib.orc_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), 1 if wrapper else 0, ids, names,
+        self._h = self._lib.orc_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), (1 if wrapper else 0) | (2 if direct else 0), ids, names,
                                                len(resolver), pcols, len(parameters or {}), ctypes.byref(err))
         if not self._h:
             raise OracleError(_take(self._lib, err.value))

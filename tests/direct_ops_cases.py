@@ -1,0 +1,126 @@
+"""Operations a step gets only through TAssign objects built in code: known-answer vectors of the reference's own tests
+and seeded inputs for GPU-versus-oracle parity.
+
+Vectors: ydb/core/formats/arrow/ut/ut_program_step.cpp:311-400 (Round0, Round1, Gcd, Lcm, Mod, ModOrZero, Abs, Negate),
+ydb/library/arrow_kernels/ut_arithmetic.cpp:69-353 and ut_round.cpp:8-34.  `run(resolver, program, batch)` returns the
+result columns by name.
+"""
+import math
+
+import numpy as np
+
+from ydb_amd.arrow_c import Col
+from ydb_amd.ssa_pb import OP, Column, Program
+
+INT_TYPES = ["int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64"]
+SIGNED = ["int8", "int16", "int32", "int64"]
+FLOATS = ["float32", "float64"]
+
+# (operation, argument types, arguments, expected) -- expected values are in the argument type unless noted
+BINARY_VECTORS = [
+    (OP.Gcd, INT_TYPES, ([32, 12], [24, 10]), [8, 2]),                 # ut_arithmetic.cpp:178-186
+    (OP.Gcd, ["int32"], ([64, 16, 8], [32, 12, 4]), [32, 4, 4]),       # ut_program_step.cpp:362-367
+    (OP.Lcm, INT_TYPES, ([6, 12], [3, 10]), [6, 60]),                  # ut_arithmetic.cpp:239-247
+    (OP.Lcm, ["int32"], ([64, 16, 8], [32, 12, 4]), [64, 48, 8]),      # ut_program_step.cpp:369-374
+    (OP.Modulo, INT_TYPES, ([10, 16], [3, 5]), [1, 1]),                # ut_arithmetic.cpp:305-313
+    (OP.Modulo, FLOATS, ([10.2234, 16.2347], [3.22343, 5.4234]), [1, 1]),  # :315-323
+    (OP.Modulo, ["int32"], ([64, 16, 8], [3, 5, 2]), [1, 1, 0]),       # ut_program_step.cpp:376-381
+    (OP.ModuloOrZero, INT_TYPES, ([10, 16], [6, 0]), [4, 0]),          # ut_arithmetic.cpp:336-344
+    (OP.ModuloOrZero, FLOATS, ([10.2234, 16.2347], [0.23, 5.4234]), [0, 1]),  # :346-353
+    (OP.ModuloOrZero, ["int32"], ([64, 16, 8], [3, 5, 0]), [1, 1, 0]),  # ut_program_step.cpp:383-388
+]
+UNARY_VECTORS = [
+    (OP.Abs, SIGNED, [-32, -12, 54], [32, 12, 54]),                    # ut_arithmetic.cpp:70-77
+    (OP.Abs, ["uint8", "uint16", "uint32", "uint64"], [32, 12, 54], [32, 12, 54]),
+    (OP.Abs, FLOATS, [-32.4, -12.3, 54.7], [32.4, 12.3, 54.7]),
+    (OP.Negate, SIGNED, [-32, -12, 54], [32, 12, -54]),                # ut_arithmetic.cpp:131-138
+    (OP.Negate, FLOATS, [-32.4, -12.3, 54.7], [32.4, 12.3, -54.7]),
+    (OP.Round, FLOATS, [2.34, 5.65, 10.01, 100.0], [2, 6, 10, 100]),   # ut_round.cpp:8-15
+    (OP.RoundBankers, FLOATS, [2.34, 5.5, 6.5, 100.7], [2, 6, 6, 101]),  # ut_round.cpp:17-24
+    (OP.RoundToExp2, INT_TYPES + FLOATS, [2.34, 5.5, 6.5, 100.7, 54], [2, 4, 4, 64, 32]),  # ut_round.cpp:26-33
+    (OP.Round, ["float64"], [32.3, 12.5, 34.7], [32.0, 13.0, 35.0]),   # ut_program_step.cpp:311-317 with libm's values
+    (OP.RoundBankers, ["float64"], [32.3, 12.5, 34.7], [32.0, 12.0, 35.0]),
+    (OP.RoundToExp2, ["float64"], [32.3, 12.5, 34.7], [32.0, 8.0, 32.0]),
+    (OP.Ceil, ["float64"], [32.3, 12.5, 34.7], [33.0, 13.0, 35.0]),    # ut_program_step.cpp:319-325
+    (OP.Floor, ["float64"], [32.3, 12.5, 34.7], [32.0, 12.0, 34.0]),
+    (OP.Trunc, ["float64"], [32.3, 12.5, 34.7], [32.0, 12.0, 34.0]),
+]
+ERROR_VECTORS = [
+    (OP.Lcm, INT_TYPES, ([0, 16], [0, 5])),                            # ut_arithmetic.cpp:294-301
+    (OP.Modulo, FLOATS, ([10.2234, 16.2347], [0, 5.4234])),            # ut_arithmetic.cpp:325-332
+]
+
+
+def type_name(t):
+    return {"float32": "float", "float64": "double"}.get(t, t)
+
+
+def _array(dtype, values):
+    return np.array(values).astype(dtype)   # NumVecToArray: static_cast of doubles to the column's C type
+
+
+def unary_program(op):
+    return Program().assign_op(Column(name="res"), op, [1]).project(["res"])
+
+
+def binary_program(op):
+    return Program().assign_op(Column(name="res"), op, [1, 2]).project(["res"])
+
+
+def check_vectors(run):
+    for op, types, (x, y), want in BINARY_VECTORS:
+        for t in types:
+            out = run([(1, "x"), (2, "y")], binary_program(op), {"x": _array(t, x), "y": _array(t, y)})
+            assert out["res"].type == type_name(t), (op, t, out["res"].type)
+            assert out["res"].to_pylist() == _array(t, want).tolist(), (op, t)
+    for op, types, x, want in UNARY_VECTORS:
+        for t in types:
+            out = run([(1, "x")], unary_program(op), {"x": _array(t, x)})
+            assert out["res"].type == type_name(t), (op, t, out["res"].type)
+            assert out["res"].to_pylist() == _array(t, want).tolist(), (op, t)
+    # the filter programs of ut_program_step.cpp:47-73: res1 = op(x), res2 = (res1 == z), filter res2 -> 3 rows
+    for op, types, x, want in UNARY_VECTORS:
+        t = types[-1]
+        prog = (Program().assign_op(Column(name="res1"), op, [1]).assign_func(Column(name="res2"), 1, ["res1", 2])
+                .filter("res2").project(["res1", "res2"]))
+        out = run([(1, "x"), (2, "z")], prog, {"x": _array(t, x), "z": _array(t, want)})
+        assert len(out["res1"].to_pylist()) == len(x) and all(out["res2"].to_pylist())
+    # constants (func_math.h:47-56,131-140) and is_valid
+    out = run([(1, "x")], Program().assign_op(Column(name="e"), OP.E).assign_op(Column(name="pi"), OP.Pi).project(["e", "pi", 1]),
+              {"x": _array("int32", [1, 2, 3])})
+    assert out["e"].to_pylist() == [math.e] * 3 and out["pi"].to_pylist() == [math.pi] * 3
+    out = run([(1, "x")], unary_program(OP.IsValid), {"x": Col(_array("int32", [1, 2, 3]), valid=np.array([True, False, True]))})
+    assert out["res"].to_pylist() == [True, False, True]
+    out = run([(1, "x")], unary_program(OP.Sqrt), {"x": _array("int32", [0, 4, 2, 1 << 20])})
+    assert out["res"].type == "double" and out["res"].to_pylist() == [0.0, 2.0, math.sqrt(2.0), 1024.0]
+
+
+def check_errors(run_fails):
+    for op, types, (x, y) in ERROR_VECTORS:
+        for t in types:
+            msg = run_fails([(1, "x"), (2, "y")], binary_program(op), {"x": _array(t, x), "y": _array(t, y)})
+            assert "divide by zero" in msg, (op, t, msg)
+    # no kernel: gcd of floats, abs of a string (ut_arithmetic.cpp:213-235)
+    msg = run_fails([(1, "x"), (2, "y")], binary_program(OP.Gcd), {"x": _array("float64", [1.0]), "y": _array("float64", [2.0])})
+    assert "no kernel" in msg
+    msg = run_fails([(1, "x")], unary_program(OP.Negate), {"x": Col(["a"], type="string")})
+    assert "no kernel" in msg
+
+
+def random_column(rng, t, n, nonzero=False, nulls=0.0):
+    if t in FLOATS:
+        v = np.where(rng.random(n) < 0.5, rng.normal(0, 50, n), rng.normal(0, 1e6, n))
+        v = np.where(rng.random(n) < 0.1, np.round(v) + 0.5, v).astype(t)   # ties for the rounding modes
+        if nonzero:
+            v = np.where(np.abs(v) < 1, v + np.copysign(2, v + 0.1), v).astype(t)
+    else:
+        info = np.iinfo(t)
+        small = rng.integers(max(info.min, -200), min(info.max, 200), n, endpoint=True)
+        lo, hi = (info.min + 1, info.max) if info.min < 0 else (0, info.max)
+        wide = rng.integers(lo, hi, n, dtype=np.int64 if t != "uint64" else np.uint64, endpoint=True)
+        v = np.where(rng.random(n) < 0.6, small.astype(t), wide.astype(t)).astype(t)
+        if nonzero:
+            v = np.where(v == 0, 3, v).astype(t)
+    if nulls > 0:
+        return Col(v, valid=rng.random(n) >= nulls)
+    return v

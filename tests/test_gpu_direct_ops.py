@@ -1,0 +1,133 @@
+"""Operations without a protobuf id on the GPU (through the C-ABI): the reference's known-answer vectors, and the CPU
+oracle on seeded inputs -- bit-exact for every operation (sqrt included: both sides round correctly)."""
+import numpy as np
+import pytest
+
+import direct_ops_cases as dc
+from cases import compare_batches
+from ydb_amd.ssa_pb import AGG, OP, Aggregate, Column, Program
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_run(resolver, program, batch):
+    from ydb_amd.program import ProgramContainer
+    pc = ProgramContainer()
+    ok, err = pc.Init(resolver, program)
+    assert ok, err
+    return pc.ApplyProgram(batch)
+
+
+def gpu_fails(resolver, program, batch):
+    from ydb_amd.program import ProgramContainer, SsaError
+    pc = ProgramContainer()
+    ok, err = pc.Init(resolver, program)
+    assert ok, err
+    with pytest.raises(SsaError) as e:
+        pc.ApplyProgram(batch)
+    return str(e.value)
+
+
+def both(resolver, program, batch):
+    from oracle import ssa_oracle
+    return gpu_run(resolver, program, batch), ssa_oracle.Oracle(resolver, program).apply(batch)
+
+
+def test_reference_vectors():
+    dc.check_vectors(gpu_run)
+
+
+def test_reference_errors():
+    dc.check_errors(gpu_fails)
+
+
+def test_flag_is_required():
+    from ydb_amd.program import ProgramContainer
+    ok, err = ProgramContainer().Init([(1, "x")], dc.unary_program(OP.Abs).encode(), olap_wrapper=False)
+    assert not ok
+
+
+UNARY = [OP.Abs, OP.Negate, OP.Round, OP.RoundBankers, OP.RoundToExp2, OP.Floor, OP.Ceil, OP.Trunc, OP.Sqrt, OP.IsValid]
+BINARY = [OP.Gcd, OP.Lcm, OP.Modulo, OP.ModuloOrZero]
+
+
+@pytest.mark.parametrize("t", dc.INT_TYPES + dc.FLOATS)
+@pytest.mark.parametrize("n,nulls", [(1, 0.0), (1025, 0.0), (70_001, 0.1)])
+def test_unary_operations_against_oracle(t, n, nulls):
+    rng = np.random.default_rng(100 + n)
+    x = dc.random_column(rng, t, n, nulls=nulls)
+    if t in dc.INT_TYPES and np.iinfo(t).bits == 64:
+        # floor / ceil / trunc cast integers to double safely: values beyond 2^53 are an error on both sides
+        ops = [o for o in UNARY if o not in (OP.Floor, OP.Ceil, OP.Trunc)]
+    else:
+        ops = UNARY
+    p = Program()
+    for i, op in enumerate(ops):
+        p.assign_op(100 + i, op, [1])
+    p.project([100 + i for i in range(len(ops))])
+    got, exp = both([(1, "x")], p, {"x": x})
+    compare_batches(got, exp)
+
+
+@pytest.mark.parametrize("t", dc.INT_TYPES + dc.FLOATS)
+@pytest.mark.parametrize("n,nulls", [(1, 0.0), (1025, 0.0), (70_001, 0.1)])
+def test_binary_operations_against_oracle(t, n, nulls):
+    rng = np.random.default_rng(200 + n)
+    x = dc.random_column(rng, t, n, nulls=nulls)
+    y = dc.random_column(rng, t, n, nonzero=True)
+    ops = [o for o in BINARY if t in dc.INT_TYPES or o in (OP.Modulo, OP.ModuloOrZero)]
+    p = Program()
+    for i, op in enumerate(ops):
+        p.assign_op(100 + i, op, [1, 2]).assign_op(110 + i, op, [2, 1] if op != OP.Modulo else [1, 2])
+    p.project([100 + i for i in range(len(ops))] + [110 + i for i in range(len(ops))])
+    got, exp = both([(1, "x"), (2, "y")], p, {"x": x, "y": y})
+    compare_batches(got, exp)
+
+
+def test_mixed_types_take_the_common_numeric_type():
+    """ut_arithmetic.cpp:198-211,259-269: operands of different integer types are cast to their common type."""
+    rng = np.random.default_rng(7)
+    n = 5000
+    for t0 in dc.INT_TYPES:
+        for t1 in dc.INT_TYPES:
+            if {t0, t1} == {"int64", "uint64"} or t0 == t1:
+                continue
+            x = rng.integers(1, 100, n).astype(t0)
+            y = rng.integers(1, 100, n).astype(t1)
+            p = (Program().assign_op(100, OP.Gcd, [1, 2]).assign_op(101, OP.Lcm, [1, 2]).assign_op(102, OP.Modulo, [1, 2])
+                 .project([100, 101, 102]))
+            got, exp = both([(1, "x"), (2, "y")], p, {"x": x, "y": y})
+            compare_batches(got, exp)
+            assert got["100"].type == exp["100"].type
+
+
+def test_operations_inside_filters_and_aggregates():
+    """The new operations feed filters, group-by keys and aggregates like any other assign; also through a kernel built
+    for the program."""
+    import os
+    rng = np.random.default_rng(9)
+    n = 300_000
+    batch = {"a": rng.integers(-10**6, 10**6, n).astype(np.int32), "b": rng.integers(1, 50, n).astype(np.int32),
+             "f": rng.normal(0, 100, n)}
+    res = [(1, "a"), (2, "b"), (3, "f")]
+    p = (Program().assign_op(100, OP.ModuloOrZero, [1, 2]).assign_op(101, OP.Abs, [100]).assign_op(102, OP.Round, [3])
+         .assign_const(103, "Int32", 3).assign_func(104, 5, [101, 103]).filter(104)
+         .group_by([Aggregate(110, AGG.SUM, [102]), Aggregate(111, AGG.COUNT, []), Aggregate(112, AGG.MAX, [100])], keys=[101]))
+    for jit in ("0", "1"):
+        os.environ["SSA_JIT"] = jit
+        try:
+            got, exp = both(res, p, batch)
+        finally:
+            del os.environ["SSA_JIT"]
+        compare_batches(got, exp, key_names=["101"], float_sum_names=["110"])
+
+
+def test_divide_by_zero_is_reported_from_any_row():
+    n = 100_000
+    x = np.arange(n, dtype=np.int64)
+    y = np.ones(n, dtype=np.int64)
+    y[n - 7] = 0
+    msg = gpu_fails([(1, "x"), (2, "y")], dc.binary_program(OP.Modulo), {"x": x, "y": y})
+    assert "divide by zero" in msg
+    out = gpu_run([(1, "x"), (2, "y")], dc.binary_program(OP.ModuloOrZero), {"x": x, "y": y})
+    assert out["res"].to_pylist() == [0] * n

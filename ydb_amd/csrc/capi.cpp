@@ -150,7 +150,7 @@ int ssa_program_create(const uint8_t* program, size_t program_size, int olap_wra
     if (!st.ok()) return Fail(st, err);
     auto p = std::make_unique<ssa_program>();
     std::string error;
-    if (!p->Container.Init(resolver, program, program_size, olap_wrapper != 0, parameters, error)) {
+    if (!p->Container.Init(resolver, program, program_size, (olap_wrapper & 1) != 0, parameters, error, (olap_wrapper & SSA_PROGRAM_DIRECT_OPERATIONS) != 0)) {
         return Fail(Status{ST_PARSE_ERROR, error}, err);
     }
     p->Device = device;  // the executor (HIP stream, device buffers) is created at first use

@@ -163,6 +163,7 @@ struct Compiler {
                 case OP_NOT: v = v ? 0 : 1; break;
                 case OP_ISNULL: v = valid ? 0 : 1; valid = true; break;
                 case OP_ISVALID: v = valid ? 1 : 0; valid = true; break;
+                case OP_FUNC: v = ApplyFunc(b, a, v, 0).v; break;
                 default: return Status::Unsupported("cannot fold unary op");
             }
             out = MakeConst(NumScalar(type, v, valid));
@@ -237,6 +238,12 @@ struct Compiler {
                     break;
                 }
                 case OP_CMP: v = CompareVals(b, a, x.Bits, y.Bits); break;
+                case OP_FUNC: {
+                    ArithResult res = ApplyFunc(b, a, x.Bits, y.Bits);
+                    if (res.error) return Status::Invalid("divide by zero");
+                    v = res.v;
+                    break;
+                }
                 case OP_AND:
                     v = (x.Bits && y.Bits);
                     if (b == DIALECT_YQL) valid = (x.Valid && y.Valid) || (x.Valid && !x.Bits) || (y.Valid && !y.Bits);
@@ -372,6 +379,51 @@ struct Compiler {
         return Binary(op, CLS_U, DIALECT_ARROW, l, r, T_BOOL, l->Nullable || r->Nullable, 0, out);
     }
 
+    // gcd / lcm / mod / modOrZero (ydb/library/arrow_kernels/func_common.h:81-143): both operands implicitly cast to the
+    // common numeric type, which is also the result type; gcd and lcm have integer kernels only.
+    Status CustomBinary(int fn, const char* name, ExprPtr l, ExprPtr r, ExprPtr& out) {
+        const int t0 = l->Type, t1 = r->Type;
+        const bool intsOnly = (fn == FN_GCD || fn == FN_LCM);
+        auto okType = [&](int t) { return intsOnly ? IsInt(t) : IsNumeric(t); };
+        int common = (t0 == t1 && okType(t0)) ? t0 : CommonNumeric(t0, t1);
+        if (common == T_NONE || !okType(common)) return Status::Invalid(NoKernel(name, t0, t1));
+        Status st = Cast(l, common, true, l);
+        if (!st.ok()) return st;
+        st = Cast(r, common, true, r);
+        if (!st.ok()) return st;
+        return Binary(OP_FUNC, common, fn, l, r, common, l->Nullable || r->Nullable, 0, out);
+    }
+
+    // abs / negate / round / roundBankers / roundToExp2: one kernel per numeric type, result of the same type
+    // (func_common.h:146-154; compute/kernels/scalar_arithmetic.cc:1205-1214).
+    Status SameTypeUnary(int fn, const char* name, ExprPtr arg, ExprPtr& out) {
+        const int t = arg->Type;
+        if (!IsNumeric(t)) return Status::Invalid(NoKernel(name, t, T_NONE));
+        return Unary(OP_FUNC, t, fn, arg, t, arg->Nullable, out);
+    }
+
+    // floor / ceil / trunc: floating kernels only, integers are implicitly cast to double
+    // (compute/kernels/scalar_arithmetic.cc:1151-1179,1281-1292).
+    Status FloatingUnary(int fn, const char* name, ExprPtr arg, ExprPtr& out) {
+        if (!IsNumeric(arg->Type)) return Status::Invalid(NoKernel(name, arg->Type, T_NONE));
+        if (IsInt(arg->Type)) {
+            Status st = Cast(arg, T_F64, true, arg);
+            if (!st.ok()) return st;
+        }
+        return Unary(OP_FUNC, arg->Type, fn, arg, arg->Type, arg->Nullable, out);
+    }
+
+    // sqrt: a kernel per numeric type with a double result; a float argument is computed in float
+    // (ydb/library/arrow_kernels/func_common.h:156-164, execs.h:113-143).
+    Status MathUnary(int fn, const char* name, ExprPtr arg, ExprPtr& out) {
+        if (!IsNumeric(arg->Type)) return Status::Invalid(NoKernel(name, arg->Type, T_NONE));
+        if (!IsFloat(arg->Type)) {
+            Status st = Cast(arg, T_F64, false, arg);
+            if (!st.ok()) return st;
+        }
+        return Unary(OP_FUNC, arg->Type, fn, arg, T_F64, arg->Nullable, out);
+    }
+
     // ydb.cast with CastOptions(safe=false): ydb/library/arrow_kernels/func_cast.cpp:101-149.
     Status YdbCast(ExprPtr arg, int to, ExprPtr& out) {
         const int from = arg->Type;
@@ -438,6 +490,33 @@ struct Compiler {
                     return Status::OK();
                 }
                 return Unary(OP_ISNULL, 0, 0, args[0], T_BOOL, false, out);
+            case EOperation::IsValid:
+                return Unary(OP_ISVALID, 0, 0, args[0], T_BOOL, false, out);
+            case EOperation::Gcd: return CustomBinary(FN_GCD, fn, args[0], args[1], out);
+            case EOperation::Lcm: return CustomBinary(FN_LCM, fn, args[0], args[1], out);
+            case EOperation::Modulo: return CustomBinary(FN_MOD, fn, args[0], args[1], out);
+            case EOperation::ModuloOrZero: return CustomBinary(FN_MODZ, fn, args[0], args[1], out);
+            case EOperation::Abs: return SameTypeUnary(FN_ABS, fn, args[0], out);
+            case EOperation::Negate: return SameTypeUnary(FN_NEG, fn, args[0], out);
+            case EOperation::Round: case EOperation::RoundBankers: case EOperation::RoundToExp2:
+                if (args.size() != 1) return Status::Invalid(std::string("Function '") + fn + "' accepts 1 arguments");
+                return SameTypeUnary(a.Operation == EOperation::Round ? FN_ROUND
+                                     : a.Operation == EOperation::RoundBankers ? FN_ROUNDBANKERS : FN_ROUNDEXP2, fn, args[0], out);
+            case EOperation::Floor: case EOperation::Ceil: case EOperation::Trunc:
+                if (args.size() != 1) return Status::Invalid(std::string("Function '") + fn + "' accepts 1 arguments");
+                return FloatingUnary(a.Operation == EOperation::Floor ? FN_FLOOR : a.Operation == EOperation::Ceil ? FN_CEIL : FN_TRUNC,
+                                     fn, args[0], out);
+            case EOperation::Sqrt:
+                if (args.size() != 1) return Status::Invalid(std::string("Function '") + fn + "' accepts 1 arguments");
+                return MathUnary(FN_SQRT, fn, args[0], out);
+            case EOperation::E: case EOperation::Pi: {
+                // nullary kernels that return a double scalar (func_common.h:116-122, func_math.h:47-56,131-140)
+                if (!args.empty()) return Status::Invalid(std::string("Function '") + fn + "' accepts 0 arguments");
+                const double v = a.Operation == EOperation::E ? 2.7182818284590452353602874713526624977572470
+                                                              : 3.1415926535897932384626433832795028841971693;
+                out = MakeConst(NumScalar(T_F64, F64ToBits(v), true));
+                return Status::OK();
+            }
             case EOperation::CastBoolean: case EOperation::CastInt8: case EOperation::CastInt16:
             case EOperation::CastInt32: case EOperation::CastInt64: case EOperation::CastUInt8:
             case EOperation::CastUInt16: case EOperation::CastUInt32: case EOperation::CastUInt64:
@@ -691,6 +770,7 @@ struct Compiler {
             case OP_SUB: return OP_RSUB;
             case OP_DIV: return OP_RDIV;
             case OP_MOD: return OP_RMOD;
+            case OP_FUNC: return OP_RFUNC;
             case OP_CMP:
                 b = b == CMP_LT ? CMP_GT : b == CMP_GT ? CMP_LT : b == CMP_LE ? CMP_GE : b == CMP_GE ? CMP_LE : b;
                 a = a == CLS_IU ? CLS_UI : a == CLS_UI ? CLS_IU : a;

@@ -17,6 +17,7 @@ const char* GetFunctionName(EOperation op) {
         case EOperation::CastUInt16: case EOperation::CastUInt32: case EOperation::CastUInt64:
         case EOperation::CastFloat: case EOperation::CastDouble: case EOperation::CastTimestamp:
             return "ydb.cast";
+        case EOperation::IsValid: return "is_valid";
         case EOperation::IsNull: return "is_null";
         case EOperation::Equal: return "equal";
         case EOperation::NotEqual: return "not_equal";
@@ -32,6 +33,38 @@ const char* GetFunctionName(EOperation op) {
         case EOperation::Subtract: return "subtract";
         case EOperation::Multiply: return "multiply";
         case EOperation::Divide: return "divide";
+        case EOperation::Abs: return "abs";
+        case EOperation::Negate: return "negate";
+        case EOperation::Gcd: return "gcd";
+        case EOperation::Lcm: return "lcm";
+        case EOperation::Modulo: return "mod";
+        case EOperation::ModuloOrZero: return "modOrZero";
+        case EOperation::AddNotNull: return "add_checked";
+        case EOperation::SubtractNotNull: return "subtract_checked";
+        case EOperation::MultiplyNotNull: return "multiply_checked";
+        case EOperation::DivideNotNull: return "divide_checked";
+        case EOperation::Acosh: return "acosh";
+        case EOperation::Atanh: return "atanh";
+        case EOperation::Cbrt: return "cbrt";
+        case EOperation::Cosh: return "cosh";
+        case EOperation::E: return "e";
+        case EOperation::Erf: return "erf";
+        case EOperation::Erfc: return "erfc";
+        case EOperation::Exp: return "exp";
+        case EOperation::Exp2: return "exp2";
+        case EOperation::Exp10: return "exp10";
+        case EOperation::Hypot: return "hypot";
+        case EOperation::Lgamma: return "lgamma";
+        case EOperation::Pi: return "pi";
+        case EOperation::Sinh: return "sinh";
+        case EOperation::Sqrt: return "sqrt";
+        case EOperation::Tgamma: return "tgamma";
+        case EOperation::Floor: return "floor";
+        case EOperation::Ceil: return "ceil";
+        case EOperation::Trunc: return "trunc";
+        case EOperation::Round: return "round";
+        case EOperation::RoundBankers: return "roundBankers";
+        case EOperation::RoundToExp2: return "roundToExp2";
         case EOperation::BinaryLength: return "binary_length";
         case EOperation::MatchSubstring: return "match_substring";
         case EOperation::MatchLike: return "match_like";
@@ -67,18 +100,27 @@ EOperation ValidateOperation(EOperation op, uint32_t argsSize) {
         case EOperation::Equal: case EOperation::NotEqual: case EOperation::Less: case EOperation::LessEqual:
         case EOperation::Greater: case EOperation::GreaterEqual: case EOperation::And: case EOperation::Or:
         case EOperation::Xor: case EOperation::Add: case EOperation::Subtract: case EOperation::Multiply:
-        case EOperation::Divide:
+        case EOperation::Divide: case EOperation::Modulo: case EOperation::AddNotNull: case EOperation::SubtractNotNull:
+        case EOperation::MultiplyNotNull: case EOperation::DivideNotNull: case EOperation::ModuloOrZero:
+        case EOperation::Gcd: case EOperation::Lcm:
             need = 2;
             break;
         case EOperation::CastBoolean: case EOperation::CastInt8: case EOperation::CastInt16:
         case EOperation::CastInt32: case EOperation::CastInt64: case EOperation::CastUInt8:
         case EOperation::CastUInt16: case EOperation::CastUInt32: case EOperation::CastUInt64:
         case EOperation::CastFloat: case EOperation::CastDouble: case EOperation::CastTimestamp:
-        case EOperation::IsNull: case EOperation::BinaryLength: case EOperation::Invert:
+        case EOperation::IsValid: case EOperation::IsNull: case EOperation::BinaryLength: case EOperation::Invert:
+        case EOperation::Abs: case EOperation::Negate:
         case EOperation::StartsWith: case EOperation::EndsWith: case EOperation::MatchSubstring:
         case EOperation::MatchLike:
             need = 1;
             break;
+        case EOperation::Acosh: case EOperation::Atanh: case EOperation::Cbrt: case EOperation::Cosh: case EOperation::E:
+        case EOperation::Erf: case EOperation::Erfc: case EOperation::Exp: case EOperation::Exp2: case EOperation::Exp10:
+        case EOperation::Hypot: case EOperation::Lgamma: case EOperation::Pi: case EOperation::Sinh: case EOperation::Sqrt:
+        case EOperation::Tgamma: case EOperation::Floor: case EOperation::Ceil: case EOperation::Trunc:
+        case EOperation::Round: case EOperation::RoundBankers: case EOperation::RoundToExp2:
+            return op;  // the reference does not check these ("TODO: check", program.cpp:361-383)
         default:
             return EOperation::Unspecified;
     }
@@ -225,7 +267,8 @@ PbColumn ReadColumn(std::string_view bytes) {
 
 class TProgramBuilder {
 public:
-    TProgramBuilder(const IColumnResolver& resolver, const TParameters& params) : Resolver(resolver), Params(params) {}
+    TProgramBuilder(const IColumnResolver& resolver, const TParameters& params, bool directOperations)
+        : Resolver(resolver), Params(params), DirectOperations(directOperations) {}
 
     std::string Error;
     std::vector<std::pair<uint32_t, TColumnInfo>> Sources;
@@ -435,6 +478,12 @@ private:
             return res;
         }
 
+        if (DirectOperations && id >= kDirectOperationBase) {
+            // a TAssign built in code: TAssign(column, EOperation, arguments) (ydb/core/formats/arrow/program.h:139-147)
+            const uint32_t op = id - kDirectOperationBase;
+            if (op > uint32_t(EOperation::RoundToExp2)) return res;
+            return finish(EOperation(op));
+        }
         switch (id) {
             case 1: return finish(EOperation::Equal);
             case 2: return finish(EOperation::NotEqual);
@@ -540,13 +589,14 @@ private:
 
     const IColumnResolver& Resolver;
     const TParameters& Params;
+    bool DirectOperations;
     std::unordered_map<std::string, TScalar> Constants;
 };
 
 }  // namespace
 
 bool TProgramContainer::Init(const IColumnResolver& columnResolver, const uint8_t* serialized, size_t size,
-                             bool olapWrapper, const TParameters& parameters, std::string& error) {
+                             bool olapWrapper, const TParameters& parameters, std::string& error, bool directOperations) {
     std::string_view program(reinterpret_cast<const char*>(serialized), size);
     if (olapWrapper) {
         bool found = false;
@@ -563,7 +613,7 @@ bool TProgramContainer::Init(const IColumnResolver& columnResolver, const uint8_
         }
         if (!found) program = std::string_view();
     }
-    if (!ParseProgram(columnResolver, program, parameters, error)) {
+    if (!ParseProgram(columnResolver, program, parameters, error, directOperations)) {
         if (error.empty()) error = "Wrong olap program";
         return false;
     }
@@ -571,9 +621,9 @@ bool TProgramContainer::Init(const IColumnResolver& columnResolver, const uint8_
 }
 
 bool TProgramContainer::ParseProgram(const IColumnResolver& columnResolver, std::string_view program,
-                                     const TParameters& parameters, std::string& error) {
+                                     const TParameters& parameters, std::string& error, bool directOperations) {
     auto ssaProgram = std::make_shared<TProgram>();
-    TProgramBuilder builder(columnResolver, parameters);
+    TProgramBuilder builder(columnResolver, parameters, directOperations);
     auto step = std::make_shared<TProgramStep>();
 
     PbReader r(program);

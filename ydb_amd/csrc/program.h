@@ -20,20 +20,26 @@
 
 namespace ssa {
 
-// Subset of NKikimr::NKernels::EOperation (ydb/library/arrow_kernels/operations.h:5-84) that the
-// protobuf parser can produce (ydb/core/tx/program/program.cpp:126-250).
+// NKikimr::NKernels::EOperation (ydb/library/arrow_kernels/operations.h:5-84), same enumerators in the same order.  The
+// protobuf parser produces the ones with a TFunction id (ydb/core/tx/program/program.cpp:126-250); the others reach a
+// program only through TAssign objects built in code (ydb/core/formats/arrow/ut/ut_program_step.cpp:30-41), which the
+// C-ABI carries as TFunction ids of kDirectOperationBase + the enumerator.
 enum class EOperation {
     Unspecified = 0,
     Constant,
     CastBoolean, CastInt8, CastInt16, CastInt32, CastInt64,
     CastUInt8, CastUInt16, CastUInt32, CastUInt64, CastFloat, CastDouble,
-    CastTimestamp,
-    IsNull,
+    CastBinary, CastFixedSizeBinary, CastString, CastTimestamp,
+    IsValid, IsNull,
     Equal, NotEqual, Less, LessEqual, Greater, GreaterEqual,
     Invert, And, Or, Xor,
-    Add, Subtract, Multiply, Divide,
+    Add, Subtract, Multiply, Divide, Abs, Negate, Gcd, Lcm, Modulo, ModuloOrZero,
+    AddNotNull, SubtractNotNull, MultiplyNotNull, DivideNotNull,
     BinaryLength, MatchSubstring, MatchLike, StartsWith, EndsWith,
+    Acosh, Atanh, Cbrt, Cosh, E, Erf, Erfc, Exp, Exp2, Exp10, Hypot, Lgamma, Pi, Sinh, Sqrt, Tgamma,
+    Floor, Ceil, Trunc, Round, RoundBankers, RoundToExp2,
 };
+constexpr uint32_t kDirectOperationBase = 1000;
 
 // ydb/core/formats/arrow/program.h:16-24
 enum class EAggregate { Unspecified = 0, Some = 1, Count = 2, Min = 3, Max = 4, Sum = 5 };
@@ -172,14 +178,15 @@ public:
     // `serialized` is a TOlapProgram when olapWrapper is true (OLAP_PROGRAM_SSA_PROGRAM_WITH_PARAMETERS),
     // else a bare TProgram.  Returns false and fills `error` on a malformed / unsupported program;
     // an empty error from the builder becomes "Wrong olap program" like the reference does.
+    // `directOperations`: accept TFunction ids of kDirectOperationBase + EOperation as well (see EOperation).
     bool Init(const IColumnResolver& columnResolver, const uint8_t* serialized, size_t size, bool olapWrapper,
-              const TParameters& parameters, std::string& error);
+              const TParameters& parameters, std::string& error, bool directOperations = false);
     bool HasProgram() const { return !!Program; }
     const std::shared_ptr<TProgram>& GetProgram() const { return Program; }
 
 private:
     bool ParseProgram(const IColumnResolver& columnResolver, std::string_view program, const TParameters& parameters,
-                      std::string& error);
+                      std::string& error, bool directOperations);
     std::shared_ptr<TProgram> Program;
 };
 

@@ -114,6 +114,7 @@ __device__ __noinline__ bool StrMatchOutlined(int kind, bool icase, const uint8_
 __device__ __noinline__ int StrCompareOutlined(const uint8_t* a, int32_t n, const uint8_t* b, int32_t m) {
     return StrCompare(a, n, b, m);
 }
+__device__ __noinline__ ArithResult ApplyFuncOutlined(int fn, int t, uint64_t x, uint64_t y) { return ApplyFunc(fn, t, x, y); }
 __device__ __noinline__ uint64_t CastValOutlined(uint64_t v, int from, int to) { return CastVal(v, from, to); }
 __device__ __noinline__ bool FitsTypeOutlined(uint64_t v, int from, int to) { return FitsType(v, from, to); }
 
@@ -967,6 +968,19 @@ struct Machine {
                 }
             }
             A.ok = ok;
+            break;
+        }
+        case OP_FUNC: case OP_RFUNC: {
+            const bool binary = IsBinaryFunc(fb);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t x = op == OP_RFUNC ? B.v[u] : A.v[u];
+                const uint64_t y = op == OP_RFUNC ? A.v[u] : binary ? B.v[u] : 0;
+                const ArithResult r = ApplyFuncOutlined(fb, fa, x, y);
+                A.v[u] = r.v;
+                if (r.error && ((act >> u) & 1u)) err |= SCAN_DIV_BY_ZERO;
+            }
+            if (binary) A.ok &= B.ok;
             break;
         }
         case OP_CMP: {

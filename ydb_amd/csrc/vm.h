@@ -157,7 +157,19 @@ enum OpCode : int32_t {
     OP_ROWIDX,    // A.value = global row index; A's validity is kept
     OP_PREDCMP,   // P &= (column si  cmp  constant a); b = CmpOp | (class << 4).  Fusion of LD col; CMP const; PRED
     OP_DECPART,   // A = part a of decimal128 column si: 0 = bits 0..31, 1 = bits 32..63, 2 = bits 64..127 (validity of the column)
+    OP_FUNC,      // A = f(A, B)          a = TypeId of the operands, b = FuncId; unary functions ignore B
+    OP_RFUNC,     // A = f(B, A)
 };
+
+// Functions of OP_FUNC: the custom-registry kernels of ydb/library/arrow_kernels/func_{gcd,lcm,modulo,modulo_or_zero,
+// round,math}.h and Arrow's abs / negate / floor / ceil / trunc.
+enum FuncId : int32_t {
+    FN_GCD = 1, FN_LCM, FN_MOD, FN_MODZ,
+    FN_ABS, FN_NEG,
+    FN_ROUND, FN_ROUNDBANKERS, FN_ROUNDEXP2, FN_FLOOR, FN_CEIL, FN_TRUNC,
+    FN_SQRT,
+};
+SSA_HD bool IsBinaryFunc(int fn) { return fn >= FN_GCD && fn <= FN_MODZ; }
 
 SSA_HD uint32_t MakeInsn(int op, int sk = 0, int si = 0, int a = 0, int b = 0) {
     return uint32_t(op & 0xFF) | (uint32_t(sk & 3) << 8) | (uint32_t(si & 0x3F) << 10) | (uint32_t(a & 0xFF) << 16) |

@@ -154,6 +154,111 @@ SSA_HD ArithResult ArithDiv(bool mod, int cls, int dialect, int t, uint64_t a, u
     return r;
 }
 
+// x % y as C++ computes it in the operands' type; MIN % -1 (undefined there) is 0.
+SSA_HD uint64_t IntRem(bool sgn, uint64_t a, uint64_t b) {
+    if (!sgn) return a % b;
+    const int64_t x = int64_t(a), y = int64_t(b);
+    return y == -1 ? 0 : uint64_t(x % y);
+}
+
+// One element of an OP_FUNC function on payloads of type `t` (both operands were cast to it).
+//  * gcd / lcm (ydb/library/arrow_kernels/func_gcd.h:20-36, func_lcm.h:6-22): Euclid with the C++ remainder, so the
+//    sign follows the operands; lcm = (lhs * rhs wrapped to the type) / gcd, gcd 0 -> "divide by zero".
+//  * mod / modOrZero (func_modulo.h:6-30, func_modulo_or_zero.h:6-28): floats are converted to int64 first.
+//  * round / roundBankers / roundToExp2 (func_round.h:23-76): integers go through double and back; roundToExp2 is the
+//    largest power of two not above the argument (0 for arguments <= 0), for floats the value with its mantissa cleared.
+//  * abs / negate (compute/kernels/scalar_arithmetic.cc:81-96,362-378): wrap-around integers.
+//  * floor / ceil / trunc (scalar_arithmetic.cc:820-838) and sqrt (func_math.h:152-160) see floating operands only.
+// The kernels are applied to every slot, null ones included (ScalarBinary / ScalarUnary applicators), so `error` does
+// not depend on validity.  Float payloads of T_F32 operands are exact doubles; results are rounded to float again.
+SSA_HD ArithResult ApplyFunc(int fn, int t, uint64_t a, uint64_t b) {
+    ArithResult r{0, false, false};
+    const bool flt = (t == T_F32 || t == T_F64);
+    const bool sgn = IsSignedInt(t) || IsTemporal(t);
+    switch (fn) {
+        case FN_GCD: case FN_LCM: {
+            uint64_t x = a, y = b;
+            while (y != 0) {
+                const uint64_t m = IntRem(sgn, x, y);
+                x = y;
+                y = m;
+            }
+            if (fn == FN_GCD) {
+                r.v = x;
+                break;
+            }
+            if (x == 0) {
+                r.error = true;
+                break;
+            }
+            const uint64_t prod = WrapTo(a * b, t);
+            if (!sgn) r.v = prod / x;
+            else r.v = int64_t(x) == -1 ? uint64_t(0) - prod : uint64_t(int64_t(prod) / int64_t(x));
+            r.v = WrapTo(r.v, t);
+            break;
+        }
+        case FN_MOD: case FN_MODZ: {
+            uint64_t x = a, y = b;
+            bool s = sgn;
+            if (flt) {
+                x = uint64_t(int64_t(BitsToF64(a)));
+                y = uint64_t(int64_t(BitsToF64(b)));
+                s = true;
+            }
+            if (y == 0) {
+                r.error = (fn == FN_MOD);
+                r.v = flt ? F64ToBits(0.0) : 0;
+                break;
+            }
+            const uint64_t m = IntRem(s, x, y);
+            if (t == T_F64) r.v = F64ToBits(double(int64_t(m)));
+            else if (t == T_F32) r.v = F64ToBits(double(float(int64_t(m))));
+            else r.v = m;
+            break;
+        }
+        case FN_ABS:
+            if (flt) r.v = F64ToBits(__builtin_fabs(BitsToF64(a)));
+            else r.v = (sgn && int64_t(a) < 0) ? WrapTo(uint64_t(0) - a, t) : a;
+            break;
+        case FN_NEG:
+            if (flt) r.v = F64ToBits(-BitsToF64(a));
+            else r.v = WrapTo(uint64_t(0) - a, t);
+            break;
+        case FN_ROUND: case FN_ROUNDBANKERS: {
+            double d = flt ? BitsToF64(a) : sgn ? double(int64_t(a)) : double(a);
+            d = fn == FN_ROUND ? __builtin_round(d) : __builtin_rint(d);
+            if (flt) r.v = F64ToBits(d);
+            else if (sgn) r.v = WrapTo(d >= 9223372036854775808.0 ? uint64_t(INT64_MIN) : uint64_t(int64_t(d)), t);
+            else r.v = WrapTo(d >= 18446744073709551616.0 ? 0 : uint64_t(d), t);
+            break;
+        }
+        case FN_ROUNDEXP2:
+            if (t == T_F64) {
+                r.v = a & ~((uint64_t(1) << 52) - 1);
+            } else if (t == T_F32) {
+                const float f = float(BitsToF64(a));
+                uint32_t bits;
+                __builtin_memcpy(&bits, &f, 4);
+                bits &= ~((uint32_t(1) << 23) - 1);
+                r.v = F64ToBits(double(BitsToF32(bits)));
+            } else if (a == 0 || (sgn && int64_t(a) < 0)) {
+                r.v = 0;
+            } else {
+                r.v = uint64_t(1) << (63 - __builtin_clzll(a));
+            }
+            break;
+        case FN_FLOOR: r.v = F64ToBits(__builtin_floor(BitsToF64(a))); break;
+        case FN_CEIL: r.v = F64ToBits(__builtin_ceil(BitsToF64(a))); break;
+        case FN_TRUNC: r.v = F64ToBits(__builtin_trunc(BitsToF64(a))); break;
+        case FN_SQRT:
+            if (t == T_F32) r.v = F64ToBits(double(__builtin_sqrtf(float(BitsToF64(a)))));
+            else r.v = F64ToBits(__builtin_sqrt(BitsToF64(a)));
+            break;
+        default: break;
+    }
+    return r;
+}
+
 SSA_HD bool CompareVals(int cmp, int cls, uint64_t a, uint64_t b) {
     int lt, eq;  // a < b, a == b (unordered floats: both 0 and ne = 1)
     bool unordered = false;

@@ -65,9 +65,11 @@ class ProgramContainer:
     # -- TProgramContainer::Init -------------------------------------------------------------------
     def Init(self, resolver: ColumnResolver, program: Union[Program, bytes], olap_wrapper: Optional[bool] = None,
              parameters: Optional[HostBatch] = None) -> Tuple[bool, str]:
+        direct = False
         if isinstance(program, Program):
             data = olap_program(program)
             wrapper = True
+            direct = program.direct
         else:
             data = bytes(program)
             wrapper = True if olap_wrapper is None else olap_wrapper
@@ -79,7 +81,7 @@ class ProgramContainer:
         buf = ctypes.create_string_buffer(data, len(data))
         pa = ctypes.byref(parameters.array) if parameters is not None else None
         ps = ctypes.byref(parameters.schema) if parameters is not None else None
-        rc = self._lib.ssa_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), 1 if wrapper else 0, ids, names,
+        rc = self._lib.ssa_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), (1 if wrapper else 0) | (2 if direct else 0), ids, names,
                                           len(resolver), pa, ps, self._device, ctypes.byref(out), ctypes.byref(err))
         msg = _lib.take_string(self._lib, err.value)
         if rc != _lib.SSA_OK:

@@ -100,6 +100,31 @@ class YQL:
 
 
 # --- primitive wire encoders --------------------------------------------------
+class OP:
+    """NKikimr::NKernels::EOperation (ydb/library/arrow_kernels/operations.h:5-84), by position.  The ones below have no
+    TFunction id: a step gets them through TAssign(column, operation, arguments) objects built in code
+    (ydb/core/formats/arrow/ut/ut_program_step.cpp:30-41), carried here as TFunction ids of DIRECT_BASE + operation."""
+    IsValid = 17
+    Abs = 33
+    Negate = 34
+    Gcd = 35
+    Lcm = 36
+    Modulo = 37
+    ModuloOrZero = 38
+    E = 52
+    Pi = 60
+    Sqrt = 62
+    Floor = 64
+    Ceil = 65
+    Trunc = 66
+    Round = 67
+    RoundBankers = 68
+    RoundToExp2 = 69
+
+
+DIRECT_BASE = 1000
+
+
 def _varint(v: int) -> bytes:
     if v < 0:
         v += 1 << 64  # negative int32/int64 are sign-extended to 10 bytes
@@ -307,6 +332,15 @@ class Program:
     def assign_func(self, column: Optional[ColLike], func_id: int, args: Sequence[ColLike]) -> "Program":
         self.commands.append(Assign(column, function=Function(func_id, args)))
         return self
+
+    def assign_op(self, column: Optional[ColLike], operation: int, args: Sequence[ColLike] = ()) -> "Program":
+        """TAssign(column, EOperation, arguments) for an operation of class OP."""
+        self.commands.append(Assign(column, function=Function(DIRECT_BASE + operation, args)))
+        return self
+
+    @property
+    def direct(self) -> bool:
+        return any(isinstance(c, Assign) and c.function is not None and c.function.id >= DIRECT_BASE for c in self.commands)
 
     def assign_yql(self, column: Optional[ColLike], yql_op: int, args: Sequence[ColLike],
                    kernel_idx: int = 0, func_id: int = 0) -> "Program":
