@@ -170,7 +170,8 @@ enum Op {
     OP_STARTS, OP_ENDS, OP_NOT, OP_AND, OP_OR, OP_XOR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_CAST, OP_YQL,
     // operations without a protobuf id (TAssign objects built in code)
     OP_ISVALID, OP_ABS, OP_NEGATE, OP_GCD, OP_LCM, OP_MODULO, OP_MODZ, OP_ROUND, OP_ROUNDBANKERS, OP_ROUNDEXP2,
-    OP_FLOOR, OP_CEIL, OP_TRUNC, OP_SQRT, OP_E, OP_PI
+    OP_FLOOR, OP_CEIL, OP_TRUNC, OP_SQRT, OP_E, OP_PI,
+    OP_ACOSH, OP_ATANH, OP_CBRT, OP_COSH, OP_ERF, OP_ERFC, OP_EXP, OP_EXP2, OP_LGAMMA, OP_SINH, OP_TGAMMA, OP_HYPOT
 };
 enum Agg { AG_NONE = 0, AG_SOME = 1, AG_COUNT = 2, AG_MIN = 3, AG_MAX = 4, AG_SUM = 5 };
 
@@ -301,6 +302,19 @@ static void ReadFunction(Program& prog, Wire w, Assign& a) {
             case 36: a.op = OP_LCM; want = 2; break;
             case 37: a.op = OP_MODULO; want = 2; break;
             case 38: a.op = OP_MODZ; want = 2; break;
+            case 48: a.op = OP_ACOSH; break;
+            case 49: a.op = OP_ATANH; break;
+            case 50: a.op = OP_CBRT; break;
+            case 51: a.op = OP_COSH; break;
+            case 53: a.op = OP_ERF; break;
+            case 54: a.op = OP_ERFC; break;
+            case 55: a.op = OP_EXP; break;
+            case 56: a.op = OP_EXP2; break;
+            case 57: throw Error("Key error: No function registered with name: exp10");  // custom_registry.cpp:35-38
+            case 58: a.op = OP_HYPOT; want = 2; break;
+            case 59: a.op = OP_LGAMMA; break;
+            case 61: a.op = OP_SINH; break;
+            case 63: a.op = OP_TGAMMA; break;
             case 52: a.op = OP_E; want = 0; break;
             case 60: a.op = OP_PI; want = 0; break;
             case 62: a.op = OP_SQRT; break;
@@ -1113,6 +1127,25 @@ static DatumPtr UnaryLike(const DatumPtr& in, int outTy) {
     return out;
 }
 
+// hypot (func_math.h:111-119 through MathBinaryExec): operands cast to the common type, double out
+static DatumPtr MathBinary(const char* name, DatumPtr a, DatumPtr b) {
+    int common = (a->ty == b->ty && IsNum(a->ty)) ? a->ty : CommonNumeric(a->ty, b->ty);
+    if (common == NONE)
+        throw Error(std::string("Function '") + name + "' has no kernel matching input types (" + TyName(a->ty) + ", " + TyName(b->ty) + ")");
+    a = CastTo(a, common, true);
+    b = CastTo(b, common, true);
+    const int64_t n = OutLen(*a, *b);
+    auto out = NewArray(F64, n);
+    out->scalar = a->scalar && b->scalar;
+    out->n = out->scalar ? 1 : n;
+    MergeValidity(*a, *b, n, *out);
+    WithCType(common, [&](auto tag) {
+        using T = decltype(tag);
+        for (int64_t r = 0; r < n; ++r) out->f[r] = double(std::hypot(GetAs<T>(*a, r), GetAs<T>(*b, r)));
+    });
+    return out;
+}
+
 static DatumPtr CustomUnary(int op, const char* name, DatumPtr a) {
     if (!IsNum(a->ty)) throw Error(std::string("Function '") + name + "' has no kernel matching input types (" + TyName(a->ty) + ")");
     if (op == OP_FLOOR || op == OP_CEIL || op == OP_TRUNC) {
@@ -1124,11 +1157,31 @@ static DatumPtr CustomUnary(int op, const char* name, DatumPtr a) {
         }
         return out;
     }
-    if (op == OP_SQRT) {  // func_math.h:152-160 through MathUnaryExec: double out, computed in the argument's C type
+    if (op == OP_SQRT || (op >= OP_ACOSH && op <= OP_TGAMMA)) {
+        // func_math.h:7-170 through MathUnaryExec: double out; std:: picks the float overload for a float argument and
+        // the double one for integers
         auto out = UnaryLike(a, F64);
         WithCType(a->ty, [&](auto tag) {
             using T = decltype(tag);
-            for (size_t r = 0; r < out->f.size(); ++r) out->f[r] = double(std::sqrt(GetAs<T>(*a, int64_t(r))));
+            for (size_t r = 0; r < out->f.size(); ++r) {
+                const T x = GetAs<T>(*a, int64_t(r));
+                double v;
+                switch (op) {
+                    case OP_SQRT: v = double(std::sqrt(x)); break;
+                    case OP_ACOSH: v = double(std::acosh(x)); break;
+                    case OP_ATANH: v = double(std::atanh(x)); break;
+                    case OP_CBRT: v = double(std::cbrt(x)); break;
+                    case OP_COSH: v = double(std::cosh(x)); break;
+                    case OP_ERF: v = double(std::erf(x)); break;
+                    case OP_ERFC: v = double(std::erfc(x)); break;
+                    case OP_EXP: v = double(std::exp(x)); break;
+                    case OP_EXP2: v = double(std::exp2(x)); break;
+                    case OP_LGAMMA: v = double(std::lgamma(x)); break;
+                    case OP_SINH: v = double(std::sinh(x)); break;
+                    default: v = double(std::tgamma(x)); break;
+                }
+                out->f[r] = v;
+            }
         });
         return out;
     }
@@ -1184,6 +1237,18 @@ static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
         case OP_CEIL: return CustomUnary(a.op, "ceil", args[0]);
         case OP_TRUNC: return CustomUnary(a.op, "trunc", args[0]);
         case OP_SQRT: return CustomUnary(a.op, "sqrt", args[0]);
+        case OP_ACOSH: return CustomUnary(a.op, "acosh", args[0]);
+        case OP_ATANH: return CustomUnary(a.op, "atanh", args[0]);
+        case OP_CBRT: return CustomUnary(a.op, "cbrt", args[0]);
+        case OP_COSH: return CustomUnary(a.op, "cosh", args[0]);
+        case OP_ERF: return CustomUnary(a.op, "erf", args[0]);
+        case OP_ERFC: return CustomUnary(a.op, "erfc", args[0]);
+        case OP_EXP: return CustomUnary(a.op, "exp", args[0]);
+        case OP_EXP2: return CustomUnary(a.op, "exp2", args[0]);
+        case OP_LGAMMA: return CustomUnary(a.op, "lgamma", args[0]);
+        case OP_SINH: return CustomUnary(a.op, "sinh", args[0]);
+        case OP_TGAMMA: return CustomUnary(a.op, "tgamma", args[0]);
+        case OP_HYPOT: return MathBinary("hypot", args[0], args[1]);
         case OP_E: return ScalarF(F64, 2.7182818284590452353602874713526624977572470);   // func_math.h:47-56
         case OP_PI: return ScalarF(F64, 3.1415926535897932384626433832795028841971693);  // func_math.h:131-140
         case OP_STRLEN: {  // binary_length -> int32 for utf8/binary (compute/kernels/scalar_string.cc:3285-3299)

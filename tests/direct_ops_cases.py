@@ -124,3 +124,39 @@ def random_column(rng, t, n, nonzero=False, nulls=0.0):
     if nulls > 0:
         return Col(v, valid=rng.random(n) >= nulls)
     return v
+
+
+# libm functions (ydb/library/arrow_kernels/func_math.h:7-170): operation, python equivalent, argument range
+MATH_OPS = [
+    (OP.Acosh, math.acosh, (1.0, 1e6)), (OP.Atanh, math.atanh, (-0.999, 0.999)), (OP.Cbrt, lambda v: math.copysign(abs(v) ** (1 / 3), v), (-1e9, 1e9)),
+    (OP.Cosh, math.cosh, (-20.0, 20.0)), (OP.Erf, math.erf, (-4.0, 4.0)), (OP.Erfc, math.erfc, (-4.0, 4.0)),
+    (OP.Exp, math.exp, (-50.0, 50.0)), (OP.Exp2, lambda v: 2.0 ** v, (-60.0, 60.0)), (OP.Lgamma, math.lgamma, (0.05, 100.0)),
+    (OP.Sinh, math.sinh, (-20.0, 20.0)), (OP.Tgamma, math.gamma, (0.05, 30.0)), (OP.Sqrt, math.sqrt, (0.0, 1e12)),
+]
+# ut_math.cpp:19-52: acosh of {2.324, 1.34234, 41.14324, 123} as float32 (computed in float), float64 and integers
+ACOSH_ARGS = [2.324, 1.34234, 41.14324, 123]
+
+
+def math_argument(rng, t, n, lo, hi):
+    v = rng.uniform(lo, hi, n)
+    if t not in FLOATS:
+        info = np.iinfo(t)
+        v = np.clip(np.round(v), max(info.min, math.ceil(lo)), min(info.max, math.floor(hi)))
+    return v.astype(t)
+
+
+def close(a, b, rtol, atol):
+    if a is None or b is None:
+        return a is None and b is None
+    if math.isnan(b) or math.isinf(b):
+        return (math.isnan(a) and math.isnan(b)) or a == b
+    return abs(a - b) <= atol + rtol * abs(b)
+
+
+def check_acosh_vectors(run, rtol64=1e-15, rtol32=1e-7):
+    for t, rtol in (("float64", rtol64), ("float32", rtol32), ("int64", rtol64), ("uint8", rtol64), ("int16", rtol64)):
+        x = _array(t, ACOSH_ARGS)
+        out = run([(1, "x")], unary_program(OP.Acosh), {"x": x})
+        assert out["res"].type == "double"
+        want = [math.acosh(float(v)) for v in x]
+        assert all(close(a, b, rtol, 0) for a, b in zip(out["res"].to_pylist(), want)), (t, out["res"].to_pylist(), want)

@@ -131,3 +131,51 @@ def test_divide_by_zero_is_reported_from_any_row():
     assert "divide by zero" in msg
     out = gpu_run([(1, "x"), (2, "y")], dc.binary_program(OP.ModuloOrZero), {"x": x, "y": y})
     assert out["res"].to_pylist() == [0] * n
+
+
+MATH_RTOL64, MATH_RTOL32 = 1e-13, 1e-6   # the device's math library against the host's: a few units in the last place
+
+
+@pytest.mark.parametrize("t", ["float64", "float32", "int32", "uint8", "int64"])
+def test_math_functions_against_oracle(t):
+    """func_math.h kernels: float arguments are computed in float, everything else in double; results within
+    MATH_RTOL64 / MATH_RTOL32 of the oracle's (which calls the host C library like the reference)."""
+    rng = np.random.default_rng(31)
+    n = 20_000
+    rtol = MATH_RTOL32 if t == "float32" else MATH_RTOL64
+    dc.check_acosh_vectors(gpu_run, rtol64=MATH_RTOL64, rtol32=MATH_RTOL32)
+    for op, _, (lo, hi) in dc.MATH_OPS:
+        x = dc.math_argument(rng, t, n, lo, hi)
+        got, exp = both([(1, "x")], dc.unary_program(op), {"x": x})
+        assert got["res"].type == "double"
+        g, e = got["res"].to_pylist(), exp["res"].to_pylist()
+        atol = 1e-6 if op == OP.Lgamma and t == "float32" else 1e-13 if op == OP.Lgamma else 0.0   # lgamma crosses zero at 1 and 2
+        bad = [(v, a, b) for v, a, b in zip(x, g, e) if not dc.close(a, b, rtol, atol)]
+        assert not bad, (op, t, bad[:5])
+    x, y = dc.math_argument(rng, t, n, -100, 100), dc.math_argument(rng, t, n, -100, 100)
+    got, exp = both([(1, "x"), (2, "y")], dc.binary_program(OP.Hypot), {"x": x, "y": y})
+    assert all(dc.close(a, b, rtol, 0) for a, b in zip(got["res"].to_pylist(), exp["res"].to_pylist()))
+    assert "No function registered" in gpu_fails([(1, "x")], dc.unary_program(OP.Exp10), {"x": x})
+
+
+def test_math_functions_in_a_built_kernel(monkeypatch):
+    monkeypatch.setenv("SSA_JIT", "1")
+    rng = np.random.default_rng(33)
+    n = 100_000
+    batch = {"x": rng.uniform(0.1, 20, n), "k": rng.integers(0, 5, n).astype(np.int32)}
+    p = (Program().assign_op(100, OP.Lgamma, [1]).assign_op(101, OP.Erf, [1]).assign_op(102, OP.Hypot, [100, 101])
+         .group_by([Aggregate(110, AGG.SUM, [102]), Aggregate(111, AGG.MAX, [100])], keys=[2]))
+    got, exp = both([(1, "x"), (2, "k")], p, batch)
+    compare_batches(got, exp, key_names=["k"], float_sum_names=["110", "111"], rtol=1e-9)
+
+
+def test_math_functions_need_a_built_kernel(monkeypatch):
+    """The generic interpreter does not carry the math library: with run-time builds switched off such a program is
+    refused, it does not run on some other path."""
+    from ydb_amd.program import SsaError
+    monkeypatch.setenv("SSA_JIT", "0")
+    with pytest.raises(SsaError) as e:
+        gpu_run([(1, "x")], dc.unary_program(OP.Erf), {"x": np.linspace(-2, 2, 1000)})
+    assert "kernel built for the program" in str(e.value)
+    out = gpu_run([(1, "x")], dc.unary_program(OP.Sqrt), {"x": np.array([4.0, 9.0])})   # the exact operations do run
+    assert out["res"].to_pylist() == [2.0, 3.0]

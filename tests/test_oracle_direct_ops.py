@@ -1,5 +1,7 @@
 """Operations without a protobuf id (gcd lcm mod modOrZero abs negate is_valid round* floor ceil trunc sqrt e pi): the CPU
 oracle against the known-answer vectors of the reference's unit tests (CPU only)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -95,3 +97,21 @@ def test_plan_compiler_lowers_the_direct_operations():
     assert "no kernel matching input types" in str(e.value)
     ok, err = ProgramContainer().Init([(1, "x")], dc.unary_program(OP.Abs).encode(), olap_wrapper=False)
     assert not ok
+
+
+def test_oracle_math_functions_against_python_libm():
+    """func_math.h kernels: the oracle calls the C library like the reference does; Python's math module is the same
+    library for doubles.  ut_math.cpp:19-52 for the argument types."""
+    dc.check_acosh_vectors(oracle_run)
+    rng = np.random.default_rng(21)
+    for op, fn, (lo, hi) in dc.MATH_OPS:
+        x = dc.math_argument(rng, "float64", 500, lo, hi)
+        got = oracle_run([(1, "x")], dc.unary_program(op), {"x": x})["res"].to_pylist()
+        own = op in (OP.Lgamma, OP.Tgamma)   # Python computes these two itself
+        assert all(dc.close(a, fn(float(v)), 1e-11 if own else 1e-13, 1e-12 if own else 1e-300) for a, v in zip(got, x)), op
+    x, y = rng.normal(0, 1e3, 500), rng.normal(0, 1e3, 500)
+    got = oracle_run([(1, "x"), (2, "y")], dc.binary_program(OP.Hypot), {"x": x, "y": y})["res"].to_pylist()
+    assert all(dc.close(a, math.hypot(p, q), 1e-15, 0) for a, p, q in zip(got, x, y))
+    with pytest.raises(ssa_oracle.OracleError) as e:
+        oracle_run([(1, "x")], dc.unary_program(OP.Exp10), {"x": x})
+    assert "No function registered" in str(e.value)

@@ -424,6 +424,24 @@ struct Compiler {
         return Unary(OP_FUNC, arg->Type, fn, arg, T_F64, arg->Nullable, out);
     }
 
+    // hypot: both operands implicitly cast to the common numeric type, double result (func_common.h:166-174).
+    Status MathBinary(int fn, const char* name, ExprPtr l, ExprPtr r, ExprPtr& out) {
+        const int t0 = l->Type, t1 = r->Type;
+        int common = (t0 == t1 && IsNumeric(t0)) ? t0 : CommonNumeric(t0, t1);
+        if (common == T_NONE) return Status::Invalid(NoKernel(name, t0, t1));
+        Status st = Cast(l, common, true, l);
+        if (!st.ok()) return st;
+        st = Cast(r, common, true, r);
+        if (!st.ok()) return st;
+        if (!IsFloat(common)) {
+            st = Cast(l, T_F64, false, l);
+            if (!st.ok()) return st;
+            st = Cast(r, T_F64, false, r);
+            if (!st.ok()) return st;
+        }
+        return Binary(OP_FUNC, l->Type, fn, l, r, T_F64, l->Nullable || r->Nullable, 0, out);
+    }
+
     // ydb.cast with CastOptions(safe=false): ydb/library/arrow_kernels/func_cast.cpp:101-149.
     Status YdbCast(ExprPtr arg, int to, ExprPtr& out) {
         const int from = arg->Type;
@@ -506,9 +524,32 @@ struct Compiler {
                 if (args.size() != 1) return Status::Invalid(std::string("Function '") + fn + "' accepts 1 arguments");
                 return FloatingUnary(a.Operation == EOperation::Floor ? FN_FLOOR : a.Operation == EOperation::Ceil ? FN_CEIL : FN_TRUNC,
                                      fn, args[0], out);
-            case EOperation::Sqrt:
+            case EOperation::Sqrt: case EOperation::Acosh: case EOperation::Atanh: case EOperation::Cbrt: case EOperation::Cosh:
+            case EOperation::Erf: case EOperation::Erfc: case EOperation::Exp: case EOperation::Exp2: case EOperation::Lgamma:
+            case EOperation::Sinh: case EOperation::Tgamma: {
                 if (args.size() != 1) return Status::Invalid(std::string("Function '") + fn + "' accepts 1 arguments");
-                return MathUnary(FN_SQRT, fn, args[0], out);
+                int id = FN_SQRT;
+                switch (a.Operation) {
+                    case EOperation::Acosh: id = FN_ACOSH; break;
+                    case EOperation::Atanh: id = FN_ATANH; break;
+                    case EOperation::Cbrt: id = FN_CBRT; break;
+                    case EOperation::Cosh: id = FN_COSH; break;
+                    case EOperation::Erf: id = FN_ERF; break;
+                    case EOperation::Erfc: id = FN_ERFC; break;
+                    case EOperation::Exp: id = FN_EXP; break;
+                    case EOperation::Exp2: id = FN_EXP2; break;
+                    case EOperation::Lgamma: id = FN_LGAMMA; break;
+                    case EOperation::Sinh: id = FN_SINH; break;
+                    case EOperation::Tgamma: id = FN_TGAMMA; break;
+                    default: break;
+                }
+                return MathUnary(id, fn, args[0], out);
+            }
+            case EOperation::Hypot:
+                if (args.size() != 2) return Status::Invalid(std::string("Function '") + fn + "' accepts 2 arguments");
+                return MathBinary(FN_HYPOT, fn, args[0], args[1], out);
+            case EOperation::Exp10:  // not in the registry (ydb/core/formats/arrow/custom_registry.cpp:35-38)
+                return Status::Invalid("Key error: No function registered with name: exp10");
             case EOperation::E: case EOperation::Pi: {
                 // nullary kernels that return a double scalar (func_common.h:116-122, func_math.h:47-56,131-140)
                 if (!args.empty()) return Status::Invalid(std::string("Function '") + fn + "' accepts 0 arguments");

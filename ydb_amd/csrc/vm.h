@@ -167,9 +167,10 @@ enum FuncId : int32_t {
     FN_GCD = 1, FN_LCM, FN_MOD, FN_MODZ,
     FN_ABS, FN_NEG,
     FN_ROUND, FN_ROUNDBANKERS, FN_ROUNDEXP2, FN_FLOOR, FN_CEIL, FN_TRUNC,
-    FN_SQRT,
+    FN_SQRT, FN_ACOSH, FN_ATANH, FN_CBRT, FN_COSH, FN_ERF, FN_ERFC, FN_EXP, FN_EXP2, FN_LGAMMA, FN_SINH, FN_TGAMMA,  // double result
+    FN_HYPOT,
 };
-SSA_HD bool IsBinaryFunc(int fn) { return fn >= FN_GCD && fn <= FN_MODZ; }
+SSA_HD bool IsBinaryFunc(int fn) { return (fn >= FN_GCD && fn <= FN_MODZ) || fn == FN_HYPOT; }
 
 SSA_HD uint32_t MakeInsn(int op, int sk = 0, int si = 0, int a = 0, int b = 0) {
     return uint32_t(op & 0xFF) | (uint32_t(sk & 3) << 8) | (uint32_t(si & 0x3F) << 10) | (uint32_t(a & 0xFF) << 16) |

@@ -10,6 +10,9 @@
 //    (ydb/library/yql/minikql/invoke_builtins/mkql_builtins_equals.cpp:13-44,
 //     mkql_builtins_less.cpp:13-44, mkql_builtins_div.cpp:30-48)
 #pragma once
+#if !defined(__HIPCC_RTC__)
+#include <math.h>
+#endif
 #include "vm.h"
 
 namespace ssa {
@@ -154,6 +157,52 @@ SSA_HD ArithResult ArithDiv(bool mod, int cls, int dialect, int t, uint64_t a, u
     return r;
 }
 
+// The libm functions of ydb/library/arrow_kernels/func_math.h:7-170: a float argument is computed in float (std::acosh(float)
+// is the float overload) and widened, everything else in double.  The device's math library and the host's differ in the
+// last bits of these functions.
+SSA_HD double MathFunc(int fn, bool f32, double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_SPEC)
+    // The generic interpreter leaves these out (their code costs every program registers); the executor builds a
+    // kernel for any program that uses one and refuses to run it otherwise.
+    (void)fn; (void)f32; (void)x; (void)y;
+    return 0;
+#else
+    if (f32) {
+        const float p = float(x), q = float(y);
+        switch (fn) {
+            case FN_ACOSH: return double(::acoshf(p));
+            case FN_ATANH: return double(::atanhf(p));
+            case FN_CBRT: return double(::cbrtf(p));
+            case FN_COSH: return double(::coshf(p));
+            case FN_ERF: return double(::erff(p));
+            case FN_ERFC: return double(::erfcf(p));
+            case FN_EXP: return double(::expf(p));
+            case FN_EXP2: return double(::exp2f(p));
+            case FN_LGAMMA: return double(::lgammaf(p));
+            case FN_SINH: return double(::sinhf(p));
+            case FN_TGAMMA: return double(::tgammaf(p));
+            case FN_HYPOT: return double(::hypotf(p, q));
+            default: return 0;
+        }
+    }
+    switch (fn) {
+        case FN_ACOSH: return ::acosh(x);
+        case FN_ATANH: return ::atanh(x);
+        case FN_CBRT: return ::cbrt(x);
+        case FN_COSH: return ::cosh(x);
+        case FN_ERF: return ::erf(x);
+        case FN_ERFC: return ::erfc(x);
+        case FN_EXP: return ::exp(x);
+        case FN_EXP2: return ::exp2(x);
+        case FN_LGAMMA: return ::lgamma(x);
+        case FN_SINH: return ::sinh(x);
+        case FN_TGAMMA: return ::tgamma(x);
+        case FN_HYPOT: return ::hypot(x, y);
+        default: return 0;
+    }
+#endif
+}
+
 // x % y as C++ computes it in the operands' type; MIN % -1 (undefined there) is 0.
 SSA_HD uint64_t IntRem(bool sgn, uint64_t a, uint64_t b) {
     if (!sgn) return a % b;
@@ -254,7 +303,9 @@ SSA_HD ArithResult ApplyFunc(int fn, int t, uint64_t a, uint64_t b) {
             if (t == T_F32) r.v = F64ToBits(double(__builtin_sqrtf(float(BitsToF64(a)))));
             else r.v = F64ToBits(__builtin_sqrt(BitsToF64(a)));
             break;
-        default: break;
+        default:
+            r.v = F64ToBits(MathFunc(fn, t == T_F32, BitsToF64(a), BitsToF64(b)));
+            break;
     }
     return r;
 }

@@ -111,9 +111,22 @@ class OP:
     Lcm = 36
     Modulo = 37
     ModuloOrZero = 38
+    Acosh = 48
+    Atanh = 49
+    Cbrt = 50
+    Cosh = 51
     E = 52
+    Erf = 53
+    Erfc = 54
+    Exp = 55
+    Exp2 = 56
+    Exp10 = 57
+    Hypot = 58
+    Lgamma = 59
     Pi = 60
+    Sinh = 61
     Sqrt = 62
+    Tgamma = 63
     Floor = 64
     Ceil = 65
     Trunc = 66
