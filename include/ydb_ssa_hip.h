@@ -58,8 +58,8 @@ void ssa_free_string(char* s);
  *    With SSA_PROGRAM_DIRECT_OPERATIONS or-ed into `olap_wrapper`, a TFunction.Id of
  *    SSA_DIRECT_OPERATION_BASE + NKikimr::NKernels::EOperation (ydb/library/arrow_kernels/operations.h:5-84) stands
  *    for TAssign(column, operation, arguments) (ydb/core/formats/arrow/program.h:139-147): the operations the
- *    protobuf has no id for (gcd lcm mod modOrZero abs negate is_valid round roundBankers roundToExp2 floor ceil
- *    trunc sqrt e pi) reach a step only through such objects (ut/ut_program_step.cpp:30-41).
+ *    protobuf has no id for (gcd lcm mod modOrZero abs negate is_valid the checked arithmetic, the rounding family,
+ *    sqrt e pi and the math-library functions) reach a step only through such objects (ut/ut_program_step.cpp:30-41).
  *  - `col_ids` / `col_names` / `ncols`: the IColumnResolver (ydb/core/tx/program/program.h:17-25); the
  *    first entry doubles as GetDefaultColumn() for `SELECT count(*)`.
  *  - `params` / `params_schema` (may be NULL): the deserialized TOlapProgram.Parameters batch (one row).

@@ -171,7 +171,8 @@ enum Op {
     // operations without a protobuf id (TAssign objects built in code)
     OP_ISVALID, OP_ABS, OP_NEGATE, OP_GCD, OP_LCM, OP_MODULO, OP_MODZ, OP_ROUND, OP_ROUNDBANKERS, OP_ROUNDEXP2,
     OP_FLOOR, OP_CEIL, OP_TRUNC, OP_SQRT, OP_E, OP_PI,
-    OP_ACOSH, OP_ATANH, OP_CBRT, OP_COSH, OP_ERF, OP_ERFC, OP_EXP, OP_EXP2, OP_LGAMMA, OP_SINH, OP_TGAMMA, OP_HYPOT
+    OP_ACOSH, OP_ATANH, OP_CBRT, OP_COSH, OP_ERF, OP_ERFC, OP_EXP, OP_EXP2, OP_LGAMMA, OP_SINH, OP_TGAMMA, OP_HYPOT,
+    OP_ADD_CHECKED, OP_SUB_CHECKED, OP_MUL_CHECKED, OP_DIV_CHECKED
 };
 enum Agg { AG_NONE = 0, AG_SOME = 1, AG_COUNT = 2, AG_MIN = 3, AG_MAX = 4, AG_SUM = 5 };
 
@@ -302,6 +303,10 @@ static void ReadFunction(Program& prog, Wire w, Assign& a) {
             case 36: a.op = OP_LCM; want = 2; break;
             case 37: a.op = OP_MODULO; want = 2; break;
             case 38: a.op = OP_MODZ; want = 2; break;
+            case 39: a.op = OP_ADD_CHECKED; want = 2; break;
+            case 40: a.op = OP_SUB_CHECKED; want = 2; break;
+            case 41: a.op = OP_MUL_CHECKED; want = 2; break;
+            case 42: a.op = OP_DIV_CHECKED; want = 2; break;
             case 48: a.op = OP_ACOSH; break;
             case 49: a.op = OP_ATANH; break;
             case 50: a.op = OP_CBRT; break;
@@ -1127,6 +1132,52 @@ static DatumPtr UnaryLike(const DatumPtr& in, int outTy) {
     return out;
 }
 
+// add_checked / subtract_checked / multiply_checked / divide_checked (compute/kernels/scalar_arithmetic.cc:147-360):
+// overflow of the column's C type is an error; only non-null slots are visited, the others hold 0.
+template <class T> static T CheckedT(int op, T x, T y) {
+    if constexpr (std::is_floating_point_v<T>) {
+        if (op == OP_DIV_CHECKED) {
+            if (y == 0) throw Error("divide by zero");
+            return x / y;
+        }
+        return op == OP_ADD_CHECKED ? x + y : op == OP_SUB_CHECKED ? x - y : x * y;
+    } else {
+        if (op == OP_DIV_CHECKED) {
+            if (y == 0) throw Error("divide by zero");
+            if constexpr (std::is_signed_v<T>) {
+                if (x == std::numeric_limits<T>::min() && y == T(-1)) throw Error("overflow");
+            }
+            return T(x / y);
+        }
+        T r = 0;
+        const bool over = op == OP_ADD_CHECKED ? __builtin_add_overflow(x, y, &r)
+                          : op == OP_SUB_CHECKED ? __builtin_sub_overflow(x, y, &r) : __builtin_mul_overflow(x, y, &r);
+        if (over) throw Error("overflow");
+        return r;
+    }
+}
+
+static DatumPtr CheckedArith(int op, const char* name, DatumPtr a, DatumPtr b) {
+    int common = (a->ty == b->ty && IsNum(a->ty)) ? a->ty : CommonNumeric(a->ty, b->ty);
+    if (common == NONE)
+        throw Error(std::string("Function '") + name + "' has no kernel matching input types (" + TyName(a->ty) + ", " + TyName(b->ty) + ")");
+    a = CastTo(a, common, true);
+    b = CastTo(b, common, true);
+    const int64_t n = OutLen(*a, *b);
+    auto out = NewArray(common, n);
+    out->scalar = a->scalar && b->scalar;
+    out->n = out->scalar ? 1 : n;
+    MergeValidity(*a, *b, n, *out);
+    WithCType(common, [&](auto tag) {
+        using T = decltype(tag);
+        for (int64_t r = 0; r < n; ++r) {
+            if (!out->ok.empty() && !out->ok[r]) continue;
+            PutAs<T>(*out, r, CheckedT<T>(op, GetAs<T>(*a, r), GetAs<T>(*b, r)));
+        }
+    });
+    return out;
+}
+
 // hypot (func_math.h:111-119 through MathBinaryExec): operands cast to the common type, double out
 static DatumPtr MathBinary(const char* name, DatumPtr a, DatumPtr b) {
     int common = (a->ty == b->ty && IsNum(a->ty)) ? a->ty : CommonNumeric(a->ty, b->ty);
@@ -1249,6 +1300,10 @@ static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
         case OP_SINH: return CustomUnary(a.op, "sinh", args[0]);
         case OP_TGAMMA: return CustomUnary(a.op, "tgamma", args[0]);
         case OP_HYPOT: return MathBinary("hypot", args[0], args[1]);
+        case OP_ADD_CHECKED: return CheckedArith(a.op, "add_checked", args[0], args[1]);
+        case OP_SUB_CHECKED: return CheckedArith(a.op, "subtract_checked", args[0], args[1]);
+        case OP_MUL_CHECKED: return CheckedArith(a.op, "multiply_checked", args[0], args[1]);
+        case OP_DIV_CHECKED: return CheckedArith(a.op, "divide_checked", args[0], args[1]);
         case OP_E: return ScalarF(F64, 2.7182818284590452353602874713526624977572470);   // func_math.h:47-56
         case OP_PI: return ScalarF(F64, 3.1415926535897932384626433832795028841971693);  // func_math.h:131-140
         case OP_STRLEN: {  // binary_length -> int32 for utf8/binary (compute/kernels/scalar_string.cc:3285-3299)

@@ -160,3 +160,54 @@ def check_acosh_vectors(run, rtol64=1e-15, rtol32=1e-7):
         assert out["res"].type == "double"
         want = [math.acosh(float(v)) for v in x]
         assert all(close(a, b, rtol, 0) for a, b in zip(out["res"].to_pylist(), want)), (t, out["res"].to_pylist(), want)
+
+
+CHECKED = [OP.AddNotNull, OP.SubtractNotNull, OP.MultiplyNotNull, OP.DivideNotNull]
+
+
+def checked_expected(op, t, a, b):
+    """Python-integer model of add_checked ... divide_checked on one pair: the value, or the error message."""
+    if t in FLOATS:
+        raise ValueError
+    info = np.iinfo(t)
+    a, b = int(a), int(b)
+    if op == OP.DivideNotNull:
+        if b == 0:
+            return "divide by zero"
+        q = abs(a) // abs(b) * (1 if (a >= 0) == (b >= 0) else -1)
+    else:
+        q = a + b if op == OP.AddNotNull else a - b if op == OP.SubtractNotNull else a * b
+    return q if info.min <= q <= info.max else "overflow"
+
+
+def check_checked_arithmetic(run, run_fails):
+    rng = np.random.default_rng(41)
+    for t in INT_TYPES:
+        info = np.iinfo(t)
+        # pairs around the type's limits, one program run per pair so that each error is attributed
+        edge = [info.min, info.min + 1, -1, 0, 1, 2, info.max - 1, info.max]
+        edge = [v for v in edge if info.min <= v <= info.max]
+        for op in CHECKED:
+            for a in edge:
+                for b in edge:
+                    want = checked_expected(op, t, a, b)
+                    batch = {"x": _array(t, [a]), "y": _array(t, [b])}
+                    if isinstance(want, str):
+                        assert want in run_fails([(1, "x"), (2, "y")], binary_program(op), batch), (op, t, a, b)
+                    else:
+                        got = run([(1, "x"), (2, "y")], binary_program(op), batch)["res"]
+                        assert got.type == type_name(t) and got.to_pylist() == [want], (op, t, a, b)
+    # null slots are not visited: an overflowing pair under a null is no error and leaves a null
+    x = Col(_array("int8", [100, 100, 3]), valid=np.array([True, False, True]))
+    y = _array("int8", [1, 100, 0])
+    out = run([(1, "x"), (2, "y")], binary_program(OP.AddNotNull), {"x": x, "y": y})
+    assert out["res"].to_pylist() == [101, None, 3]
+    assert "divide by zero" in run_fails([(1, "x"), (2, "y")], binary_program(OP.DivideNotNull), {"x": x, "y": y})
+    # floats: plain arithmetic, division by zero is an error
+    for t in FLOATS:
+        a, b = rng.normal(0, 100, 200).astype(t), (rng.normal(0, 100, 200).astype(t) + np.array(1000, dtype=t))
+        for op, f in zip(CHECKED, (np.add, np.subtract, np.multiply, np.divide)):
+            out = run([(1, "x"), (2, "y")], binary_program(op), {"x": a, "y": b})
+            assert out["res"].to_pylist() == f(a, b).tolist(), (op, t)
+        assert "divide by zero" in run_fails([(1, "x"), (2, "y")], binary_program(OP.DivideNotNull),
+                                             {"x": _array(t, [1.0]), "y": _array(t, [0.0])})

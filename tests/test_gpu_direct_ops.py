@@ -179,3 +179,32 @@ def test_math_functions_need_a_built_kernel(monkeypatch):
     assert "kernel built for the program" in str(e.value)
     out = gpu_run([(1, "x")], dc.unary_program(OP.Sqrt), {"x": np.array([4.0, 9.0])})   # the exact operations do run
     assert out["res"].to_pylist() == [2.0, 3.0]
+
+
+def test_checked_arithmetic():
+    """add_checked ... divide_checked around every integer type's limits (Python integers as the model) and on floats."""
+    dc.check_checked_arithmetic(gpu_run, gpu_fails)
+
+
+@pytest.mark.parametrize("t", ["int16", "uint32", "int64", "float64"])
+def test_checked_arithmetic_against_oracle(t):
+    rng = np.random.default_rng(43)
+    n = 50_000
+    if t in dc.FLOATS:
+        x, y = rng.normal(0, 100, n), rng.normal(0, 100, n) + 1000
+    else:
+        hi = 150 if t == "int16" else 60_000 if t == "uint32" else 3_000_000_000
+        x = rng.integers(hi // 2, hi, n).astype(t)     # x >= y: an unsigned difference must not wrap
+        y = rng.integers(1, hi // 2, n).astype(t)
+    x = dc.Col(x, valid=rng.random(n) > 0.1)
+    p = Program()
+    outs = []
+    for i, op in enumerate(dc.CHECKED):
+        p.assign_op(100 + i, op, [1, 2])
+        outs.append(100 + i)
+        if not (t.startswith("uint") and op == OP.SubtractNotNull):
+            p.assign_op(110 + i, op, [2, 1])
+            outs.append(110 + i)
+    p.project(outs)
+    got, exp = both([(1, "x"), (2, "y")], p, {"x": x, "y": y})
+    compare_batches(got, exp)

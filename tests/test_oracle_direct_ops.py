@@ -115,3 +115,7 @@ def test_oracle_math_functions_against_python_libm():
     with pytest.raises(ssa_oracle.OracleError) as e:
         oracle_run([(1, "x")], dc.unary_program(OP.Exp10), {"x": x})
     assert "No function registered" in str(e.value)
+
+
+def test_oracle_checked_arithmetic_against_python_integers():
+    dc.check_checked_arithmetic(oracle_run, oracle_fails)

@@ -187,6 +187,7 @@ Status Executor::CheckScanStatus(bool* tableFull) {
     SSA_HIP(hipMemsetAsync(StatusWord->Ptr, 0, sizeof(st), StreamHandle));
     if (st & SCAN_DIV_BY_ZERO) return Status::Invalid("divide by zero");
     if (st & SCAN_CAST_OVERFLOW) return Status::Invalid("Integer value not in range");
+    if (st & SCAN_OVERFLOW) return Status::Invalid("overflow");
     if (st == SCAN_TABLE_FULL && tableFull) {
         *tableFull = true;
         return Status::OK();

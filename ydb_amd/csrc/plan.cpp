@@ -239,8 +239,10 @@ struct Compiler {
                 }
                 case OP_CMP: v = CompareVals(b, a, x.Bits, y.Bits); break;
                 case OP_FUNC: {
+                    if (IsNotNullFunc(b) && !valid) break;  // v = 0
                     ArithResult res = ApplyFunc(b, a, x.Bits, y.Bits);
                     if (res.error) return Status::Invalid("divide by zero");
+                    if (res.overflow) return Status::Invalid("overflow");
                     v = res.v;
                     break;
                 }
@@ -424,6 +426,19 @@ struct Compiler {
         return Unary(OP_FUNC, arg->Type, fn, arg, T_F64, arg->Nullable, out);
     }
 
+    // add_checked / subtract_checked / multiply_checked / divide_checked: typed like their unchecked forms
+    // (compute/kernels/scalar_arithmetic.cc:1193-1203).
+    Status CheckedArith(int fn, const char* name, ExprPtr l, ExprPtr r, ExprPtr& out) {
+        const int t0 = l->Type, t1 = r->Type;
+        int common = (t0 == t1 && IsNumeric(t0)) ? t0 : CommonNumeric(t0, t1);
+        if (common == T_NONE) return Status::Invalid(NoKernel(name, t0, t1));
+        Status st = Cast(l, common, true, l);
+        if (!st.ok()) return st;
+        st = Cast(r, common, true, r);
+        if (!st.ok()) return st;
+        return Binary(OP_FUNC, common, fn, l, r, common, l->Nullable || r->Nullable, 0, out);
+    }
+
     // hypot: both operands implicitly cast to the common numeric type, double result (func_common.h:166-174).
     Status MathBinary(int fn, const char* name, ExprPtr l, ExprPtr r, ExprPtr& out) {
         const int t0 = l->Type, t1 = r->Type;
@@ -514,6 +529,10 @@ struct Compiler {
             case EOperation::Lcm: return CustomBinary(FN_LCM, fn, args[0], args[1], out);
             case EOperation::Modulo: return CustomBinary(FN_MOD, fn, args[0], args[1], out);
             case EOperation::ModuloOrZero: return CustomBinary(FN_MODZ, fn, args[0], args[1], out);
+            case EOperation::AddNotNull: return CheckedArith(FN_ADD_CHECKED, fn, args[0], args[1], out);
+            case EOperation::SubtractNotNull: return CheckedArith(FN_SUB_CHECKED, fn, args[0], args[1], out);
+            case EOperation::MultiplyNotNull: return CheckedArith(FN_MUL_CHECKED, fn, args[0], args[1], out);
+            case EOperation::DivideNotNull: return CheckedArith(FN_DIV_CHECKED, fn, args[0], args[1], out);
             case EOperation::Abs: return SameTypeUnary(FN_ABS, fn, args[0], out);
             case EOperation::Negate: return SameTypeUnary(FN_NEG, fn, args[0], out);
             case EOperation::Round: case EOperation::RoundBankers: case EOperation::RoundToExp2:

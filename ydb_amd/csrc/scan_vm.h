@@ -972,15 +972,21 @@ struct Machine {
         }
         case OP_FUNC: case OP_RFUNC: {
             const bool binary = IsBinaryFunc(fb);
+            if (binary) A.ok &= B.ok;
+            // the checked kernels visit valid slots only and leave 0 under the others
+            const uint32_t visit = IsNotNullFunc(fb) ? (act & A.ok) : act;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint64_t x = op == OP_RFUNC ? B.v[u] : A.v[u];
                 const uint64_t y = op == OP_RFUNC ? A.v[u] : binary ? B.v[u] : 0;
-                const ArithResult r = ApplyFuncOutlined(fb, fa, x, y);
-                A.v[u] = r.v;
-                if (r.error && ((act >> u) & 1u)) err |= SCAN_DIV_BY_ZERO;
+                uint64_t v = 0;
+                if (!IsNotNullFunc(fb) || ((visit >> u) & 1u)) {
+                    const ArithResult r = ApplyFuncOutlined(fb, fa, x, y);
+                    v = r.v;
+                    if ((visit >> u) & 1u) err |= (r.error ? SCAN_DIV_BY_ZERO : 0u) | (r.overflow ? SCAN_OVERFLOW : 0u);
+                }
+                A.v[u] = v;
             }
-            if (binary) A.ok &= B.ok;
             break;
         }
         case OP_CMP: {

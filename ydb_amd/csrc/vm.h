@@ -169,8 +169,10 @@ enum FuncId : int32_t {
     FN_ROUND, FN_ROUNDBANKERS, FN_ROUNDEXP2, FN_FLOOR, FN_CEIL, FN_TRUNC,
     FN_SQRT, FN_ACOSH, FN_ATANH, FN_CBRT, FN_COSH, FN_ERF, FN_ERFC, FN_EXP, FN_EXP2, FN_LGAMMA, FN_SINH, FN_TGAMMA,  // double result
     FN_HYPOT,
+    FN_ADD_CHECKED, FN_SUB_CHECKED, FN_MUL_CHECKED, FN_DIV_CHECKED,  // computed on non-null slots only
 };
-SSA_HD bool IsBinaryFunc(int fn) { return (fn >= FN_GCD && fn <= FN_MODZ) || fn == FN_HYPOT; }
+SSA_HD bool IsBinaryFunc(int fn) { return (fn >= FN_GCD && fn <= FN_MODZ) || fn >= FN_HYPOT; }
+SSA_HD bool IsNotNullFunc(int fn) { return fn >= FN_ADD_CHECKED && fn <= FN_DIV_CHECKED; }
 
 SSA_HD uint32_t MakeInsn(int op, int sk = 0, int si = 0, int a = 0, int b = 0) {
     return uint32_t(op & 0xFF) | (uint32_t(sk & 3) << 8) | (uint32_t(si & 0x3F) << 10) | (uint32_t(a & 0xFF) << 16) |
@@ -196,7 +198,8 @@ enum ScanStatus : uint32_t {
     SCAN_OK = 0,
     SCAN_DIV_BY_ZERO = 1,      // Arrow integer divide by zero -> Status::Invalid("divide by zero")
     SCAN_CAST_OVERFLOW = 2,    // safe implicit cast failed -> Status::Invalid("Integer value ... not in range")
-    SCAN_TABLE_FULL = 4,       // group-by spill table ran out of slots (host retries with a bigger one)
+    SCAN_TABLE_FULL = 4,
+    SCAN_OVERFLOW = 8,         // checked integer arithmetic -> Status::Invalid("overflow")       // group-by spill table ran out of slots (host retries with a bigger one)
 };
 
 struct DevColumn {

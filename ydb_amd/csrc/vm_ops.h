@@ -108,6 +108,7 @@ struct ArithResult {
     uint64_t v;
     bool null;   // YQL: result is NULL
     bool error;  // Arrow: divide by zero
+    bool overflow;  // Arrow checked arithmetic: the result does not fit the type
 };
 
 // ADD/SUB/MUL on payloads; integer results still need WrapTo(result type).
@@ -221,7 +222,7 @@ SSA_HD uint64_t IntRem(bool sgn, uint64_t a, uint64_t b) {
 // The kernels are applied to every slot, null ones included (ScalarBinary / ScalarUnary applicators), so `error` does
 // not depend on validity.  Float payloads of T_F32 operands are exact doubles; results are rounded to float again.
 SSA_HD ArithResult ApplyFunc(int fn, int t, uint64_t a, uint64_t b) {
-    ArithResult r{0, false, false};
+    ArithResult r{0, false, false, false};
     const bool flt = (t == T_F32 || t == T_F64);
     const bool sgn = IsSignedInt(t) || IsTemporal(t);
     switch (fn) {
@@ -303,6 +304,50 @@ SSA_HD ArithResult ApplyFunc(int fn, int t, uint64_t a, uint64_t b) {
             if (t == T_F32) r.v = F64ToBits(double(__builtin_sqrtf(float(BitsToF64(a)))));
             else r.v = F64ToBits(__builtin_sqrt(BitsToF64(a)));
             break;
+        case FN_ADD_CHECKED: case FN_SUB_CHECKED: case FN_MUL_CHECKED: case FN_DIV_CHECKED: {
+            // add_checked ... divide_checked (compute/kernels/scalar_arithmetic.cc:147-169,329-360)
+            if (flt) {
+                if (fn == FN_DIV_CHECKED && BitsToF64(b) == 0.0) {
+                    r.error = true;
+                    r.v = F64ToBits(0.0);
+                    break;
+                }
+                const int cls = t == T_F32 ? CLS_F32 : CLS_F64;
+                if (fn == FN_DIV_CHECKED) r.v = ArithDiv(false, cls, DIALECT_ARROW, t, a, b).v;
+                else r.v = ArithBasic(fn == FN_ADD_CHECKED ? OP_ADD : fn == FN_SUB_CHECKED ? OP_SUB : OP_MUL, cls, a, b);
+                break;
+            }
+            if (fn == FN_DIV_CHECKED) {
+                if (b == 0) {
+                    r.error = true;
+                    break;
+                }
+                if (sgn) {
+                    const int64_t lo = (t == T_I8) ? -128 : (t == T_I16) ? -32768 : (t == T_I32) ? -2147483648LL : INT64_MIN;
+                    if (int64_t(a) == lo && int64_t(b) == -1) r.overflow = true;
+                    else r.v = uint64_t(int64_t(a) / int64_t(b));
+                } else {
+                    r.v = a / b;
+                }
+                break;
+            }
+            bool over;
+            if (sgn) {
+                long long v = 0;
+                const long long x = (long long)int64_t(a), y = (long long)int64_t(b);
+                over = fn == FN_ADD_CHECKED ? __builtin_saddll_overflow(x, y, &v)
+                       : fn == FN_SUB_CHECKED ? __builtin_ssubll_overflow(x, y, &v) : __builtin_smulll_overflow(x, y, &v);
+                r.v = uint64_t(v);
+            } else {
+                unsigned long long v = 0;
+                over = fn == FN_ADD_CHECKED ? __builtin_uaddll_overflow(a, b, &v)
+                       : fn == FN_SUB_CHECKED ? __builtin_usubll_overflow(a, b, &v) : __builtin_umulll_overflow(a, b, &v);
+                r.v = uint64_t(v);
+            }
+            if (!over && WrapTo(r.v, t) != r.v) over = true;  // fits 64 bits but not the column's type
+            r.overflow = over;
+            break;
+        }
         default:
             r.v = F64ToBits(MathFunc(fn, t == T_F32, BitsToF64(a), BitsToF64(b)));
             break;

@@ -111,6 +111,10 @@ class OP:
     Lcm = 36
     Modulo = 37
     ModuloOrZero = 38
+    AddNotNull = 39        # add_checked
+    SubtractNotNull = 40
+    MultiplyNotNull = 41
+    DivideNotNull = 42
     Acosh = 48
     Atanh = 49
     Cbrt = 50
