@@ -1245,6 +1245,30 @@ static DatumPtr CustomUnary(int op, const char* name, DatumPtr a) {
     return out;
 }
 
+// BlockIf (ydb/library/yql/minikql/comp_nodes/mkql_block_if.cpp:66-250): row i takes then[i] or else[i], value and
+// nullness, by the predicate's value byte; a scalar predicate returns the chosen branch as it is.
+static DatumPtr YqlIf(const DatumPtr& pred, const DatumPtr& th, const DatumPtr& el) {
+    if (!(pred->ty == U8 || pred->ty == BOOL) || pred->MayHaveNulls() || (pred->scalar && !pred->Valid(0)))
+        throw Error("Expected bool as first argument");
+    if (th->ty != el->ty) throw Error("Different return types in branches.");
+    if (IsStr(th->ty) || th->ty == DEC) throw Error("Unsupported: If over string or decimal branches");
+    if (pred->scalar) return pred->u[0] ? th : el;
+    const int64_t n = pred->n;
+    auto out = NewArray(th->ty, n);
+    const bool nulls = !th->ok.empty() || !el->ok.empty();
+    if (nulls) out->ok.assign(size_t(n), 1);
+    for (int64_t r = 0; r < n; ++r) {
+        const Datum& src = pred->u[r] ? *th : *el;
+        switch (StoreOf(th->ty)) {
+            case S_I: out->i[r] = src.I(r); break;
+            case S_U: out->u[r] = src.U(r); break;
+            default: out->f[r] = src.F(r); break;
+        }
+        if (nulls) out->ok[r] = src.Valid(r);
+    }
+    return out;
+}
+
 static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
     if (a.op == OP_CONST) return a.constant;
     std::vector<DatumPtr> args;
@@ -1341,6 +1365,9 @@ static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
             return CastTo(args[0], a.castTo, false);
         }
         case OP_YQL:
+            // the only kernel of three arguments is If, sent with a KernelIdx alone
+            // (ydb/core/kqp/query_compiler/kqp_olap_compiler.cpp:740-759)
+            if (!a.yqlHasOp && args.size() == 3) return YqlIf(args[0], args[1], args[2]);
             if (!a.yqlHasOp) throw Error("Unsupported: YQL kernel without YqlOperationId");
             if (args.size() != 2) throw Error("Unsupported: YQL kernel arity");
             return YqlKernel(a.yqlOp, args[0], args[1]);

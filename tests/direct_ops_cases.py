@@ -211,3 +211,34 @@ def check_checked_arithmetic(run, run_fails):
             assert out["res"].to_pylist() == f(a, b).tolist(), (op, t)
         assert "divide by zero" in run_fails([(1, "x"), (2, "y")], binary_program(OP.DivideNotNull),
                                              {"x": _array(t, [1.0]), "y": _array(t, [0.0])})
+
+
+def if_program(pred=1, then=2, otherwise=3):
+    """The ternary YQL kernel as KQP sends it: function type YQL_KERNEL, a KernelIdx and three arguments, nothing else
+    (ydb/core/kqp/query_compiler/kqp_olap_compiler.cpp:740-759)."""
+    return Program(version=5).assign_yql(Column(name="res"), None, [pred, then, otherwise], kernel_idx=7).project(["res"])
+
+
+def check_block_if(run, run_fails):
+    res = [(1, "p"), (2, "a"), (3, "b")]
+    p = np.array([1, 0, 1, 0, 0], dtype=np.uint8)
+    a = Col(np.array([10, 11, 12, 13, 14], dtype=np.int32), valid=np.array([True, True, False, True, True]))
+    b = Col(np.array([20, 21, 22, 23, 24], dtype=np.int32), valid=np.array([True, False, True, True, True]))
+    out = run(res, if_program(), {"p": p, "a": a, "b": b})
+    assert out["res"].type == "int32" and out["res"].to_pylist() == [10, None, None, 23, 24]
+    # scalar branches broadcast
+    prog = (Program(version=5).assign_const(Column(name="c1"), "Double", 1.5).assign_const(Column(name="c2"), "Double", -2.5)
+            .assign_yql(Column(name="res"), None, [1, "c1", "c2"], kernel_idx=0).project(["res"]))
+    out = run(res, prog, {"p": p, "a": a, "b": b})
+    assert out["res"].to_pylist() == [1.5, -2.5, 1.5, -2.5, -2.5]
+    # computed predicate and branches
+    prog = (Program(version=5).assign_const(100, "Int32", 12).assign_yql(101, 13, [2, 100])      # a < 12
+            .assign_yql(102, 3, [2, 3]).assign_yql(103, 4, [3, 2])                                   # a + b, b - a
+            .assign_const(104, "Uint8", 0).assign_yql(105, 17, [101, 104])                          # coalesce(pred, false)
+            .assign_yql(Column(name="res"), None, [105, 102, 103], kernel_idx=1).project(["res"]))
+    out = run(res, prog, {"p": p, "a": a, "b": b})
+    assert out["res"].to_pylist() == [30, None, None, 10, 10]
+    assert "Different return types" in run_fails(res, if_program(1, 2, 1), {"p": p, "a": a, "b": b})
+    assert "Expected bool" in run_fails(res, if_program(2, 2, 3), {"p": p, "a": a, "b": b})
+    nullable_pred = Col(p, valid=np.array([True, True, False, True, True]))
+    assert "Expected bool" in run_fails(res, if_program(), {"p": nullable_pred, "a": a, "b": b})

@@ -208,3 +208,25 @@ def test_checked_arithmetic_against_oracle(t):
     p.project(outs)
     got, exp = both([(1, "x"), (2, "y")], p, {"x": x, "y": y})
     compare_batches(got, exp)
+
+
+def test_block_if():
+    dc.check_block_if(gpu_run, gpu_fails)
+
+
+@pytest.mark.parametrize("t", ["int8", "uint16", "int64", "float32", "float64"])
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_block_if_against_oracle(t, jit, monkeypatch):
+    monkeypatch.setenv("SSA_JIT", jit)
+    rng = np.random.default_rng(51)
+    n = 70_001
+    batch = {"p": (rng.random(n) < 0.4).astype(np.uint8), "a": dc.random_column(rng, t, n, nulls=0.1),
+             "b": dc.random_column(rng, t, n, nulls=0.2), "k": rng.integers(0, 9, n).astype(np.int16)}
+    res = [(1, "p"), (2, "a"), (3, "b"), (4, "k")]
+    got, exp = both(res, dc.if_program(), batch)
+    compare_batches(got, exp)
+    # feeding a filter and an aggregate: COUNT / MIN / MAX of the selected side per key, rows where it is null dropped by COUNT
+    prog = (Program(version=5).assign_yql(100, None, [1, 2, 3], kernel_idx=0)
+            .group_by([Aggregate(110, AGG.COUNT, [100]), Aggregate(111, AGG.MIN, [100]), Aggregate(112, AGG.MAX, [100])], keys=[4]))
+    got, exp = both(res, prog, batch)
+    compare_batches(got, exp, key_names=["k"])

@@ -119,3 +119,7 @@ def test_oracle_math_functions_against_python_libm():
 
 def test_oracle_checked_arithmetic_against_python_integers():
     dc.check_checked_arithmetic(oracle_run, oracle_fails)
+
+
+def test_oracle_block_if():
+    dc.check_block_if(oracle_run, oracle_fails)

@@ -59,7 +59,7 @@ struct Expr;
 using ExprPtr = std::shared_ptr<Expr>;
 
 struct Expr {
-    enum EKind { COL, CONST, ALIAS, UNARY, BINARY, STROP } Kind = COL;
+    enum EKind { COL, CONST, ALIAS, UNARY, BINARY, STROP, SELECT } Kind = COL;
     int32_t Type = T_NONE;
     bool Nullable = false;
     int ColSlot = -1;     // COL: VM column slot
@@ -67,6 +67,7 @@ struct Expr {
     TScalar Scalar;       // CONST
     int Op = 0, A = 0, B = 0;
     ExprPtr L, R;
+    ExprPtr C;  // SELECT: L = predicate, R = then, C = else
     // codegen state
     int Uses = 0;
     int Reg = -1;
@@ -651,8 +652,33 @@ struct Compiler {
     }
 
     // ---- YQL_KERNEL functions (block kernels selected by YqlOperationId) ----------------------
+    // BlockIf (ydb/library/yql/minikql/comp_nodes/mkql_block_if.cpp:120-250): a Bool predicate that is not optional,
+    // branches of one type; each row takes the value and the nullness of the branch its predicate byte selects.
+    Status YqlIf(ExprPtr pred, ExprPtr th, ExprPtr el, ExprPtr& out) {
+        if (!(pred->Type == T_U8 || pred->Type == T_BOOL) || pred->Nullable) return Status::Invalid("Expected bool as first argument");
+        if (th->Type != el->Type) return Status::Invalid("Different return types in branches.");
+        if (IsStringLike(th->Type) || th->Type == T_DEC128) return Status::Unsupported("If over string or decimal branches");
+        if (pred->Kind == Expr::CONST) {  // TBlockIfScalarWrapper: the chosen branch as it is
+            out = pred->Scalar.Bits ? th : el;
+            return Status::OK();
+        }
+        auto e = std::make_shared<Expr>();
+        e->Kind = Expr::SELECT;
+        e->L = pred;
+        e->R = th;
+        e->C = el;
+        e->Type = th->Type;
+        e->Nullable = th->Nullable || el->Nullable;
+        out = e;
+        return Status::OK();
+    }
+
     Status YqlFunction(const TAssign& a, std::vector<ExprPtr>& args, ExprPtr& out) {
         if (!a.YqlOperationId) return Status::Unsupported("YQL kernel without YqlOperationId");
+        if (EYqlOp(*a.YqlOperationId) == EYqlOp::If) {
+            if (args.size() != 3) return Status::Invalid("Expected 3 args");
+            return YqlIf(args[0], args[1], args[2], out);
+        }
         if (args.size() != 2) return Status::Unsupported("YQL kernel arity");
         ExprPtr l = args[0], r = args[1];
         const int t0 = l->Type, t1 = r->Type;
@@ -800,6 +826,11 @@ struct Compiler {
             CountUses(e->L.get());
             CountUses(e->R.get());
         }
+        if (e->Kind == Expr::SELECT) {
+            CountUses(e->L.get());
+            CountUses(e->R.get());
+            CountUses(e->C.get());
+        }
     }
 
     // Operand that an instruction can take directly as its B source.
@@ -878,6 +909,29 @@ struct Compiler {
                     Gen(l, st);
                     Emit(MakeInsn(e->Op, SRC_REG, t, e->A, e->B), st);
                 }
+                break;
+            }
+            case Expr::SELECT: {
+                // else into a register, then as the instruction's operand, the predicate in the accumulator
+                Expr* c = Strip(e->C.get());
+                Gen(c, st);
+                int t = c->Reg;
+                if (!(c->Done && t >= 0)) {
+                    t = AllocTemp(st);
+                    Emit(MakeInsn(OP_ST, 0, t), st);
+                }
+                Expr* th = Strip(e->R.get());
+                if (!DirectSource(th, sk, si, st)) {
+                    Gen(th, st);
+                    sk = SRC_REG;
+                    si = th->Reg;
+                    if (!(th->Done && si >= 0)) {
+                        si = AllocTemp(st);
+                        Emit(MakeInsn(OP_ST, 0, si), st);
+                    }
+                }
+                Gen(Strip(e->L.get()), st);
+                Emit(MakeInsn(OP_SELECT, sk, si, t, 0), st);
                 break;
             }
             case Expr::STROP: {

@@ -451,6 +451,8 @@ private:
             res.KernelIdx = kernelIdx;
             if (yqlOp) {
                 res.YqlOperationId = yqlOp;
+            } else if (res.Arguments.size() == 3) {
+                res.YqlOperationId = uint32_t(EYqlOp::If);
             } else {
                 switch (id) {
                     case 33: res.YqlOperationId = uint32_t(EYqlOp::StartsWith); break;

@@ -48,6 +48,9 @@ enum class EAggregate { Unspecified = 0, Some = 1, Count = 2, Min = 3, Max = 4, 
 enum class EYqlOp : uint32_t {
     And = 0, Or, Xor, Add, Sub, Mul, Div, Mod, StartsWith, EndsWith, StringContains,
     Equals, NotEquals, Less, LessOrEqual, Greater, GreaterOrEqual, Coalesce,
+    // Not an EBinaryOp: TKernelRequestBuilder::AddIf (request.h:49) is the only kernel of three arguments and is sent
+    // with a KernelIdx alone (ydb/core/kqp/query_compiler/kqp_olap_compiler.cpp:740-759); recognised by its arity.
+    If = 0x10000,
 };
 
 const char* GetFunctionName(EOperation op);          // program.cpp:163-301

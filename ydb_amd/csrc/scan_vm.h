@@ -989,6 +989,19 @@ struct Machine {
             }
             break;
         }
+        case OP_SELECT: {
+            Val<U> C;
+            FetchReg(fa, C);
+            uint32_t ok = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool p = A.v[u] != 0;
+                A.v[u] = p ? B.v[u] : C.v[u];
+                ok |= (((p ? B.ok : C.ok) >> u) & 1u) << u;
+            }
+            A.ok = ok;
+            break;
+        }
         case OP_CMP: {
             uint32_t lt, eq, un;
             CompareMasks<U>(fa, A.v, B.v, lt, eq, un);

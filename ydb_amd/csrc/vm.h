@@ -159,6 +159,7 @@ enum OpCode : int32_t {
     OP_DECPART,   // A = part a of decimal128 column si: 0 = bits 0..31, 1 = bits 32..63, 2 = bits 64..127 (validity of the column)
     OP_FUNC,      // A = f(A, B)          a = TypeId of the operands, b = FuncId; unary functions ignore B
     OP_RFUNC,     // A = f(B, A)
+    OP_SELECT,    // A = (A != 0) ? B : R[a]   value and validity of the chosen side (YQL BlockIf)
 };
 
 // Functions of OP_FUNC: the custom-registry kernels of ydb/library/arrow_kernels/func_{gcd,lcm,modulo,modulo_or_zero,
