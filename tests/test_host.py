@@ -145,3 +145,42 @@ def test_product_refuses_to_run_without_a_gpu():
     li = tpch.lineitem_host(0, 16)
     with pytest.raises(SsaError):
         pc.ApplyProgram({c: li[c] for c in tpch.Q6_COLUMNS})
+
+
+def test_mutated_program_bytes_never_crash_the_parsers():
+    """Truncated, bit-flipped and spliced serialized programs: the product's parser answers ok / not ok, the oracle's
+    parses or raises -- neither reads out of bounds or aborts (a crash would take the test process down)."""
+    import random
+    from oracle import ssa_oracle
+    from ydb_amd import clickbench, tpch
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import olap_program
+    rnd = random.Random(1234)
+    seeds = [olap_program(p) for p in clickbench.programs().values()]
+    seeds += [olap_program(tpch.q1_program()), olap_program(tpch.q6_program())]
+    resolver = clickbench.HITS_RESOLVER + [(100 + i, n) for i, n in enumerate(["l_quantity", "l_shipdate", "l_discount"])]
+    tried = 0
+    for data in seeds:
+        for _ in range(150):
+            b = bytearray(data)
+            kind = rnd.randrange(4)
+            if kind == 0 and len(b) > 1:
+                del b[rnd.randrange(1, len(b)):]
+            elif kind == 1:
+                for _ in range(rnd.randrange(1, 4)):
+                    b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+            elif kind == 2:
+                at = rnd.randrange(len(b))
+                b[at:at] = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9)))
+            else:
+                at, n = rnd.randrange(len(b)), rnd.randrange(1, 6)
+                b[at:at + n] = bytes([0xFF] * n)   # long varints / huge lengths
+            for flags in (True, False):
+                ok, err = ProgramContainer().Init(resolver, bytes(b), olap_wrapper=flags)
+                assert ok or err
+                try:
+                    ssa_oracle.Oracle(resolver, bytes(b), olap_wrapper=flags)
+                except ssa_oracle.OracleError:
+                    pass
+                tried += 1
+    assert tried >= 2000
