@@ -207,3 +207,22 @@ def test_built_kernel_is_the_specialised_one(monkeypatch):
         ms, launches, _ = pc.ReadProfile()
         times[mode] = ms / launches
     assert times["1"] * 1.5 < times["0"], times
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_a_multiply_and_an_add_are_rounded_separately(jit, monkeypatch):
+    """Two instructions of a step program stay two roundings in a kernel built for it: a * b + c equals the oracle's
+    bit for bit (a fused multiply-add differs in the last bit on about a quarter of random rows)."""
+    from ydb_amd.ssa_pb import F, Program
+    monkeypatch.setenv("SSA_JIT", jit)
+    rng = np.random.default_rng(1)
+    n = 200_000
+    batch = {"a": rng.normal(0, 1, n), "b": rng.normal(0, 1, n), "c": rng.normal(0, 1, n),
+             "f": rng.normal(0, 1, n).astype(np.float32), "g": rng.normal(0, 1, n).astype(np.float32)}
+    res = [(1, "a"), (2, "b"), (3, "c"), (4, "f"), (5, "g")]
+    p = (Program(version=5).assign_func(100, F.MATH_MULTIPLY, [1, 2]).assign_func(101, F.MATH_ADD, [100, 3])
+         .assign_func(102, F.MATH_SUBTRACT, [3, 100]).assign_yql(103, 5, [2, 3]).assign_yql(104, 4, [103, 1])
+         .assign_func(105, F.MATH_MULTIPLY, [4, 5]).assign_func(106, F.MATH_ADD, [105, 4])
+         .project([101, 102, 104, 106]))
+    got, exp = P.both(res, p, batch)
+    compare_batches(got, exp)

@@ -183,8 +183,12 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
             // The step program's loops are unrolled by pragma with the whole interpreter inlined in their bodies: the
             // default size limit of pragma-forced unrolling (16 K instructions before folding) is too small for that
             // and, once exceeded, silently leaves the generic interpreter in the built kernel.
-            const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm", "-mllvm",
-                                  "-pragma-unroll-threshold=1048576"};
+            // No contraction of a multiply and a following add into one fused operation: in the straight-line code of a
+            // built kernel two instructions of the step program sit next to each other, and the reference rounds after
+            // each of them (a * b + c differed in the last bit on a quarter of the rows).  Where a fused operation is
+            // wanted (the register-held groups) the source asks for it by name.
+            const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm", "-ffp-contract=off",
+                                  "-mllvm", "-pragma-unroll-threshold=1048576"};
             const hiprtcResult rc = st.R.CompileProgram(prog, int(sizeof(opts) / sizeof(opts[0])), opts);
             if (rc != HIPRTC_SUCCESS) {
                 size_t n = 0;
