@@ -230,3 +230,12 @@ def test_block_if_against_oracle(t, jit, monkeypatch):
             .group_by([Aggregate(110, AGG.COUNT, [100]), Aggregate(111, AGG.MIN, [100]), Aggregate(112, AGG.MAX, [100])], keys=[4]))
     got, exp = both(res, prog, batch)
     compare_batches(got, exp, key_names=["k"])
+
+
+def test_only_the_math_library_needs_a_built_kernel(monkeypatch):
+    """Checked arithmetic, the rounding family and If run on the generic kernels too."""
+    monkeypatch.setenv("SSA_JIT", "0")
+    x = np.array([1, 2, 3], dtype=np.int32)
+    for op in dc.CHECKED:
+        out = gpu_run([(1, "x"), (2, "y")], dc.binary_program(op), {"x": x, "y": x})
+        assert len(out["res"].to_pylist()) == 3

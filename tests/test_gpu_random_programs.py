@@ -1,0 +1,148 @@
+"""Randomly generated step programs, GPU (generic kernels and kernels built for the program) against the CPU oracle:
+every projected column bit-exact, or both sides refuse the program with an error."""
+import numpy as np
+import pytest
+
+from cases import compare_batches
+from ydb_amd.arrow_c import Col
+from ydb_amd.ssa_pb import OP, F, Program
+
+pytestmark = pytest.mark.gpu
+
+RES = [(1, "i32"), (2, "i64"), (3, "f64"), (4, "u8"), (5, "nz"), (6, "i32n"), (7, "f64n"), (8, "flag"), (9, "f32")]
+
+
+def make_batch(rng, n):
+    return {
+        "i32": rng.integers(-1000, 1000, n).astype(np.int32),
+        "i64": rng.integers(-10**9, 10**9, n).astype(np.int64),
+        "f64": rng.normal(0, 100, n),
+        "u8": rng.integers(0, 200, n).astype(np.uint8),
+        "nz": rng.integers(1, 50, n).astype(np.int32),
+        "i32n": Col(rng.integers(-50, 50, n).astype(np.int32), valid=rng.random(n) > 0.15),
+        "f64n": Col(rng.normal(0, 10, n), valid=rng.random(n) > 0.15),
+        "flag": (rng.random(n) < 0.5).astype(np.uint8),
+        "f32": rng.normal(0, 10, n).astype(np.float32),
+    }
+
+
+def random_program(rng, nassign):
+    """Values are tracked as (column, kind, exact type or None, may be null): kind in num / abool (Arrow boolean) /
+    ybool (YQL Bool, a uint8)."""
+    vals = [(1, "num", "int32", False), (2, "num", "int64", False), (3, "num", "double", False), (4, "num", "uint8", False),
+            (5, "num", "int32", False), (6, "num", "int32", True), (7, "num", "double", True), (8, "ybool", "uint8", False),
+            (9, "num", "float", False)]
+    p = Program(version=5)
+    nxt = 100
+    outs = []
+
+    def pick(kind):
+        c = [v for v in vals if v[1] == kind]
+        return c[rng.integers(len(c))] if c else None
+
+    for _ in range(nassign):
+        choice = rng.integers(12)
+        a, b = pick("num"), pick("num")
+        new = None
+        if choice == 0:      # Arrow arithmetic
+            p.assign_func(nxt, int(rng.choice([F.MATH_ADD, F.MATH_SUBTRACT, F.MATH_MULTIPLY])), [a[0], b[0]])
+            new = (nxt, "num", a[2] if a[2] == b[2] else None, a[3] or b[3])
+        elif choice == 1:    # Arrow compare
+            p.assign_func(nxt, int(rng.integers(1, 7)), [a[0], b[0]])
+            new = (nxt, "abool", "bool", a[3] or b[3])
+        elif choice == 2:    # Arrow logic
+            x, y = pick("abool"), pick("abool")
+            if x is None:
+                continue
+            p.assign_func(nxt, int(rng.choice([11, 12, 13])), [x[0], y[0]])
+            new = (nxt, "abool", "bool", x[3] or y[3])
+        elif choice == 3:    # YQL arithmetic (Div and Mod yield NULL on a zero divisor)
+            p.assign_yql(nxt, int(rng.integers(3, 8)), [a[0], b[0]])
+            new = (nxt, "num", None, True)
+        elif choice == 4:    # YQL compare
+            p.assign_yql(nxt, int(rng.integers(11, 17)), [a[0], b[0]])
+            new = (nxt, "ybool", "uint8", a[3] or b[3])
+        elif choice == 5:    # YQL logic (Kleene)
+            x, y = pick("ybool"), pick("ybool")
+            p.assign_yql(nxt, int(rng.integers(0, 3)), [x[0], y[0]])
+            new = (nxt, "ybool", "uint8", x[3] or y[3])
+        elif choice == 6:    # same-type unary
+            p.assign_op(nxt, int(rng.choice([OP.Abs, OP.Negate, OP.Round, OP.RoundBankers, OP.RoundToExp2])), [a[0]])
+            new = (nxt, "num", a[2], a[3])
+        elif choice == 7:    # double-valued unary
+            p.assign_op(nxt, int(rng.choice([OP.Sqrt, OP.Floor, OP.Ceil, OP.Trunc])), [a[0]])
+            new = (nxt, "num", None, a[3])
+        elif choice == 8:    # custom integer kernels
+            p.assign_op(nxt, int(rng.choice([OP.Gcd, OP.Lcm, OP.ModuloOrZero, OP.Modulo, OP.AddNotNull, OP.MultiplyNotNull])), [a[0], b[0]])
+            new = (nxt, "num", None, a[3] or b[3])
+        elif choice == 9:    # is_valid / is_null
+            if rng.integers(2):
+                p.assign_op(nxt, OP.IsValid, [a[0]])
+            else:
+                p.assign_func(nxt, F.IS_NULL, [a[0]])
+            new = (nxt, "abool", "bool", False)
+        elif choice == 10:   # If: predicate that cannot be null, branches of one known type
+            preds = [v for v in vals if v[1] == "ybool" and not v[3]]
+            pr = preds[rng.integers(len(preds))]
+            same = [v for v in vals if v[1] == "num" and v[2] is not None and v[2] == a[2]]
+            if a[2] is None or not same:
+                continue
+            e = same[rng.integers(len(same))]
+            p.assign_yql(nxt, None, [pr[0], a[0], e[0]], kernel_idx=int(rng.integers(4)))
+            new = (nxt, "num", a[2], a[3] or e[3])
+        else:                # cast
+            to = int(rng.choice([F.CAST_TO_INT8, F.CAST_TO_INT32, F.CAST_TO_INT64, F.CAST_TO_UINT16, F.CAST_TO_FLOAT, F.CAST_TO_DOUBLE]))
+            p.assign_func(nxt, to, [a[0]])
+            new = (nxt, "num", None, a[3])
+        vals.append(new)
+        outs.append(nxt)
+        nxt += 1
+    if not outs:
+        return None
+    keep = sorted(set(int(x) for x in rng.choice(outs, size=min(len(outs), 6), replace=False)))
+    return p.project(keep)
+
+
+def run_both(program, batch, monkeypatch, jit):
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer, SsaError
+    monkeypatch.setenv("SSA_JIT", jit)
+    pc = ProgramContainer()
+    ok, err = pc.Init(RES, program)
+    got = gerr = exp = oerr = None
+    if ok:
+        try:
+            got = pc.ApplyProgram(batch)
+        except SsaError as e:
+            gerr = str(e)
+    else:
+        gerr = err
+    try:
+        exp = ssa_oracle.Oracle(RES, program).apply(batch)
+    except ssa_oracle.OracleError as e:
+        oerr = str(e)
+    return got, gerr, exp, oerr
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_programs(seed, monkeypatch):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 63, 1025, 20_011]))
+    batch = make_batch(rng, n)
+    program = random_program(rng, int(rng.integers(2, 9)))
+    if program is None:
+        pytest.skip("empty program")
+    for jit in ("0", "1"):
+        got, gerr, exp, oerr = run_both(program, batch, monkeypatch, jit)
+        if oerr is not None:
+            assert gerr is not None, (jit, oerr)
+            if "unsupported" in gerr.lower():   # a program the GPU path declines (e.g. too many registers): not a wrong answer
+                continue
+            for word in ("divide by zero", "overflow", "not in range", "no kernel"):
+                if word in oerr:
+                    assert word in gerr, (jit, gerr, oerr)
+            continue
+        if gerr is not None and "unsupported" in gerr.lower():
+            continue
+        assert gerr is None, (jit, gerr)
+        compare_batches(got, exp)

@@ -808,7 +808,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
 static bool NeedsBuiltKernel(const ScanArgs& args) {
     for (int i = 0; i < args.ncode; ++i) {
         const uint32_t w = args.code[i * 3 + 2];
-        if ((InsnOp(w) == OP_FUNC || InsnOp(w) == OP_RFUNC) && InsnB(w) >= FN_ACOSH) return true;
+        if ((InsnOp(w) == OP_FUNC || InsnOp(w) == OP_RFUNC) && InsnB(w) >= FN_ACOSH && InsnB(w) <= FN_HYPOT) return true;
     }
     return false;
 }
