@@ -26,7 +26,7 @@ def make_batch(rng, n):
     }
 
 
-def random_program(rng, nassign):
+def random_program(rng, nassign, finish=None):
     """Values are tracked as (column, kind, exact type or None, may be null): kind in num / abool (Arrow boolean) /
     ybool (YQL Bool, a uint8)."""
     vals = [(1, "num", "int32", False), (2, "num", "int64", False), (3, "num", "double", False), (4, "num", "uint8", False),
@@ -97,6 +97,8 @@ def random_program(rng, nassign):
         vals.append(new)
         outs.append(nxt)
         nxt += 1
+    if finish is not None:
+        return finish(p, vals)
     if not outs:
         return None
     keep = sorted(set(int(x) for x in rng.choice(outs, size=min(len(outs), 6), replace=False)))
@@ -146,3 +148,64 @@ def test_random_programs(seed, monkeypatch):
             continue
         assert gerr is None, (jit, gerr)
         compare_batches(got, exp)
+
+
+NAMES = dict(RES)
+
+
+def random_group_by(rng, nassign):
+    """Random assigns, then maybe a filter, then a group-by: 0-2 keys, 1-4 aggregates over columns or computed values.
+    Returns (program, key names, names of floating SUMs)."""
+    from ydb_amd.ssa_pb import AGG, Aggregate
+    info = {}
+
+    def finish(p, vals):
+        def name(v):
+            return NAMES.get(v[0], str(v[0]))
+        preds = [v for v in vals if v[1] in ("ybool", "abool")]
+        if preds and rng.random() < 0.6:
+            p.filter(preds[rng.integers(len(preds))][0])
+        nums = [v for v in vals if v[1] == "num"]
+        keyable = [v for v in vals if v[0] in (4, 5, 6, 8) or (v[0] >= 100 and v[1] != "num")]
+        keys = []
+        for _ in range(int(rng.integers(0, 3))):
+            k = keyable[rng.integers(len(keyable))]
+            if k not in keys:
+                keys.append(k)
+        aggs, fsums = [], []
+        for j in range(int(rng.integers(1, 5))):
+            kind = int(rng.choice([AGG.SUM, AGG.MIN, AGG.MAX, AGG.COUNT, AGG.COUNT, AGG.SOME]))
+            if kind == AGG.COUNT and rng.random() < 0.4:
+                aggs.append(Aggregate(200 + j, AGG.COUNT, []))
+                continue
+            a = nums[rng.integers(len(nums))]
+            aggs.append(Aggregate(200 + j, kind, [a[0]]))
+            if kind == AGG.SUM:
+                fsums.append(str(200 + j))   # float or not is only known after typing: tolerance is harmless for integers
+        p.group_by(aggs, keys=[k[0] for k in keys])
+        info["keys"] = [name(k) for k in keys]
+        info["fsums"] = fsums
+        return p
+
+    p = random_program(rng, nassign, finish)
+    return p, info["keys"], info["fsums"]
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_group_bys(seed, monkeypatch):
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1, 64, 1025, 4097, 50_021]))
+    batch = make_batch(rng, n)
+    program, keys, fsums = random_group_by(rng, int(rng.integers(0, 6)))
+    for jit in ("0", "1"):
+        got, gerr, exp, oerr = run_both(program, batch, monkeypatch, jit)
+        if oerr is not None:
+            assert gerr is not None, (jit, oerr)
+            continue
+        if gerr is not None and "unsupported" in gerr.lower():
+            continue
+        assert gerr is None, (jit, gerr)
+        if not keys:
+            compare_batches(got, exp, float_sum_names=fsums)
+        else:
+            compare_batches(got, exp, key_names=keys, float_sum_names=fsums)

@@ -1696,7 +1696,8 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
             aggCols[size_t(k)].Field.Scale = ap.Scale;
         }
         if (ap.SomeInputColumn >= 0) {
-            SSA_RETURN_NOT_OK(GatherRows(in.Cols[size_t(ap.SomeInputColumn)], aggRowIdx[size_t(k)], ngroups, true, aggCols[size_t(k)]));
+            // (on the single-byte-key path argument nulls are not looked at: the first row's value, never null)
+            SSA_RETURN_NOT_OK(GatherRows(in.Cols[size_t(ap.SomeInputColumn)], aggRowIdx[size_t(k)], ngroups, ap.ArgNullable, aggCols[size_t(k)]));
         } else if (aggValid[size_t(k)]) {
             SSA_RETURN_NOT_OK(PackValidity(aggValid[size_t(k)], ngroups, aggCols[size_t(k)]));
         }

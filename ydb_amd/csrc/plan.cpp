@@ -870,6 +870,21 @@ struct Compiler {
         }
     }
 
+    // Can evaluating `e` end the program with an error (a failing implicit cast, an Arrow division by zero, a custom
+    // kernel's error)?
+    static bool MayFail(Expr* e) {
+        e = Strip(e);
+        if (e->IsLeaf() || e->Kind == Expr::STROP) return false;
+        if (e->Kind == Expr::UNARY && e->Op == OP_CHECK) return true;
+        if (e->Kind == Expr::BINARY && (e->Op == OP_DIV || e->Op == OP_MOD) && (e->B & 1) == DIALECT_ARROW && (e->A == CLS_I || e->A == CLS_U)) return true;
+        if ((e->Kind == Expr::BINARY || e->Kind == Expr::UNARY) && e->Op == OP_FUNC &&
+            (e->B == FN_LCM || e->B == FN_MOD || IsNotNullFunc(e->B))) return true;
+        if (e->L && MayFail(e->L.get())) return true;
+        if (e->R && MayFail(e->R.get())) return true;
+        if (e->C && MayFail(e->C.get())) return true;
+        return false;
+    }
+
     // Leaves the value of `e` in the accumulator.
     void Gen(Expr* e, Status& st) {
         if (!st.ok()) return;
@@ -1307,6 +1322,17 @@ struct Compiler {
             for (auto& f : filters) CountUses(f.get());
         }
         for (auto& ro : regOuts) CountUses(ro.E.get());
+        // The reference evaluates every Assign, used or not (TProgramStep::ApplyAssignes, program.cpp:869-878), so an
+        // assign nothing reads can still fail the program: those that can are evaluated for their errors, in the one
+        // pass of the step that sees every row.
+        std::vector<Expr*> unread;
+        if (mode != CM_OUTPUTS_ONLY || filters.empty()) {
+            for (auto& kv : Env) {
+                Expr* s = Strip(kv.second.get());
+                if (!s->IsLeaf() && s->Uses == 0 && MayFail(s)) unread.push_back(s);
+            }
+            for (Expr* s : unread) CountUses(s);
+        }
         // code: filters first, then outputs
         if (mode != CM_OUTPUTS_ONLY) {
             for (auto& f : filters) {
@@ -1318,6 +1344,9 @@ struct Compiler {
         for (auto& ro : regOuts) {
             if (ro.E->Nullable) Plan.Nullable = true;
             GenToReg(ro.E.get(), ro.Reg, st);
+        }
+        for (Expr* s : unread) {
+            if (!s->Done) Gen(s, st);
         }
         if (!st.ok()) return st;
         Plan.Code.push_back(MakeInsn(OP_END));
