@@ -18,7 +18,10 @@ namespace ssa {
 #define SSA_HIP(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return Status::Hip(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+        if (e_ != hipSuccess) {   \
+            (void)hipGetLastError(); /* the runtime keeps the error for the next caller otherwise */   \
+            return Status::Hip(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+        }   \
     } while (0)
 
 #define SSA_RETURN_NOT_OK(expr)     \
@@ -1203,6 +1206,14 @@ Status Executor::RunProject(const TProgramStep& step, const StepPlan& plan, cons
     std::vector<int> regOuts;
     for (size_t i = 0; i < plan.Outs.size(); ++i) {
         if (plan.Outs[i].Source == OutColumn::FROM_REG) regOuts.push_back(int(i));
+    }
+    if (regOuts.empty() && !plan.HasFilter && plan.UnreadFallible) {
+        // nothing to filter or compute, yet an assign that nothing reads may fail the program: one pass for its errors
+        StepPlan errorsPlan;
+        BufferPtr allBits, allOffsets;
+        int64_t all = rows;
+        SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_FILTER_ONLY, errorsPlan));
+        SSA_RETURN_NOT_OK(RunFilterBitmap(errorsPlan, in, allBits, allOffsets, all));
     }
     if (!regOuts.empty()) {
         if (regOuts.size() > size_t(kMaxOuts)) return Status::Unsupported("too many computed output columns");

@@ -15,7 +15,10 @@ namespace ssa {
 #define SSA_HIP(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return Status::Hip(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) { \
+            (void)hipGetLastError(); /* the runtime keeps the error for the next caller otherwise */   \
+            return Status::Hip(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+        } \
     } while (0)
 #define SSA_RETURN_NOT_OK(expr) \
     do {                        \

@@ -1155,7 +1155,10 @@ struct Compiler {
                 if (ap.Spec.kind == AGG_SOME) {
                     // first non-null in row order == the value at the smallest row index whose argument is
                     // valid: aggregate MIN(row index) here, the executor gathers the value afterwards.
-                    if (ap.ArgInputColumn < 0) return Status::Unsupported("some() over a computed expression");
+                    if (ap.ArgInputColumn < 0 || Input[size_t(ap.ArgInputColumn)].Type != at) {
+                        // (a widening cast of a column is still that column to the VM, but not to the gather)
+                        return Status::Unsupported("some() over a computed expression");
+                    }
                     auto rowIdx = std::make_shared<Expr>();
                     rowIdx->Kind = Expr::UNARY;
                     rowIdx->Op = OP_ROWIDX;
@@ -1332,6 +1335,7 @@ struct Compiler {
                 if (!s->IsLeaf() && s->Uses == 0 && MayFail(s)) unread.push_back(s);
             }
             for (Expr* s : unread) CountUses(s);
+            Plan.UnreadFallible = !unread.empty();
         }
         // code: filters first, then outputs
         if (mode != CM_OUTPUTS_ONLY) {

@@ -82,6 +82,7 @@ struct StepPlan {
     std::vector<int> SourceColumns;   // VM column slot -> index into the step's input batch
     bool Nullable = false;
     bool HasFilter = false;
+    bool UnreadFallible = false;  // assigns that nothing reads but that can fail: evaluated for their errors
     int NumRegsUsed = 0;
     // sink description
     std::vector<OutColumn> Outs;      // output batch columns in order
