@@ -221,7 +221,7 @@ def random_group_by(rng, nassign):
     return p, info["keys"], info["fsums"]
 
 
-@pytest.mark.parametrize("seed", range(150))
+@pytest.mark.parametrize("seed", range(100))
 def test_random_group_bys(seed, monkeypatch):
     rng = np.random.default_rng(5000 + seed)
     n = int(rng.choice([1, 64, 1025, 4097, 50_021]))
@@ -252,7 +252,7 @@ def random_filter_projection(rng, nassign):
     return random_program(rng, nassign, finish, strings=True)
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(80))
 def test_random_filter_projections(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.choice([1, 64, 1025, 4097, 30_011]))
