@@ -1,4 +1,4 @@
-# Round-1 "c" profiles: kernel traces of the three workloads at SF100 and FETCH_SIZE passes at 128 M rows.
+# Profile set "r1_c": kernel traces of the three workloads at SF100 and FETCH_SIZE passes at 128 M rows.
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

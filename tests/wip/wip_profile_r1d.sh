@@ -1,4 +1,4 @@
-# Round-1 "d" profiles: kernel traces of the TPC-H workloads at SF100, FETCH_SIZE passes at 128 M rows, ClickBench
+# Profile set "r1_d": kernel traces of the TPC-H workloads at SF100, FETCH_SIZE passes at 128 M rows, ClickBench
 # scan-aggregates at 1 G rows (10 x hits) and group-bys at the hits size, the filter algebra kernels.
 set -e
 cd /tmp && export TMPDIR=/tmp

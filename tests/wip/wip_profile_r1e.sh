@@ -1,4 +1,4 @@
-# Round-1 "e" profiles: the final library of the round.  Kernel traces of the TPC-H workloads at SF100, the ClickBench
+# Profile set "r1_e": kernel traces of the TPC-H workloads at SF100, the ClickBench
 # group-bys whose kernels changed after the "d" set, the direct-operation tests' kernels.
 set -e
 cd /tmp && export TMPDIR=/tmp
