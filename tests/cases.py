@@ -286,7 +286,8 @@ def compare_batches(got, exp, key_names: Sequence[str] = (), float_sum_names: Se
             if a is None or b is None:
                 assert a is None and b is None, (name, rg, a, b)
             elif name in float_sum_names:
-                assert abs(a - b) <= rtol * max(abs(a), abs(b)) or a == b, (name, a, b)
+                both_nan = isinstance(a, float) and isinstance(b, float) and math.isnan(a) and math.isnan(b)
+                assert both_nan or abs(a - b) <= rtol * max(abs(a), abs(b)) or a == b, (name, a, b)
             elif isinstance(b, float) and math.isnan(b):
                 assert isinstance(a, float) and math.isnan(a), (name, a, b)
             else:

@@ -477,3 +477,21 @@ def test_substring_search_over_whole_tiles(n):
     got, exp = both([(1, "x")], prog, {"x": Col(values, type="string")})
     compare_batches(got, exp)
     assert int(got["108"].to_pylist()[0]) == sum("abba" in v for v in values)
+
+
+def test_folded_constant_arrays_stay_arrays():
+    """is_null of a column without nulls is known to be false for every row; whatever is computed from it alone is
+    still an array of the batch's length -- a filter takes it (and drops every row), a projection materialises it."""
+    n = 1000
+    batch = {"a": np.arange(n, dtype=np.int32), "b": np.arange(n, dtype=np.float64)}
+    res = [(1, "a"), (2, "b")]
+    p = (Program().assign_func(100, F.IS_NULL, [1]).assign_func(101, F.BINARY_AND, [100, 100]).assign_func(102, F.BINARY_NOT, [101])
+         .filter(101).project([2, 100]))
+    got, exp = both(res, p, batch)
+    compare_batches(got, exp)
+    assert len(got["b"].valid) == 0
+    p = (Program().assign_func(100, F.IS_NULL, [1]).assign_func(101, F.BINARY_AND, [100, 100]).assign_func(102, F.BINARY_NOT, [101])
+         .filter(102).project([2, 101, 102]))
+    got, exp = both(res, p, batch)
+    compare_batches(got, exp)
+    assert len(got["b"].valid) == n

@@ -168,6 +168,7 @@ struct Compiler {
                 default: return Status::Unsupported("cannot fold unary op");
             }
             out = MakeConst(NumScalar(type, v, valid));
+            if (IsArrayShaped(arg)) ArrayShapedConsts.push_back(out.get());  // a folded array stays an array
             return Status::OK();
         }
         auto e = std::make_shared<Expr>();
@@ -205,6 +206,7 @@ struct Compiler {
                 TScalar s = cur->Scalar;
                 s.Type = to;
                 out = MakeConst(s);
+                if (IsArrayShaped(cur)) ArrayShapedConsts.push_back(out.get());
                 return Status::OK();
             }
             auto e = std::make_shared<Expr>();  // payload unchanged, only the static type changes
@@ -264,6 +266,7 @@ struct Compiler {
             }
             if (wrapType) v = WrapTo(v, wrapType);
             out = MakeConst(NumScalar(type, v, valid));
+            if (IsArrayShaped(l) || IsArrayShaped(r)) ArrayShapedConsts.push_back(out.get());
             return Status::OK();
         }
         auto e = std::make_shared<Expr>();
@@ -660,6 +663,10 @@ struct Compiler {
         if (IsStringLike(th->Type) || th->Type == T_DEC128) return Status::Unsupported("If over string or decimal branches");
         if (pred->Kind == Expr::CONST) {  // TBlockIfScalarWrapper: the chosen branch as it is
             out = pred->Scalar.Bits ? th : el;
+            if (IsArrayShaped(pred) && out->Kind == Expr::CONST && !IsArrayShaped(out)) {
+                out = MakeConst(out->Scalar);
+                ArrayShapedConsts.push_back(out.get());
+            }
             return Status::OK();
         }
         auto e = std::make_shared<Expr>();
