@@ -1049,9 +1049,15 @@ template <class T> static T LcmT(T lhs, T rhs) {
     return T(m / g);
 }
 // func_modulo.h:6-30, func_modulo_or_zero.h:6-28: floats go through int64
+// static_cast<int64_t>(double) of a NaN or an out-of-range value is undefined; the reference's x86-64 build gets
+// cvttsd2si's "integer indefinite", INT64_MIN, which is pinned here
+static int64_t ToI64LikeX86(double d) {
+    if (!(d >= -9223372036854775808.0 && d < 9223372036854775808.0)) return INT64_MIN;
+    return int64_t(d);
+}
 template <class T> static T ModT(T lhs, T rhs, bool orZero) {
     if constexpr (std::is_floating_point_v<T>) {
-        const int64_t x = int64_t(lhs), y = int64_t(rhs);
+        const int64_t x = ToI64LikeX86(double(lhs)), y = ToI64LikeX86(double(rhs));
         if (y == 0) { if (orZero) return 0; throw Error("divide by zero"); }
         return T(RemT<int64_t>(x, y));
     } else {

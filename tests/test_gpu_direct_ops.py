@@ -239,3 +239,13 @@ def test_only_the_math_library_needs_a_built_kernel(monkeypatch):
     for op in dc.CHECKED:
         out = gpu_run([(1, "x"), (2, "y")], dc.binary_program(op), {"x": x, "y": x})
         assert len(out["res"].to_pylist()) == 3
+
+
+def test_modulo_of_nan_and_infinities_follows_the_x86_conversion():
+    """mod / modOrZero convert floats to int64 first; for NaN and out-of-range values that conversion is what the
+    reference's x86-64 build produces (INT64_MIN), not the GPU instruction's saturation."""
+    x = np.array([743.0, np.inf, -np.inf, np.nan, 1e30, 7.5])
+    y = np.array([np.nan, -np.inf, np.inf, 5.0, 3.0, -1e30])
+    got, exp = both([(1, "x"), (2, "y")], dc.binary_program(OP.ModuloOrZero), {"x": x, "y": y})
+    compare_batches(got, exp)
+    assert got["res"].to_pylist()[:3] == [743.0, 0.0, 0.0]

@@ -204,6 +204,13 @@ SSA_HD double MathFunc(int fn, bool f32, double x, double y) {
 #endif
 }
 
+// double -> int64 as the reference's x86-64 build converts (cvttsd2si): NaN and everything outside the int64 range give
+// INT64_MIN.  (The conversion is undefined in C++; the GPU's own instruction saturates and turns NaN into 0.)
+SSA_HD int64_t F64ToI64LikeX86(double d) {
+    if (!(d >= -9223372036854775808.0 && d < 9223372036854775808.0)) return INT64_MIN;
+    return int64_t(d);
+}
+
 // x % y as C++ computes it in the operands' type; MIN % -1 (undefined there) is 0.
 SSA_HD uint64_t IntRem(bool sgn, uint64_t a, uint64_t b) {
     if (!sgn) return a % b;
@@ -251,8 +258,8 @@ SSA_HD ArithResult ApplyFunc(int fn, int t, uint64_t a, uint64_t b) {
             uint64_t x = a, y = b;
             bool s = sgn;
             if (flt) {
-                x = uint64_t(int64_t(BitsToF64(a)));
-                y = uint64_t(int64_t(BitsToF64(b)));
+                x = uint64_t(F64ToI64LikeX86(BitsToF64(a)));
+                y = uint64_t(F64ToI64LikeX86(BitsToF64(b)));
                 s = true;
             }
             if (y == 0) {
