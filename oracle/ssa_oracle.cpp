@@ -537,6 +537,30 @@ static bool IntFits(bool srcSigned, int64_t si, uint64_t ui, int to) {
     return ui <= hi;
 }
 
+// static_cast<integer>(double) is undefined for NaN and out-of-range values; these follow what the reference's x86-64
+// build (clang, no AVX-512) computes: cvttsd2si returns the "integer indefinite" value INT64_MIN / INT32_MIN for such
+// inputs; targets of up to 32 bits convert through int32 (uint32 through int64) and are then truncated; uint64 is
+// cvttsd2si(x) | (cvttsd2si(x - 2^63) & sign(cvttsd2si(x))).
+static int64_t CvtI64(double d) {
+    if (!(d >= -9223372036854775808.0 && d < 9223372036854775808.0)) return INT64_MIN;
+    return int64_t(d);
+}
+static int32_t CvtI32(double d) {
+    if (!(d > -2147483649.0 && d < 2147483648.0)) return INT32_MIN;
+    return int32_t(d);
+}
+static uint64_t UnsafeFloatToInt(double v, int to) {
+    switch (to) {
+        case I64: case TS: case DUR: return uint64_t(CvtI64(v));
+        case U64: {
+            const int64_t a = CvtI64(v), b = CvtI64(v - 9223372036854775808.0);
+            return uint64_t(a) | (uint64_t(b) & uint64_t(a >> 63));
+        }
+        case U32: return uint64_t(CvtI64(v));
+        default: return uint64_t(int64_t(CvtI32(v)));
+    }
+}
+
 // Numeric cast.  safe = CastOptions::Safe() of Arrow's implicit casts (out-of-range integers and integers
 // a float cannot hold are errors: compute/kernels/scalar_cast_numeric.cc:70-290); unsafe = the
 // CastOptions(false) of ydb.cast (ydb/library/arrow_kernels/func_cast.cpp:101-149): C++ conversions.
@@ -562,13 +586,13 @@ static DatumPtr CastTo(const DatumPtr& in, int to, bool safe) {
             }
             if (to == BOOL) { out->u[r] = v != 0; continue; }
             if (st == S_I) {
-                int64_t x = (v >= -9.3e18 && v <= 9.2e18) ? int64_t(v) : 0;
-                if (safe && valid && !IntFits(true, x, 0, to)) throw Error("Float value out of range");
-                out->i[r] = WrapI(x, to);
+                if (safe && valid && (!(v >= -9223372036854775808.0 && v < 9223372036854775808.0) || !IntFits(true, int64_t(v), 0, to)))
+                    throw Error("Float value out of range");
+                out->i[r] = WrapI(int64_t(UnsafeFloatToInt(v, to)), to);
             } else {
-                uint64_t x = (v >= 0 && v <= 1.8e19) ? uint64_t(v) : uint64_t(int64_t(v >= -9.3e18 && v <= 9.2e18 ? v : 0));
-                if (safe && valid && (v < 0 || !IntFits(false, 0, x, to))) throw Error("Float value out of range");
-                out->u[r] = WrapU(x, to);
+                if (safe && valid && (!(v >= 0 && v < 18446744073709551616.0) || !IntFits(false, 0, uint64_t(v), to)))
+                    throw Error("Float value out of range");
+                out->u[r] = WrapU(UnsafeFloatToInt(v, to), to);
             }
             continue;
         }
@@ -1630,7 +1654,75 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
     std::vector<GroupState> groups;
     std::vector<int64_t> repRow;
     std::string key;
-    for (int64_t r = 0; r < rows; ++r) {
+    auto newState = [&](int64_t r) {
+        GroupState st;
+        st.has.assign(na, 0);
+        st.i.assign(na, 0); st.u.assign(na, 0); st.f.assign(na, 0); st.hi.assign(na, 0);
+        st.firstRow = r;
+        return st;
+    };
+    // IAggregateFunction::add of aggregate k for row r
+    auto addRow = [&](GroupState& st, size_t k, int64_t r) {
+        const Agg fn = step.groupBy[k].fn;
+        const Datum* a = args[k].get();
+        // addBatch skips rows whose argument is null (IAggregateFunction.h:199-221) -- except on the key8 path
+        if (a && !key8 && !a->Valid(r)) return;
+        if (fn == AG_COUNT) { ++st.u[k]; st.has[k] = 1; return; }
+        const Store s = StoreOf(a->ty);
+        switch (fn) {
+            case AG_SUM:  // AggregateFunctionSum.h:31-47: sequential adds in row order, integers wrap
+                if (a->ty == DEC) AddDec(st.u[k], st.hi[k], a->u[r], a->hi[r]);  // extension: wrapping 128-bit sum
+                else if (s == S_I) st.i[k] = int64_t(uint64_t(st.i[k]) + uint64_t(a->i[r]));
+                else if (s == S_U) st.u[k] += a->u[r];
+                else st.f[k] += a->f[r];
+                break;
+            case AG_MIN: case AG_MAX: {  // AggregateFunctionMinMaxAny.h:96-138: first value, then `<` / `>`
+                const bool mn = fn == AG_MIN;
+                if (!st.has[k]) { st.i[k] = s == S_I ? a->i[r] : 0; st.u[k] = s == S_U ? a->u[r] : 0; st.f[k] = s == S_F ? a->f[r] : 0; }
+                else if (s == S_I) { if (mn ? a->i[r] < st.i[k] : a->i[r] > st.i[k]) st.i[k] = a->i[r]; }
+                else if (s == S_U) { if (mn ? a->u[r] < st.u[k] : a->u[r] > st.u[k]) st.u[k] = a->u[r]; }
+                else { if (mn ? a->f[r] < st.f[k] : a->f[r] > st.f[k]) st.f[k] = a->f[r]; }
+                break;
+            }
+            case AG_SOME:
+                if (!st.has[k]) { st.i[k] = s == S_I ? a->i[r] : 0; st.u[k] = s == S_U ? a->u[r] : 0; st.f[k] = s == S_F ? a->f[r] : 0; }
+                break;
+            default: break;
+        }
+        st.has[k] = 1;
+    };
+    // IAggregateFunction::merge of aggregate k: `from` into `st` (Sum: sum += rhs; Count: count += rhs; Min / Max:
+    // changeIfLess / changeIfGreater(to); Any: changeFirstTime(to) -- AggregateFunctionMinMaxAny.h:68-138)
+    auto mergeState = [&](GroupState& st, const GroupState& from, size_t k) {
+        const Agg fn = step.groupBy[k].fn;
+        if (!from.has[k]) return;
+        if (fn == AG_COUNT) { st.u[k] += from.u[k]; st.has[k] = 1; return; }
+        const Store s = StoreOf(args[k]->ty);
+        switch (fn) {
+            case AG_SUM:
+                if (s == S_I) st.i[k] = int64_t(uint64_t(st.i[k]) + uint64_t(from.i[k]));
+                else if (s == S_U) st.u[k] += from.u[k];
+                else st.f[k] += from.f[k];
+                break;
+            case AG_MIN: case AG_MAX: {
+                const bool mn = fn == AG_MIN;
+                bool take = !st.has[k];
+                if (!take) {
+                    if (s == S_I) take = mn ? from.i[k] < st.i[k] : from.i[k] > st.i[k];
+                    else if (s == S_U) take = mn ? from.u[k] < st.u[k] : from.u[k] > st.u[k];
+                    else take = mn ? from.f[k] < st.f[k] : from.f[k] > st.f[k];
+                }
+                if (take) { st.i[k] = from.i[k]; st.u[k] = from.u[k]; st.f[k] = from.f[k]; }
+                break;
+            }
+            case AG_SOME:
+                if (!st.has[k]) { st.i[k] = from.i[k]; st.u[k] = from.u[k]; st.f[k] = from.f[k]; }
+                break;
+            default: break;
+        }
+        st.has[k] = 1;
+    };
+    auto groupOf = [&](int64_t r) {
         key.clear();
         for (auto& k : keys) {
             if (nullAware) {
@@ -1641,47 +1733,40 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
             AppendRaw(key, *k, r);
         }
         auto it = index.find(key);
-        size_t g;
-        if (it == index.end()) {
-            g = groups.size();
-            index.emplace(key, g);
-            GroupState st;
-            st.has.assign(na, 0);
-            st.i.assign(na, 0); st.u.assign(na, 0); st.f.assign(na, 0); st.hi.assign(na, 0);
-            st.firstRow = r;
-            groups.push_back(std::move(st));
-        } else {
-            g = it->second;
+        if (it != index.end()) return it->second;
+        const size_t g = groups.size();
+        index.emplace(key, g);
+        groups.push_back(newState(r));
+        return g;
+    };
+    if (key8) {
+        // The single one-byte key takes the lookup-table path (Aggregator.cpp:302-325): every aggregate goes over the
+        // batch in four interleaved streams with states of their own (row i of the first rows / 4 * 4 rows belongs to
+        // stream i % 4), the streams are merged into the group's state in stream order, and the last rows % 4 rows are
+        // added to it one by one (IAggregateFunction.h:384-459).
+        const int64_t unrolled = rows / 4 * 4;
+        std::vector<std::vector<GroupState>> streams(4);
+        for (int64_t r = 0; r < rows; ++r) {
+            const size_t g = groupOf(r);
+            if (r >= unrolled) continue;
+            auto& sub = streams[size_t(r % 4)];
+            while (sub.size() <= g) sub.push_back(newState(r));
+            for (size_t k = 0; k < na; ++k) addRow(sub[g], k, r);
         }
-        GroupState& st = groups[g];
-        for (size_t k = 0; k < na; ++k) {
-            const Agg fn = step.groupBy[k].fn;
-            const Datum* a = args[k].get();
-            // addBatch skips rows whose argument is null (IAggregateFunction.h:199-221) -- except on the key8 path
-            if (a && !key8 && !a->Valid(r)) continue;
-            if (fn == AG_COUNT) { ++st.u[k]; st.has[k] = 1; continue; }
-            const Store s = StoreOf(a->ty);
-            switch (fn) {
-                case AG_SUM:  // AggregateFunctionSum.h:31-47: sequential adds in row order, integers wrap
-                    if (a->ty == DEC) AddDec(st.u[k], st.hi[k], a->u[r], a->hi[r]);  // extension: wrapping 128-bit sum
-                    else if (s == S_I) st.i[k] = int64_t(uint64_t(st.i[k]) + uint64_t(a->i[r]));
-                    else if (s == S_U) st.u[k] += a->u[r];
-                    else st.f[k] += a->f[r];
-                    break;
-                case AG_MIN: case AG_MAX: {  // AggregateFunctionMinMaxAny.h:96-138: first value, then `<` / `>`
-                    const bool mn = fn == AG_MIN;
-                    if (!st.has[k]) { st.i[k] = s == S_I ? a->i[r] : 0; st.u[k] = s == S_U ? a->u[r] : 0; st.f[k] = s == S_F ? a->f[r] : 0; }
-                    else if (s == S_I) { if (mn ? a->i[r] < st.i[k] : a->i[r] > st.i[k]) st.i[k] = a->i[r]; }
-                    else if (s == S_U) { if (mn ? a->u[r] < st.u[k] : a->u[r] > st.u[k]) st.u[k] = a->u[r]; }
-                    else { if (mn ? a->f[r] < st.f[k] : a->f[r] > st.f[k]) st.f[k] = a->f[r]; }
-                    break;
-                }
-                case AG_SOME:
-                    if (!st.has[k]) { st.i[k] = s == S_I ? a->i[r] : 0; st.u[k] = s == S_U ? a->u[r] : 0; st.f[k] = s == S_F ? a->f[r] : 0; }
-                    break;
-                default: break;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            for (int j = 0; j < 4; ++j) {
+                if (streams[size_t(j)].size() <= g) continue;
+                for (size_t k = 0; k < na; ++k) mergeState(groups[g], streams[size_t(j)][g], k);
             }
-            st.has[k] = 1;
+        }
+        for (int64_t r = unrolled; r < rows; ++r) {
+            const size_t g = groupOf(r);
+            for (size_t k = 0; k < na; ++k) addRow(groups[g], k, r);
+        }
+    } else {
+        for (int64_t r = 0; r < rows; ++r) {
+            const size_t g = groupOf(r);
+            for (size_t k = 0; k < na; ++k) addRow(groups[g], k, r);
         }
     }
     // Output: aggregates in GroupBy order, then keys (program.cpp:728-763); rows in first-appearance order here

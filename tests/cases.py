@@ -265,9 +265,11 @@ def _sort_key(v):
     return (1, v)
 
 
-def compare_batches(got, exp, key_names: Sequence[str] = (), float_sum_names: Sequence[str] = (), rtol: float = FLOAT_SUM_RTOL):
+def compare_batches(got, exp, key_names: Sequence[str] = (), float_sum_names: Sequence[str] = (), rtol: float = FLOAT_SUM_RTOL,
+                    signed_zero_names: Sequence[str] = ()):
     """Same column names in the same order, same types, same rows (after sorting by the key columns when given).
-    Everything is compared exactly except the columns named in `float_sum_names`."""
+    Everything is compared exactly except the columns named in `float_sum_names`; in the columns named in
+    `signed_zero_names` a zero must also have the expected sign."""
     assert list(got.keys()) == list(exp.keys()), (list(got.keys()), list(exp.keys()))
     for name in exp:
         assert got[name].type == exp[name].type, (name, got[name].type, exp[name].type)
@@ -292,3 +294,5 @@ def compare_batches(got, exp, key_names: Sequence[str] = (), float_sum_names: Se
                 assert isinstance(a, float) and math.isnan(a), (name, a, b)
             else:
                 assert a == b, (name, rg, a, b)
+                if name in signed_zero_names and isinstance(b, float) and b == 0.0:
+                    assert math.copysign(1.0, a) == math.copysign(1.0, b), (name, rg, a, b)

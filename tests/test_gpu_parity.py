@@ -163,6 +163,115 @@ def test_group_by_high_cardinality(n):
     compare_batches(got, exp, key_names=["k"], float_sum_names=["17"], rtol=1e-9)
 
 
+def special_floats(rng, n, dtype=np.float64):
+    """Mostly small numbers with NaN, +-inf and both zeros mixed in."""
+    v = rng.integers(-3, 4, n).astype(dtype)
+    pick = rng.random(n)
+    v[pick < 0.10] = np.nan
+    v[(pick >= 0.10) & (pick < 0.14)] = np.inf
+    v[(pick >= 0.14) & (pick < 0.18)] = -np.inf
+    v[(pick >= 0.18) & (pick < 0.30)] = -0.0
+    v[(pick >= 0.30) & (pick < 0.42)] = 0.0
+    return v
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 1025, 60_000])
+@pytest.mark.parametrize("ngroups", [3, 700, 40_000])
+def test_keyed_min_max_keep_a_leading_nan_and_the_first_zero(n, ngroups):
+    # AggregateFunctionMinMaxAny.h:96-138: the state takes the group's first non-null value, then `<` / `>` decide
+    rng = np.random.default_rng(4100 + n + ngroups)
+    key = rng.integers(0, ngroups, n).astype(np.int32)
+    f = special_floats(rng, n)
+    g = Col(special_floats(rng, n, np.float32), valid=rng.random(n) > 0.3, type="float")
+    p = (Program().assign_func(100, F.MATH_ADD, [2, 2])
+         .group_by([Aggregate(10, AGG.MIN, [2]), Aggregate(11, AGG.MAX, [2]), Aggregate(12, AGG.MIN, [3]), Aggregate(13, AGG.MAX, [3]),
+                    Aggregate(14, AGG.MIN, [100]), Aggregate(15, AGG.COUNT, [3])], keys=[1]))
+    got, exp = both([(1, "k"), (2, "f"), (3, "g")], p, {"k": key, "f": f, "g": g})
+    compare_batches(got, exp, key_names=["k"], signed_zero_names=["10", "11", "12", "13", "14"])
+
+
+def test_keyed_min_max_nan_rule_by_hand():
+    nan = float("nan")
+    key = np.array([1, 1, 1, 2, 2, 2, 3, 3, 4, 4, 5, 5], dtype=np.int64)
+    f = np.array([nan, 1.0, 2.0, 1.0, nan, 2.0, nan, nan, 0.0, -0.0, -0.0, 0.0])
+    p = Program().group_by([Aggregate(10, AGG.MIN, [2]), Aggregate(11, AGG.MAX, [2])], keys=[1])
+    from ydb_amd.program import ProgramContainer
+    pc = ProgramContainer()
+    assert pc.Init([(1, "k"), (2, "f")], p)[0]
+    out = pc.ApplyProgram({"k": key, "f": f})
+    rows = {int(k): (mn, mx) for k, mn, mx in zip(out["k"].to_pylist(), out["10"].to_pylist(), out["11"].to_pylist())}
+    import math
+    assert math.isnan(rows[1][0]) and math.isnan(rows[1][1])        # NaN came first: it stays
+    assert rows[2] == (1.0, 2.0)                                    # a later NaN never wins
+    assert math.isnan(rows[3][0]) and math.isnan(rows[3][1])
+    assert math.copysign(1, rows[4][0]) == 1.0 and math.copysign(1, rows[4][1]) == 1.0    # the first zero stays
+    assert math.copysign(1, rows[5][0]) == -1.0 and math.copysign(1, rows[5][1]) == -1.0
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 9, 1000, 70_003])
+@pytest.mark.parametrize("filtered", [False, True])
+def test_single_byte_key_visits_rows_in_four_streams(n, filtered):
+    # IAggregateFunction.h:384-459: SOME is the first row of the lowest stream, a zero MIN / MAX the first zero in that order
+    rng = np.random.default_rng(4200 + n)
+    key = rng.integers(0, 5, n).astype(np.uint8)
+    v = rng.integers(0, 1 << 30, n).astype(np.int64)
+    f = rng.integers(-2, 3, n).astype(np.float64)
+    f[rng.random(n) < 0.3] = -0.0
+    keep = (rng.random(n) < 0.6).astype(np.uint8)
+    p = Program()
+    if filtered:
+        p.filter(4)
+    p.group_by([Aggregate(10, AGG.SOME, [2]), Aggregate(11, AGG.MIN, [3]), Aggregate(12, AGG.MAX, [3]), Aggregate(13, AGG.COUNT, []),
+                Aggregate(14, AGG.SUM, [2])], keys=[1])
+    got, exp = both([(1, "k"), (2, "v"), (3, "f"), (4, "keep")], p, {"k": key, "v": v, "f": f, "keep": keep})
+    compare_batches(got, exp, key_names=["k"], signed_zero_names=["11", "12"])
+
+
+def test_single_byte_key_with_a_nan_under_min_is_declined():
+    from oracle import ssa_oracle
+    from ydb_amd import _lib
+    from ydb_amd.program import ProgramContainer, SsaError
+    key = np.array([1, 1, 2, 2, 1, 1, 2, 2], dtype=np.int8)
+    f = np.array([1.0, float("nan"), 3.0, 4.0, 0.5, 6.0, 7.0, 8.0])
+    p = Program().group_by([Aggregate(10, AGG.MIN, [2])], keys=[1])
+    pc = ProgramContainer()
+    assert pc.Init([(1, "k"), (2, "f")], p)[0]
+    with pytest.raises(SsaError) as e:
+        pc.ApplyProgram({"k": key, "f": f})
+    assert e.value.code == _lib.SSA_UNSUPPORTED
+    # the oracle follows the reference: the NaN leads stream 1 of key 1, whose later 6.0 is lost; 0.5 is in stream 0
+    exp = ssa_oracle.Oracle([(1, "k"), (2, "f")], p).apply({"k": key, "f": f})
+    assert sorted(zip(exp["k"].to_pylist(), exp["10"].to_pylist())) == [(1, 0.5), (2, 3.0)]
+    # without the NaN the same program runs
+    f[1] = 9.0
+    got, exp = both([(1, "k"), (2, "f")], p, {"k": key, "f": f})
+    compare_batches(got, exp, key_names=["k"])
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_colliding_key_hashes_are_told_apart_by_the_key_bytes(jit, monkeypatch):
+    # rows whose keys are hashed (strings of more than 8 bytes, more than 119 key bits) with the hash cut to three bits:
+    # hundreds of different keys per hash value, every one its own group
+    monkeypatch.setenv("SSA_JIT", jit)
+    monkeypatch.setenv("SSA_DEBUG_FLAGS", "64")
+    rng = np.random.default_rng(4300)
+    n = 40_000
+    words = ["", "short", "12345678"] + ["long-key-%05d-%s" % (i, "x" * (i % 23)) for i in range(600)]
+    s = [words[i] for i in rng.integers(0, len(words), n)]
+    v = rng.integers(-1000, 1000, n).astype(np.int32)
+    p = Program().group_by([Aggregate(10, AGG.SUM, [2]), Aggregate(11, AGG.COUNT, []), Aggregate(12, AGG.MIN, [2])], keys=[1])
+    got, exp = both([(1, "s"), (2, "v")], p, {"s": s, "v": v})
+    assert len(exp["s"].to_pylist()) == len(set(s))
+    compare_batches(got, exp, key_names=["s"])
+    # wide fixed-width keys (two nullable int64 and an int32: 162 key bits)
+    a = Col(rng.integers(0, 30, n).astype(np.int64), valid=rng.random(n) > 0.1)
+    b = Col(rng.integers(0, 30, n).astype(np.int64), valid=rng.random(n) > 0.1)
+    c = rng.integers(0, 3, n).astype(np.int32)
+    p = Program().group_by([Aggregate(10, AGG.SUM, [4]), Aggregate(11, AGG.COUNT, [])], keys=[1, 2, 3])
+    got, exp = both([(1, "a"), (2, "b"), (3, "c"), (4, "v")], p, {"a": a, "b": b, "c": c, "v": v})
+    compare_batches(got, exp, key_names=["a", "b", "c"])
+
+
 @pytest.mark.parametrize("widths", [("int32", "int16"), ("int64", "int64"), ("uint8", "float"), ("int64", "uint64", "int32")])
 def test_group_by_nullable_and_wide_keys(widths):
     rng = np.random.default_rng(5000 + len(widths) + sum(map(len, widths)))
@@ -495,3 +604,19 @@ def test_folded_constant_arrays_stay_arrays():
     got, exp = both(res, p, batch)
     compare_batches(got, exp)
     assert len(got["b"].valid) == n
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_unsafe_float_to_integer_casts(jit, monkeypatch):
+    # static_cast<T>(double) where C++ leaves it open: both sides follow the x86-64 conversions (known answers for the
+    # oracle in test_oracle_by_hand.py)
+    monkeypatch.setenv("SSA_JIT", jit)
+    nan, inf = float("nan"), float("inf")
+    base = [nan, inf, -inf, 1e20, -1e20, -1.5, 3e9, 5e9, 1e19, 1.9e19, 70000.5, 300.7, -129.9, 2147483647.5, -2147483648.5, 0.0, -0.0]
+    rng = np.random.default_rng(77)
+    d = np.array(base + list(rng.normal(0, 1e10, 3000)) + list(rng.normal(0, 1e20, 1000)))
+    f = d.astype(np.float32)
+    casts = [F.CAST_TO_INT8, F.CAST_TO_INT16, F.CAST_TO_INT32, F.CAST_TO_INT64, F.CAST_TO_UINT8, F.CAST_TO_UINT16, F.CAST_TO_UINT32,
+             F.CAST_TO_UINT64, F.CAST_TO_BOOLEAN]
+    ops = [("f", c, [src]) for c in casts for src in (1, 2)]
+    both_chunked([(1, "d"), (2, "f")], ops, {"d": d, "f": f})

@@ -13,17 +13,27 @@ RES = [(1, "i32"), (2, "i64"), (3, "f64"), (4, "u8"), (5, "nz"), (6, "i32n"), (7
 WORDS = ["", "a", "ab", "abc", "google", "xabx", "Ab", "the quick brown fox", "zzzzzzzzzz", "ab" * 20, "日本語", "b"]
 
 
-def make_batch(rng, n):
+def with_specials(rng, a):
+    """NaN, +-inf and both zeros in about a tenth of the slots."""
+    a = a.copy()
+    pick = rng.random(len(a))
+    for lo, v in ((0.00, np.nan), (0.03, np.inf), (0.05, -np.inf), (0.07, -0.0), (0.09, 0.0)):
+        a[(pick >= lo) & (pick < lo + 0.02)] = v
+    return a
+
+
+def make_batch(rng, n, specials=False):
+    sp = (lambda a: with_specials(rng, a)) if specials else (lambda a: a)
     return {
         "i32": rng.integers(-1000, 1000, n).astype(np.int32),
         "i64": rng.integers(-10**9, 10**9, n).astype(np.int64),
-        "f64": rng.normal(0, 100, n),
+        "f64": sp(rng.normal(0, 100, n)),
         "u8": rng.integers(0, 200, n).astype(np.uint8),
         "nz": rng.integers(1, 50, n).astype(np.int32),
         "i32n": Col(rng.integers(-50, 50, n).astype(np.int32), valid=rng.random(n) > 0.15),
-        "f64n": Col(rng.normal(0, 10, n), valid=rng.random(n) > 0.15),
+        "f64n": Col(sp(rng.normal(0, 10, n)), valid=rng.random(n) > 0.15),
         "flag": (rng.random(n) < 0.5).astype(np.uint8),
-        "f32": rng.normal(0, 10, n).astype(np.float32),
+        "f32": sp(rng.normal(0, 10, n).astype(np.float32)),
         "s": Col([WORDS[i] for i in rng.integers(0, len(WORDS), n)], valid=rng.random(n) > 0.1, type="string"),
     }
 
@@ -225,7 +235,7 @@ def random_group_by(rng, nassign):
 def test_random_group_bys(seed, monkeypatch):
     rng = np.random.default_rng(5000 + seed)
     n = int(rng.choice([1, 64, 1025, 4097, 50_021]))
-    batch = make_batch(rng, n)
+    batch = make_batch(rng, n, specials=seed % 2 == 1)   # every other seed: NaN, infinities and signed zeros in the floats
     program, keys, fsums = random_group_by(rng, int(rng.integers(0, 6)))
     for jit in ("0", "1"):
         got, gerr, exp, oerr = run_both(program, batch, monkeypatch, jit)

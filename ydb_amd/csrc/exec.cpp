@@ -191,6 +191,10 @@ Status Executor::CheckScanStatus(bool* tableFull) {
     if (st & SCAN_DIV_BY_ZERO) return Status::Invalid("divide by zero");
     if (st & SCAN_CAST_OVERFLOW) return Status::Invalid("Integer value not in range");
     if (st & SCAN_OVERFLOW) return Status::Invalid("overflow");
+    if (st & SCAN_NAN_ORDER) {
+        return Status::Unsupported("MIN / MAX of floating-point values with a NaN among them under a single one-byte GROUP BY key: the "
+                                   "result depends on the order the reference's lookup-table path visits the rows in");
+    }
     if (st == SCAN_TABLE_FULL && tableFull) {
         *tableFull = true;
         return Status::OK();
@@ -1360,6 +1364,35 @@ Status Executor::GatherRows(const Column& src, const BufferPtr& rowIdx, int64_t 
 // assigns and filters run fused with a two-level hash aggregation; the table is then turned into one
 // output row per group, aggregates first, keys after them.
 Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out) {
+    if (plan.NeedsFilteredPositions && plan.HasFilter) {
+        // The result depends on where the rows stand in the filtered batch: filter first, as the reference does
+        // (TProgramStep::ApplyFilters, program.cpp:798-832), then aggregate the compacted columns.
+        StepPlan filterPlan;
+        SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_FILTER_ONLY, filterPlan));
+        BufferPtr bitmap, tileOffsets;
+        int64_t selected = 0;
+        SSA_RETURN_NOT_OK(RunFilterBitmap(filterPlan, in, bitmap, tileOffsets, selected));
+        StepPlan rest;
+        SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_OUTPUTS_ONLY, rest));
+        rest.HasFilter = false;
+        Batch compact;
+        compact.Rows = selected;
+        compact.Cols.resize(in.Cols.size());
+        for (size_t i = 0; i < in.Cols.size(); ++i) {
+            compact.Cols[i].Field = in.Cols[i].Field;
+            compact.Cols[i].Length = selected;
+        }
+        for (int ci : rest.SourceColumns) {
+            if (selected == in.Rows) {
+                compact.Cols[size_t(ci)] = in.Cols[size_t(ci)];
+            } else {
+                SSA_RETURN_NOT_OK(CompactColumn(in.Cols[size_t(ci)], in.Rows, bitmap, tileOffsets, selected, compact.Cols[size_t(ci)]));
+                // (the plan was made for the input's schema: a column keeps its validity slot even when no null is left)
+                compact.Cols[size_t(ci)].Field = in.Cols[size_t(ci)].Field;
+            }
+        }
+        return RunKeyed(step, rest, compact, out);
+    }
     const int naggsUser = int(plan.Aggs.size());
     const int nkeys = int(plan.Keys.size());
     int keyBits = 0;
@@ -1390,7 +1423,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         int found = -1;
         for (size_t j = 0; j < phys.size(); ++j) {
             if (phys[j].kind == spec.kind && phys[j].reg == spec.reg && phys[j].check_valid == spec.check_valid &&
-                phys[j].arg_class == spec.arg_class) found = int(j);
+                phys[j].arg_class == spec.arg_class && phys[j].flags == spec.flags) found = int(j);
         }
         if (found < 0) {
             found = int(phys.size());
@@ -1656,6 +1689,8 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         const AggPlan& ap = plan.Aggs[size_t(k)];
         fa.aggs[k] = ap.Spec;
         fa.agg_src[k] = aggSrc[size_t(k)];
+        fa.agg_nan_src[k] = ap.NanTag >= 0 ? aggSrc[size_t(ap.NanTag)] : -1;
+        fa.agg_zero_src[k] = ap.ZeroTag >= 0 ? aggSrc[size_t(ap.ZeroTag)] : -1;
         Column& col = aggCols[size_t(k)];
         col.Field.Type = ap.OutType;
         col.Length = ngroups;

@@ -84,8 +84,21 @@ __global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArg
             bool valid = true;
             if (f.agg_row_index[k]) {
                 valid = v != ~0ull;  // smallest row with a non-null argument, none -> null
+                if (valid) v &= kRowIndexMask;  // (the order of the single-byte-key path sits above the row index)
             } else {
-                if (kind == AGG_MIN_F || kind == AGG_MAX_F) v = F64FromOrdered(v);
+                if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
+                    v = F64FromOrdered(v);
+                    // the group's first non-null argument was a NaN: the reference's state never leaves it
+                    if (f.agg_nan_src[k] >= 0) {
+                        const uint64_t first = f.t_acc[size_t(f.agg_nan_src[k]) * f.capacity + i];
+                        if (first != ~0ull && (first & 1ull)) v = 0x7FF8000000000000ull;
+                    }
+                    // a zero result: the first zero that arrived stays, `<` / `>` do not tell the two zeros apart
+                    if (f.agg_zero_src[k] >= 0 && (v << 1) == 0) {
+                        const uint64_t first = f.t_acc[size_t(f.agg_zero_src[k]) * f.capacity + i];
+                        if (first != ~0ull) v = (first & 1ull) << 63;
+                    }
+                }
                 if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> f.agg_src[k]) & 1u;
                 if (!valid) v = 0;
                 v = PayloadToStored(v, f.agg_out_type[k]);

@@ -138,6 +138,8 @@ struct KeyedFinalizeArgs {
     int32_t agg_src[kMaxAggs];        // accumulator each output aggregate reads
     int32_t agg_out_type[kMaxAggs];
     int32_t agg_row_index[kMaxAggs];  // the accumulator is a row index (some()): raw uint64 out
+    int32_t agg_nan_src[kMaxAggs];    // float MIN / MAX: accumulator holding MIN((row << 1) | is-NaN), or -1
+    int32_t agg_zero_src[kMaxAggs];   // float MIN / MAX: accumulator holding MIN((row << 1) | sign) over zero arguments, or -1
     KeySpec keys[kMaxKeys];
     // outputs (one row per group)
     uint64_t* group_rep_row;          // hashed keys: representative input row of each group

@@ -15,8 +15,10 @@
 // Keys are 128 bits (lo, hi).  Fixed-width keys of up to 119 bits in total are packed exactly (value
 // bits and, for the null-aware methods, one null flag per key), so the table compares keys, not
 // hashes, and the output key columns are decoded from the table.  Anything wider -- and every string
-// key -- is reduced to a 126-bit hash; those tables also keep the smallest row index of each group and
-// the output keys are gathered from that row of the input.
+// key of more than 8 bytes -- is reduced to a 126-bit hash that finds the slot; the slot is the row's group
+// only if the key columns of its representative row equal the row's (SameKeyRows), so the grouping is
+// exact.  Those tables keep the smallest row index of each group and the output keys are gathered from
+// that row of the input.
 //
 // HBM traffic of the scan is the referenced source columns once plus the table, which is tiny for the
 // groupings this path is for; the bound is HBM bandwidth.
@@ -151,6 +153,85 @@ __device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uin
     return -1;
 }
 
+// Grouping keys of rows r1 and r2 compared value by value, from the key columns in memory.  Used for the rows whose
+// table key is a hash (a string of more than 8 bytes, more than 119 key bits): the hash finds a slot, this decides
+// whether the slot's group is the row's -- equal hashes of different keys end up in different slots.  Such steps take
+// all their keys from input columns.  A string whose offsets do not describe the chars buffer counts as empty.
+__device__ __noinline__ bool SameKeyRows(const ScanArgs& a, const KeyedSink& s, uint64_t r1, uint64_t r2) {
+    if (r1 == r2) return true;
+    for (int k = 0; k < s.nkeys; ++k) {
+        const KeySpec& ks = s.keys[k];
+        const DevColumn& col = a.cols[ks.col >= 0 ? ks.col : -2 - ks.reg];
+        if (ks.col >= 0) {
+            const int32_t* offs = static_cast<const int32_t*>(col.values);
+            int32_t b1 = offs[r1], n1 = offs[r1 + 1] - b1, b2 = offs[r2], n2 = offs[r2 + 1] - b2;
+            if (b1 < 0 || n1 < 0 || int64_t(b1) + n1 > int64_t(col.chars_bytes)) n1 = 0;
+            if (b2 < 0 || n2 < 0 || int64_t(b2) + n2 > int64_t(col.chars_bytes)) n2 = 0;
+            if (n1 != n2) return false;
+            const uint8_t* p = col.chars + b1;
+            const uint8_t* q = col.chars + b2;
+            int32_t i = 0;
+            for (; i + 8 <= n1; i += 8) {
+                uint64_t x, y;
+                __builtin_memcpy(&x, p + i, 8);
+                __builtin_memcpy(&y, q + i, 8);
+                if (x != y) return false;
+            }
+            for (; i < n1; ++i) {
+                if (p[i] != q[i]) return false;
+            }
+        } else {
+            if (ks.nullable && col.validity != nullptr) {
+                const uint32_t v1 = LoadBit(col.validity, int64_t(r1) + col.valid_bit_off);
+                const uint32_t v2 = LoadBit(col.validity, int64_t(r2) + col.valid_bit_off);
+                if (v1 != v2) return false;
+                if (!v1) continue;
+            }
+            const int w = TypeWidth(col.type);
+            if (LoadRaw(col.values, w, int64_t(r1)) != LoadRaw(col.values, w, int64_t(r2))) return false;
+        }
+    }
+    return true;
+}
+
+// TableUpsert for a row whose key is a hash: a slot with the row's hash is the row's group only if the keys of the
+// slot's representative row equal the row's (`same(rep)`); otherwise the probe goes on, so two keys with one hash
+// take two slots.  The owner of a slot stores its row as the representative before it publishes hi; a reader that
+// still sees no representative looks again on its next trip.  Keeps the smallest row of the group as representative.
+template <class Same>
+__device__ __forceinline__ int64_t TableUpsertVerified(uint64_t* tLo, uint64_t* tHi, uint64_t* tRep, uint64_t mask, uint64_t start,
+                                                       uint64_t lo, uint64_t hi, uint64_t row, uint32_t maxProbes, Same same) {
+    uint64_t s = start & mask;
+    uint32_t probes = 0;
+    while (probes < maxProbes) {
+        uint64_t cur = __hip_atomic_load(tLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmpty) {
+            cur = atomicCAS(reinterpret_cast<unsigned long long*>(tLo + s), static_cast<unsigned long long>(kEmpty),
+                            static_cast<unsigned long long>(lo));
+            if (cur == kEmpty) {
+                __hip_atomic_store(tRep + s, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(tHi + s, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return int64_t(s);
+            }
+        }
+        if (cur == lo) {
+            const uint64_t ch = __hip_atomic_load(tHi + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ch == kUnpublished) continue;
+            if (ch == hi) {
+                const uint64_t rep = __hip_atomic_load(tRep + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rep == ~0ull) continue;  // the owner's stores arrive in any order
+                if (same(rep)) {
+                    if (row < rep) atomicMin(reinterpret_cast<unsigned long long*>(tRep + s), static_cast<unsigned long long>(row));
+                    return int64_t(s);
+                }
+            }
+        }
+        s = (s + 1) & mask;
+        ++probes;
+    }
+    return -1;
+}
+
 // Hash of a string key: its length, then its bytes in 8-byte little-endian words.  Takes and returns
 // the two hash lanes by value so that the caller's key state stays in registers.
 struct HashPair {
@@ -249,9 +330,11 @@ constexpr int kHotGroups = 4;               // groups whose SUM / COUNT accumula
 // Level-1 upsert.  Hash positions are claimed like level 2; the owner then numbers the group with the next dense id
 // (order of first appearance in this workgroup), records a representative row and publishes the id.  Accumulators are
 // indexed by dense id, so the first kHotGroups groups of a workgroup are the ones kept in registers.
+// `verify`: the key is a hash -- a slot with it is the row's group only if `same(representative row)`.
+template <class Same>
 __device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint64_t* lRep, uint32_t* lDense, uint32_t* lCount,
                                               uint64_t* lHotKey, uint32_t mask, uint64_t start, uint64_t lo, uint64_t hi, bool twoWords,
-                                              uint64_t row, uint32_t maxProbes) {
+                                              uint64_t row, uint32_t maxProbes, bool verify, Same sameRows) {
     uint32_t s = uint32_t(start) & mask;
     uint32_t probes = 0;
     while (probes < maxProbes) {
@@ -281,7 +364,7 @@ __device__ __forceinline__ int LdsUpsertDense(uint64_t* lLo, uint64_t* lHi, uint
             if (same) {
                 const uint32_t id = __hip_atomic_load(lDense + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (id == kNoDense) continue;
-                return int(id);
+                if (!verify || sameRows(lRep[s])) return int(id);
             }
         }
         s = (s + 1) & mask;
@@ -370,7 +453,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
     const uint32_t tKeyFk = s.keys[ki].fetch_kind, tKeyPayload = s.keys[ki].fetch_payload;
     const int ai = lane < kMaxAggs ? lane : 0;
     const uint32_t tAggKind = uint32_t(s.aggs[ai].kind), tAggReg = uint32_t(s.aggs[ai].reg), tAggCheck = uint32_t(s.aggs[ai].check_valid);
-    const uint32_t tAggFk = s.aggs[ai].fetch_kind, tAggPayload = s.aggs[ai].fetch_payload;
+    const uint32_t tAggFk = s.aggs[ai].fetch_kind, tAggPayload = s.aggs[ai].fetch_payload, tAggFlags = uint32_t(s.aggs[ai].flags);
     const int hi_ = lane < kHotAggs ? lane : 0;
     const uint32_t tHotKind = (lane < kHotAggs && !(m.S().debug_flags & 32)) ? uint32_t(s.hot_kind[hi_]) : 0u;
     const uint32_t tHotOff = uint32_t(s.hot_off[hi_]);
@@ -555,13 +638,19 @@ __device__ __forceinline__ void ScanKeyedBody() {
         for (int u = 0; u < U; ++u) {
             slot[u] = -1;
             if (!((m.P >> u) & 1u)) continue;
-            kb.Finish(u, ((toHash >> u) & 1u) != 0);
+            const bool byHash = ((toHash >> u) & 1u) != 0;
+            kb.Finish(u, byHash);
+            if (byHash && (m.S().debug_flags & 64)) {  // tests: eight hash values for all such rows
+                kb.lo[u] &= 7ull;
+                kb.hi[u] = 0x8000000000000001ull;
+            }
             int id = -1;
 #pragma unroll
             for (int g = 0; g < kHotGroups; ++g) {
                 if (kb.lo[u] == hotLo[g] && (!twoWords || kb.hi[u] == hotHi[g])) id = g;
             }
-            if (id >= 0 && useHot) slot[u] = id; else pending |= 1u << u;
+            // (a row whose key is a hash goes through the tables, where its key is compared with the group's)
+            if (id >= 0 && useHot && !byHash) slot[u] = id; else pending |= 1u << u;
         }
         // Rows of other groups (and of the first groups until their keys are known) go through the tables.  Every trip
         // of the loop takes each lane's next pending row, whichever of its U rows that is: behind a selective filter
@@ -580,15 +669,23 @@ __device__ __forceinline__ void ScanKeyedBody() {
             if (has) {
                 const uint64_t row = uint64_t(m.Row(0)) + uint64_t(pu) * 64u;
                 const uint32_t h = Fold32(klo, khi);
-                if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes);
+                const bool byHash = hashed && (khi >> 63) != 0;  // (exact keys keep the top of hi clear)
+                auto sameRows = [&](uint64_t rep) { return SameKeyRows(a, s, row, rep); };
+                if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes, byHash, sameRows);
                 if (sl < 0) {
-                    const int64_t g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, klo, khi, twoWords, 4096u);
+                    const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
+                    int64_t g;
+                    if (byHash) {
+                        g = TableUpsertVerified(rs.t_key_lo, rs.t_key_hi, rs.t_rep_row, rs.table_mask, start, klo, khi, row, 4096u, sameRows);
+                    } else {
+                        g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, start, klo, khi, twoWords, 4096u);
+                        if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(row));
+                    }
                     if (g < 0) {
                         m.err |= SCAN_TABLE_FULL;
                         m.P &= ~(1u << pu);
                     } else {
                         sl = -2 - g;
-                        if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(row));
                     }
                 }
             }
@@ -674,6 +771,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
             spec.check_valid = int32_t(SSA_ROW(tAggCheck, s.aggs[k].check_valid, k));
             spec.fetch_kind = SSA_ROW(tAggFk, s.aggs[k].fetch_kind, k);
             spec.fetch_payload = SSA_ROW(tAggPayload, s.aggs[k].fetch_payload, k);
+            spec.flags = int32_t(SSA_ROW(tAggFlags, s.aggs[k].flags, k));
             Val<U> x;
             if (spec.reg != -1) {
                 m.FetchOperand(spec.fetch_kind, spec.fetch_payload, x);
@@ -702,7 +800,10 @@ __device__ __forceinline__ void ScanKeyedBody() {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const double d = BitsToF64(x.v[u]);
-                    if (d != d) live &= ~(1u << u);
+                    if (d != d) {
+                        if ((spec.flags & AGG_NAN_UNSUPPORTED) && ((live >> u) & 1u)) m.err |= SCAN_NAN_ORDER;
+                        live &= ~(1u << u);
+                    }
                     x.v[u] = OrderedFromF64(x.v[u]);
                 }
             }
@@ -754,12 +855,20 @@ __device__ __forceinline__ void ScanKeyedBody() {
         const uint64_t hi = twoWords ? lHi[i] : 0ull;
         const uint32_t d = lDense[i];
         const uint32_t h = Fold32(lo, twoWords ? hi : 0ull);
-        const int64_t g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24, lo, hi, twoWords, 4096u);
+        const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
+        int64_t g;
+        if (hashed && (hi >> 63) != 0) {
+            const uint64_t row = lRep[i];
+            g = TableUpsertVerified(rs.t_key_lo, rs.t_key_hi, rs.t_rep_row, rs.table_mask, start, lo, hi, row, 4096u,
+                                    [&](uint64_t rep) { return SameKeyRows(a, s, row, rep); });
+        } else {
+            g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, start, lo, hi, twoWords, 4096u);
+            if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(lRep[i]));
+        }
         if (g < 0) {
             m.err |= SCAN_TABLE_FULL;
             continue;
         }
-        if (hashed) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(lRep[i]));
         for (int k = 0; k < naggs; ++k) {
             const int kind = s.aggs[k].kind;
             const uint64_t* src = lAcc + (size_t(k) * L + d) * R;

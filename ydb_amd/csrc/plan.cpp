@@ -1106,7 +1106,7 @@ struct Compiler {
             // key8 lookup-table path does not look at argument validity (IAggregateFunction.h:258-296,384-459).
             const bool key8Path = !hasNullableKey && keyExprs.size() == 1 && TypeWidth(keyExprs[0]->Type) == 1;
 
-            std::vector<int> decimalSums;
+            std::vector<int> decimalSums, nanTagged, zeroTagged;
             for (size_t i = 0; i < Step.GroupBy.size(); ++i) {
                 const TAggregateAssign& g = Step.GroupBy[i];
                 AggPlan ap{};
@@ -1172,6 +1172,10 @@ struct Compiler {
                     rowIdx->L = arg;
                     rowIdx->Type = T_U64;
                     rowIdx->Nullable = arg->Nullable;
+                    if (key8Path && !Step.GroupByKeys.empty()) {
+                        rowIdx->A = ROWIDX_LOOKUP_ORDER;
+                        Plan.NeedsFilteredPositions = true;
+                    }
                     ap.Spec.kind = AGG_MIN_U;
                     ap.Spec.arg_class = CLS_U;
                     ap.SomeInputColumn = ap.ArgInputColumn;
@@ -1204,6 +1208,17 @@ struct Compiler {
                     }
                 }
                 if (!st.ok()) return st;
+                if ((ap.Spec.kind == AGG_MIN_F || ap.Spec.kind == AGG_MAX_F) && !Step.GroupByKeys.empty()) {
+                    if (key8Path) {
+                        // Four interleaved streams, each with the NaN-first rule, merged afterwards: values behind a
+                        // stream's leading NaN are lost.  Not reproduced: a NaN argument sends the batch to the CPU path.
+                        ap.Spec.flags |= AGG_NAN_UNSUPPORTED;
+                        Plan.NeedsFilteredPositions = true;
+                    } else {
+                        nanTagged.push_back(int(i));
+                    }
+                    zeroTagged.push_back(int(i));
+                }
                 Plan.Aggs.push_back(ap);
                 OutColumn oc;
                 oc.Source = OutColumn::FROM_AGG;
@@ -1226,6 +1241,40 @@ struct Compiler {
                     (part == 1 ? Plan.Aggs[size_t(user)].DecMid : Plan.Aggs[size_t(user)].DecHi) = int(Plan.Aggs.size());
                     Plan.Aggs.push_back(hidden);
                 }
+            }
+            for (int pass = 0; pass < 2; ++pass) {
+              std::vector<std::pair<Expr*, int>> made;  // MIN and MAX of one argument share their tags
+              for (int user : (pass == 0 ? nanTagged : zeroTagged)) {
+                Expr* of = Strip(Lookup(Step.GroupBy[size_t(user)].Arguments[0].ColumnName).get());
+                int shared = -1;
+                for (auto& m : made) {
+                    if (m.first == of) shared = m.second;
+                }
+                if (shared >= 0) {
+                    (pass == 0 ? Plan.Aggs[size_t(user)].NanTag : Plan.Aggs[size_t(user)].ZeroTag) = shared;
+                    continue;
+                }
+                made.emplace_back(of, int(Plan.Aggs.size()));
+                AggPlan hidden{};
+                hidden.Hidden = true;
+                hidden.OutType = T_U64;
+                hidden.ArgType = T_U64;
+                hidden.ArgNullable = Plan.Aggs[size_t(user)].ArgNullable;
+                hidden.Spec.kind = AGG_MIN_U;
+                hidden.Spec.arg_class = CLS_U;
+                hidden.Spec.check_valid = hidden.ArgNullable ? 1 : 0;
+                ExprPtr arg = Lookup(Step.GroupBy[size_t(user)].Arguments[0].ColumnName);
+                auto tag = std::make_shared<Expr>();
+                tag->Kind = Expr::UNARY;
+                tag->Op = OP_ROWIDX;
+                tag->A = pass == 0 ? ROWIDX_NAN_TAG : (ROWIDX_ZERO_TAG | (key8Path ? ROWIDX_LOOKUP_ORDER : 0));
+                tag->L = arg;
+                tag->Type = T_U64;
+                tag->Nullable = arg->Nullable;
+                hidden.Spec.reg = addRegOut(tag);
+                (pass == 0 ? Plan.Aggs[size_t(user)].NanTag : Plan.Aggs[size_t(user)].ZeroTag) = int(Plan.Aggs.size());
+                Plan.Aggs.push_back(hidden);
+              }
             }
             if (Plan.Aggs.size() > size_t(kMaxAggs)) return Status::Unsupported("too many aggregates in one step");
             if (!st.ok()) return st;

@@ -66,6 +66,13 @@ struct AggPlan {
     int DecMid = -1, DecHi = -1;
     int32_t Precision = 0, Scale = 0;
     bool Hidden = false;
+    // Keyed float MIN / MAX: index of the hidden aggregate MIN((row << 1) | is-NaN) over the same argument.  The
+    // reference's state takes the group's first non-null value whatever it is and then compares with `<` / `>`, which a
+    // NaN never passes (AggregateFunctionMinMaxAny.h:96-138): the result is NaN exactly when that first value is one.
+    int NanTag = -1;
+    // The same compares never replace a zero by the zero of the other sign: a zero result has the sign of the group's
+    // first zero argument.  Index of the hidden aggregate MIN((row << 1) | sign) over the zero arguments.
+    int ZeroTag = -1;
 };
 
 struct KeyPlan {
@@ -83,6 +90,9 @@ struct StepPlan {
     bool Nullable = false;
     bool HasFilter = false;
     bool UnreadFallible = false;  // assigns that nothing reads but that can fail: evaluated for their errors
+    // The step groups by one single-byte key and an aggregate's result depends on the positions of the rows in the
+    // FILTERED batch (RowIdxFlags): a step with filters is run on the compacted batch, as the reference does.
+    bool NeedsFilteredPositions = false;
     int NumRegsUsed = 0;
     // sink description
     std::vector<OutColumn> Outs;      // output batch columns in order

@@ -1074,7 +1074,19 @@ struct Machine {
         }
         case OP_ROWIDX:
 #pragma unroll
-            for (int u = 0; u < U; ++u) A.v[u] = uint64_t(Row(u));
+            for (int u = 0; u < U; ++u) {
+                uint64_t r = uint64_t(Row(u));
+                if (fa & ROWIDX_LOOKUP_ORDER) {
+                    const uint64_t stream = int64_t(r) < (nrows & ~int64_t(3)) ? (r & 3ull) : 4ull;
+                    r |= stream << kRowStreamShift;
+                }
+                if (fa & ROWIDX_NAN_TAG) {
+                    const double d = BitsToF64(A.v[u]);
+                    r = (r << 1) | (d != d ? 1ull : 0ull);
+                }
+                if (fa & ROWIDX_ZERO_TAG) r = BitsToF64(A.v[u]) == 0.0 ? ((r << 1) | (A.v[u] >> 63)) : ~0ull;
+                A.v[u] = r;
+            }
             break;
         case OP_DECPART: {
             // 128-bit sums are carried as three 64-bit sums of these parts (the 32-bit halves of the low word cannot

@@ -154,7 +154,8 @@ enum OpCode : int32_t {
     OP_STRMATCH,  // A = match(string column si, pattern const a); b = StrMatchKind | (ignore_case << 4)
     OP_STRCMP,    // A = string column si  cmp  (const a | column a); b = CmpOp | (rhs_is_column << 4)
     OP_PRED,      // P &= (A != 0)   -- value bit only, validity ignored (reference: program.cpp:517-527)
-    OP_ROWIDX,    // A.value = global row index; A's validity is kept
+    OP_ROWIDX,    // A.value = global row index; A's validity is kept.  a = RowIdxFlags (the order the reference's
+                  // single-byte-key path visits rows in; a NaN tag in bit 0 of the result)
     OP_PREDCMP,   // P &= (column si  cmp  constant a); b = CmpOp | (class << 4).  Fusion of LD col; CMP const; PRED
     OP_DECPART,   // A = part a of decimal128 column si: 0 = bits 0..31, 1 = bits 32..63, 2 = bits 64..127 (validity of the column)
     OP_FUNC,      // A = f(A, B)          a = TypeId of the operands, b = FuncId; unary functions ignore B
@@ -189,7 +190,7 @@ constexpr int kMaxCols = 16;     // source columns referenced by one scan progra
 constexpr int kMaxRegs = 16;     // R registers (outputs first, then temporaries); they live in LDS
 constexpr int kMaxConsts = 24;
 constexpr int kMaxCode = 64;      // instructions per step (one per lane of a wave)
-constexpr int kMaxAggs = 12;
+constexpr int kMaxAggs = 16;
 constexpr int kMaxKeys = 6;
 constexpr int kMaxOuts = 12;
 constexpr int kMaxPatternBytes = 256;  // all string constants of one program, concatenated
@@ -199,9 +200,22 @@ enum ScanStatus : uint32_t {
     SCAN_OK = 0,
     SCAN_DIV_BY_ZERO = 1,      // Arrow integer divide by zero -> Status::Invalid("divide by zero")
     SCAN_CAST_OVERFLOW = 2,    // safe implicit cast failed -> Status::Invalid("Integer value ... not in range")
-    SCAN_TABLE_FULL = 4,
-    SCAN_OVERFLOW = 8,         // checked integer arithmetic -> Status::Invalid("overflow")       // group-by spill table ran out of slots (host retries with a bigger one)
+    SCAN_TABLE_FULL = 4,       // group-by spill table ran out of slots (host retries with a bigger one)
+    SCAN_OVERFLOW = 8,         // checked integer arithmetic -> Status::Invalid("overflow")
+    SCAN_NAN_ORDER = 16,       // a NaN reached a float MIN / MAX whose result would depend on the reference's visiting order
 };
+
+// OP_ROWIDX variants.  The reference's aggregator visits the rows of a batch grouped by ONE single-byte key in four
+// interleaved streams (rows 0, 4, 8, ..; 1, 5, ..; ..) and then the last rows % 4 of the batch
+// (ydb/library/arrow_clickhouse/AggregateFunctions/IAggregateFunction.h:384-459): "the first row of a group" is the
+// smallest row in that order.
+enum RowIdxFlags : int32_t {
+    ROWIDX_LOOKUP_ORDER = 1,  // result = (stream << kRowStreamShift) | row, stream = row % 4, or 4 for the last nrows % 4 rows
+    ROWIDX_NAN_TAG = 2,       // result = (result << 1) | (A is NaN)
+    ROWIDX_ZERO_TAG = 4,      // result = A is +-0.0 ? (result << 1) | (sign of A) : ~0 (the identity of an unsigned MIN)
+};
+constexpr int kRowStreamShift = 58;
+constexpr uint64_t kRowIndexMask = (1ull << kRowStreamShift) - 1ull;
 
 struct DevColumn {
     const void* values;       // fixed width: values; BOOL: bitmap; strings: int32 offsets (rows + 1 entries)
@@ -267,6 +281,11 @@ struct AggSpec {
     int32_t check_valid; // skip rows whose argument is null (0: the argument's validity is not consulted)
     uint32_t fetch_kind;    // pre-decoded operand (FetchKind, payload) for `reg`
     uint32_t fetch_payload;
+    int32_t flags;      // AggFlags
+    int32_t reserved;
+};
+enum AggFlags : int32_t {
+    AGG_NAN_UNSUPPORTED = 1,  // float MIN / MAX: a NaN argument raises SCAN_NAN_ORDER instead of being skipped
 };
 
 struct KeySpec {

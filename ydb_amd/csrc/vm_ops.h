@@ -47,7 +47,22 @@ SSA_HD uint64_t WrapTo(uint64_t v, int t) {
     }
 }
 
-// static_cast between numeric representations.  `from` is the payload class, `to` a TypeId.
+// double -> int64 / int32 as the reference's x86-64 build converts (cvttsd2si): NaN and everything outside the target's
+// range give INT64_MIN / INT32_MIN.  (The conversion is undefined in C++; the GPU's own instruction saturates and turns
+// NaN into 0.)
+SSA_HD int64_t F64ToI64LikeX86(double d) {
+    if (!(d >= -9223372036854775808.0 && d < 9223372036854775808.0)) return INT64_MIN;
+    return int64_t(d);
+}
+SSA_HD int32_t F64ToI32LikeX86(double d) {
+    if (!(d > -2147483649.0 && d < 2147483648.0)) return (-2147483647 - 1);
+    return int32_t(d);
+}
+
+// static_cast between numeric representations.  `from` is the payload class, `to` a TypeId.  A floating value goes to
+// an integer type as the reference's build (clang for x86-64 without AVX-512) compiles static_cast<T>(double), also
+// where C++ leaves the result open: int64 by cvttsd2si, targets of up to 32 bits through int32 (uint32 through int64)
+// and then truncated, uint64 as cvttsd2si(x) | (cvttsd2si(x - 2^63) & sign(cvttsd2si(x))).
 SSA_HD uint64_t CastVal(uint64_t v, int from, int to) {
     const bool toF = (to == T_F32 || to == T_F64);
     if (from == CLS_I || from == CLS_U) {
@@ -65,8 +80,18 @@ SSA_HD uint64_t CastVal(uint64_t v, int from, int to) {
     if (to == T_F64) return v;
     if (to == T_F32) return F64ToBits(double(float(d)));
     if (to == T_BOOL) return d != 0.0 ? 1 : 0;
-    if (IsUnsignedInt(to)) return WrapTo(uint64_t(d), to);
-    return WrapTo(uint64_t(int64_t(d)), to);
+    switch (to) {
+        case T_I64: case T_TS: case T_DUR:
+            return uint64_t(F64ToI64LikeX86(d));
+        case T_U64: {
+            const int64_t a = F64ToI64LikeX86(d), b = F64ToI64LikeX86(d - 9223372036854775808.0);
+            return uint64_t(a) | (uint64_t(b) & uint64_t(a >> 63));
+        }
+        case T_U32:
+            return WrapTo(uint64_t(F64ToI64LikeX86(d)), to);
+        default:
+            return WrapTo(uint64_t(int64_t(F64ToI32LikeX86(d))), to);
+    }
 }
 
 // Would a *safe* cast of this value to `to` succeed?  (Arrow's implicit casts inserted by
@@ -202,13 +227,6 @@ SSA_HD double MathFunc(int fn, bool f32, double x, double y) {
         default: return 0;
     }
 #endif
-}
-
-// double -> int64 as the reference's x86-64 build converts (cvttsd2si): NaN and everything outside the int64 range give
-// INT64_MIN.  (The conversion is undefined in C++; the GPU's own instruction saturates and turns NaN into 0.)
-SSA_HD int64_t F64ToI64LikeX86(double d) {
-    if (!(d >= -9223372036854775808.0 && d < 9223372036854775808.0)) return INT64_MIN;
-    return int64_t(d);
 }
 
 // x % y as C++ computes it in the operands' type; MIN % -1 (undefined there) is 0.
