@@ -175,6 +175,17 @@ int ssa_filter_from_runs(ssa_program_t* program, int first_value, const uint32_t
 /* TProgramStep::BuildFilter (ydb/core/formats/arrow/program.cpp:921-946) on an HBM-resident batch, the result staying in
  * HBM.  *out = NULL when the step has no Filter command (the reference returns nullptr). */
 int ssa_filter_from_program(ssa_program_t* program, size_t step_index, const ssa_batch_t* batch, ssa_filter_t** out, char** err);
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): ssa_filter_from_program with the result in caller-provided
+ * memory.  `out_bits` is DEVICE memory of ceil(rows / 64) 64-bit words and receives the filter as an Arrow-order
+ * bitmap (bit i of word i / 64 = row i passes, zero past the last row); *out_selected the number of rows kept.  The
+ * scan's per-tile counts go to a static buffer of 256 KiB + 256 bytes that every GPU the library runs on holds for
+ * the life of the process; the generic scan kernel runs (none is built for the program); no hipMalloc / hipFree is
+ * called.  At most 67 108 864 (2^26) rows: more is SSA_INVALID.  A step without a Filter command is SSA_INVALID.
+ * Calls on one GPU share that GPU's buffer: calls that overlap on one GPU -- from programs of their own too -- race;
+ * serialise them. */
+int ssa_filter_from_program_noalloc(ssa_program_t* program, size_t step_index, const ssa_batch_t* batch, uint64_t* out_bits,
+                                    int64_t* out_selected, char** err);
 /* TColumnFilter::MakePredicateFilter(batch, border, compareType) (arrow_filter.cpp:118-136, 259-311; caller
  * engines/predicate/container.h:74): `border` is a one-row RecordBatch (host memory, Arrow C Data Interface) whose
  * columns are the leading key columns; rows are compared with it key after key (values only: validity is not looked

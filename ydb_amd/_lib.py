@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "ssa_gen_lineitem",
     "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
     "ssa_filter_combine_sequential_and", "ssa_filter_info", "ssa_filter_runs", "ssa_filter_bits", "ssa_filter_filtered_count",
-    "ssa_filter_apply", "ssa_filter_destroy",
+    "ssa_filter_apply", "ssa_filter_destroy", "ssa_filter_from_program_noalloc",
 ]
 
 _lib = None
@@ -117,6 +117,8 @@ def load() -> ctypes.CDLL:
     lib.ssa_filter_from_runs.restype = i32
     lib.ssa_filter_from_program.argtypes = [vp, sz, vp, P(vp), P(vp)]
     lib.ssa_filter_from_program.restype = i32
+    lib.ssa_filter_from_program_noalloc.argtypes = [vp, sz, vp, vp, P(i64), P(vp)]
+    lib.ssa_filter_from_program_noalloc.restype = i32
     lib.ssa_filter_predicate.argtypes = [vp, vp, P(ArrowArray), P(ArrowSchema), i32, P(vp), P(vp)]
     lib.ssa_filter_predicate.restype = i32
     for f in (lib.ssa_filter_and, lib.ssa_filter_or, lib.ssa_filter_combine_sequential_and):

@@ -399,6 +399,20 @@ int ssa_filter_from_program(ssa_program_t* program, size_t step_index, const ssa
     return SSA_OK;
 }
 
+int ssa_filter_from_program_noalloc(ssa_program_t* program, size_t step_index, const ssa_batch_t* batch, uint64_t* out_bits,
+                                    int64_t* out_selected, char** err) {
+    SSA_FILTER_ENTER();
+    auto& steps = program->Container.GetProgram()->Steps;
+    if (step_index >= steps.size()) return Fail(Status::Invalid("no such step"), err);
+    if (steps[step_index]->Filters.empty()) return Fail(Status::Invalid("the step has no Filter command"), err);
+    if (!batch || !out_selected) return Fail(Status::Invalid("null argument"), err);
+    int64_t selected = 0;
+    Status st = program->Exec->FilterFromStepNoAlloc(*steps[step_index], *batch->Batch, out_bits, selected);
+    if (!st.ok()) return Fail(st, err);
+    *out_selected = selected;
+    return SSA_OK;
+}
+
 int ssa_filter_predicate(ssa_program_t* program, const ssa_batch_t* batch, const ArrowArray* border, const ArrowSchema* border_schema,
                          int compare_type, ssa_filter_t** out, char** err) {
     SSA_FILTER_ENTER();

@@ -149,6 +149,9 @@ Executor::Executor(int device) : Device(device) {
     if (cfgErr != hipSuccess) std::fprintf(stderr, "ydb_ssa_hip: cannot raise the LDS limit of the scan kernels: %s\n", hipGetErrorString(cfgErr));
     StatusWord = Buffer::Alloc(256);
     if (StatusWord) (void)hipMemset(StatusWord->Ptr, 0, 256);
+    hipError_t scratchErr = hipSuccess;
+    NoAllocScratch = NoAllocScratchFor(device, &scratchErr);
+    if (!NoAllocScratch) std::fprintf(stderr, "ydb_ssa_hip: no static scratch buffer on device %d: %s\n", device, hipGetErrorString(scratchErr));
 }
 
 Executor::~Executor() {
@@ -1803,6 +1806,41 @@ Status Executor::ApplyProgram(const TProgram& program, const BatchPtr& in, Batch
         cur = next;
     }
     out = cur;
+    return Status::OK();
+}
+
+// No device memory is allocated or freed here: the generic scan kernel (a kernel built for the program would have to
+// be loaded), the caller's bitmap, the static scratch buffer, the status word made with the executor.
+Status Executor::FilterFromStepNoAlloc(const TProgramStep& step, const Batch& in, uint64_t* outBits, int64_t& selected) {
+    (void)hipSetDevice(Device);
+    selected = 0;
+    if (in.Rows > kNoAllocMaxRows) {
+        return Status::Invalid("ssa_filter_from_program_noalloc takes at most " + std::to_string(kNoAllocMaxRows) + " rows, the batch has " +
+                               std::to_string(in.Rows));
+    }
+    if (!NoAllocScratch || !StatusWord) return Status::Hip("the static scratch buffer of this device is not available");
+    if (!outBits && in.Rows > 0) return Status::Invalid("null output bitmap");
+    StepPlan plan;
+    SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_FILTER_ONLY, plan));
+    if (in.Rows == 0) return Status::OK();
+    ScanArgs args;
+    LaunchCfg cfg;
+    int64_t algoBytes;
+    SSA_RETURN_NOT_OK(FillScanArgs(plan, in, 0, SCAN_FILTER, args, cfg, algoBytes));
+    SSA_RETURN_NOT_OK(GenericKernelCan(args));
+    unsigned char* base = static_cast<unsigned char*>(NoAllocScratch);
+    uint32_t* tileCounts = reinterpret_cast<uint32_t*>(base);
+    unsigned long long* total = reinterpret_cast<unsigned long long*>(base + kNoAllocTotalOffset);
+    const int64_t ntiles = (in.Rows + kTileRows - 1) / kTileRows;
+    FilterSink sink{outBits, tileCounts};
+    ProfileBegin();
+    SSA_HIP(LaunchScanFilter(args, sink, cfg));
+    ProfileEnd("ScanFilterKernel", algoBytes);
+    SSA_HIP(LaunchSumTileCounts(tileCounts, ntiles, total, StreamHandle));
+    unsigned long long sel = 0;
+    SSA_HIP(hipMemcpyAsync(&sel, total, 8, hipMemcpyDeviceToHost, StreamHandle));
+    SSA_RETURN_NOT_OK(CheckScanStatus());
+    selected = int64_t(sel);
     return Status::OK();
 }
 

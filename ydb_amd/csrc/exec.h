@@ -124,6 +124,9 @@ public:
     Status FilterToRuns(const DeviceFilter& f, std::vector<uint32_t>& runs, bool& lastValue);
     // TProgramStep::BuildFilter kept in HBM.
     Status FilterFromStep(const TProgramStep& step, const BatchPtr& in, FilterPtr& out);
+    // The same without allocating device memory: the bitmap goes to caller-provided device memory (ceil(rows / 64)
+    // words), the per-tile counts to the library's static scratch buffer; up to kNoAllocMaxRows rows.
+    Status FilterFromStepNoAlloc(const TProgramStep& step, const Batch& in, uint64_t* outBits, int64_t& selected);
     Status FilterAndOr(const DeviceFilter& a, const DeviceFilter& b, bool isOr, FilterPtr& out);
     Status FilterCombineSequentialAnd(const DeviceFilter& self, const DeviceFilter& ext, FilterPtr& out);
     Status FilterPredicate(const Batch& in, const std::vector<BorderValue>& border, int compareType, FilterPtr& out);
@@ -166,6 +169,7 @@ private:
     hipEvent_t EvStart = nullptr, EvStop = nullptr;
     hipEvent_t EvTuneA = nullptr, EvTuneB = nullptr;
     BufferPtr StatusWord;   // device uint32
+    void* NoAllocScratch = nullptr;  // this device's copy of the static scratch buffer (resolved at construction)
     // Sizing of the two hash-table levels of a keyed step, learnt from its previous run (performance only).
     struct KeyedHint {
         int LdsCap = 16;

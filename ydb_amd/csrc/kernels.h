@@ -168,6 +168,14 @@ hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, 
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);
 
+// ---- the entry point that allocates nothing -----------------------------------------------------------
+constexpr int64_t kNoAllocMaxRows = int64_t(1) << 26;  // 64 Mi rows: 65 536 tiles
+// [tile counts: one uint32 per tile of kTileRows rows][total: 8 bytes, 256-byte aligned]
+constexpr size_t kNoAllocTotalOffset = size_t(kNoAllocMaxRows / kTileRows) * 4;
+constexpr size_t kNoAllocScratchBytes = kNoAllocTotalOffset + 256;
+void* NoAllocScratchFor(int device, hipError_t* error);
+hipError_t LaunchSumTileCounts(const uint32_t* counts, int64_t ntiles, unsigned long long* total, hipStream_t st);
+
 constexpr int kMaxShardKeys = 8;  // key columns of a sharding hash / a predicate border
 
 // ---- TColumnFilter on the device ----------------------------------------------------------------------
