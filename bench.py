@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Scan-pushdown benchmark: rows/s of the SSA program executor over an HBM-resident lineitem.
 
-    python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q6|cb_*] [--rows R]
+    python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q6|mixed|cb_*] [--rows R]
 
 One step = one pass of the program (TPC-H Q1 by default: filter, two computed columns, nine aggregates
 grouped by (l_returnflag, l_linestatus)) over this rank's SF100 lineitem shard, result on the host.  With
 N > 1 (one process per GPU, launched by torch.distributed.run) every rank scans its own SF100-sized
 row range and the partial aggregates are merged through one RCCL all-gather plus a merge program, all
 inside the timed region; `value` is the rows all ranks scanned divided by the slowest rank's time.
+
+At N = 1 the default run also times the other half of the metric on the same resident table -- TPC-H Q6 and Q1 over
+1-byte flag codes -- and reports them under "also", each with its own roofline and CPU baseline.
+
+`--workload mixed` is the stream of the sharded SF1000 configuration: Q1 and Q6 alternate over one resident shard of
+SF1000 / 8 = 750 M rows; one step = one Q1 pass plus one Q6 pass.
 
 The cb_* workloads are the ClickBench scan-aggregate programs over a synthetic 100 M-row `hits` (ydb_amd/clickbench.py);
 their high-cardinality group-bys leave the result table in HBM on one GPU (the row count is read back).
@@ -25,17 +31,18 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
-PMC_TRAFFIC_FILE = "r1_d_pmc_traffic.json"  # FETCH_SIZE passes of the scan kernels, as ratios to the algorithmic bytes
+# FETCH_SIZE passes of the scan kernels (rocprofv3 --pmc, their own runs), kept as ratios to the algorithmic bytes
+PMC_TRAFFIC_FILES = ("r2_pmc_traffic.json", "r1_d_pmc_traffic.json")
+SF1000_SHARD_ROWS = 750_000_000  # SF1000 lineitem (6.0e9 rows) over the 8 GPUs of a node
 
 
-def cpu_baseline(workload: str, seconds_target: float = 15.0):
+def cpu_baseline(workload: str, seconds_target: float = 15.0, all_cores_seconds: float = 8.0):
     """Times the CPU oracle (a port of the reference's op-at-a-time execution) on a bounded sample."""
     try:
         from oracle import ssa_oracle
     except Exception as e:  # oracle library not built
         return {"value": None, "unit": "rows/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
     from ydb_amd import tpch
-    import numpy as np
 
     batch_rows = 1_000_000  # the reference hands the program batches of about this size
     if workload.startswith("cb_"):
@@ -69,7 +76,7 @@ def cpu_baseline(workload: str, seconds_target: float = 15.0):
     # (the oracle is called through ctypes, which releases the interpreter lock), each thread with its own program.
     import threading
     cores = max(1, min(16, os.cpu_count() or 1))
-    per_thread = max(1, int(n * min(1.0, 8.0 / max(dt, 1e-3))))
+    per_thread = max(1, int(n * min(1.0, all_cores_seconds / max(dt, 1e-3))))
     workers = []
     for _ in range(cores):
         o = ssa_oracle.Oracle(resolver, prog)
@@ -94,15 +101,63 @@ def cpu_baseline(workload: str, seconds_target: float = 15.0):
     return out
 
 
+def pmc_traffic(workload: str, algo_bytes_per_launch: float):
+    """HBM bytes per launch from the committed FETCH_SIZE passes: (bytes, where the ratio comes from) or (None, None)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                pmc = json.load(f).get(workload)
+        except OSError:
+            continue
+        if pmc and "note" not in pmc:
+            rows = pmc.get("rows")
+            return (pmc["ratio_to_algorithmic"] * algo_bytes_per_launch,
+                    f"not a counter of this run: ratio {pmc['ratio_to_algorithmic']:.4f} of HBM bytes read (rocprofv3 --pmc FETCH_SIZE, "
+                    f"its own pass{', ' + str(rows) + ' rows' if rows else ''}) to algorithmic bytes, from profiles/{name}, "
+                    "times the algorithmic bytes of this launch")
+    return None, None
+
+
+def tpch_workload(workload: str):
+    """(program, columns, algorithmic bytes per row, name) of a TPC-H workload."""
+    from ydb_amd import tpch
+    if workload == "q6":
+        return tpch.q6_program(), tpch.Q6_COLUMNS, tpch.Q6_BYTES_PER_ROW, "TPC-H Q6"
+    codes = workload == "q1_codes"
+    return (tpch.q1_program(codes), tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8,
+            tpch.Q1_BYTES_PER_ROW_CODES if codes else tpch.Q1_BYTES_PER_ROW_UTF8,
+            "TPC-H Q1" + (" (1-byte flag codes)" if codes else " (utf8 flags)"))
+
+
+def roofline_of(workload: str, prog, kernel_ms: float, launches: int, algo_bytes: int, spec_launches: int):
+    from ydb_amd.shard import last_group_by
+    gb = last_group_by(prog)
+    keyed = bool(gb.keys) if gb is not None else False
+    avg_kernel_s = (kernel_ms / 1e3) / max(1, launches)
+    per_launch = algo_bytes / max(1, launches)
+    achieved = per_launch / avg_kernel_s / 1e9 if launches and avg_kernel_s > 0 else 0.0
+    traffic, source = pmc_traffic(workload, per_launch)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": source,
+            # the scan kernel built at run time for this program (same source as the generic ScanKeyedKernel /
+            # ScanNoKeyKernel, the program's tables as constants) when one ran
+            "kernel": (("ssa_spec_keyed" if keyed else "ssa_spec_nokey") if spec_launches
+                       else ("ScanKeyedKernel" if keyed else "ScanNoKeyKernel")),
+            "avg_kernel_ms": 1e3 * avg_kernel_s, "launches": launches, "algorithmic_bytes_per_launch": int(per_launch)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6", "cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv",
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6", "mixed", "cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv",
                                                          "cb_userid", "cb_phrase", "cb_q20"])
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: TPC-H SF100 lineitem; ClickBench hits for cb_*)")
+    ap.add_argument("--rows", type=int, default=0,
+                    help="rows per GPU (default: TPC-H SF100 lineitem; SF1000 / 8 for mixed; ClickBench hits for cb_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="N = 1, workload q1: do not time Q6 and Q1-codes as well")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses cuda:0 and the exchange runs over gloo (checks the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -134,17 +189,18 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    rows = args.rows or tpch.SF100_ROWS
-    codes = args.workload == "q1_codes"
+    mixed = args.workload == "mixed"
     clickbench_run = args.workload.startswith("cb_")
+    also = ["q6", "q1_codes"] if (args.workload == "q1" and world == 1 and not args.no_also) else []
+    rows = args.rows or (SF1000_SHARD_ROWS if mixed else tpch.SF100_ROWS)
     resolver = tpch.LINEITEM_RESOLVER
-    table = "SF100-sized lineitem shard"
+    table = "SF1000 / 8 lineitem shard" if mixed else "SF100-sized lineitem shard"
+    stream = []  # (workload key, program, batch, bytes per row, name)
     if clickbench_run:
         from ydb_amd import clickbench
         rows = args.rows or clickbench.HITS_ROWS
         prog = clickbench.programs()[args.workload]
         cols, bpr = clickbench.COLUMNS[args.workload]
-        name = "ClickBench " + args.workload[3:]
         resolver = clickbench.HITS_RESOLVER
         table = "hits-sized shard"
         li = clickbench.DeviceHits(rows, device=local_rank, row0=rank * rows, columns=cols)
@@ -152,19 +208,15 @@ def main():
             bpr = 4 + li.phrase_bytes / rows
         if args.workload == "cb_q20":
             bpr = 4 + li.url_bytes / rows
-    elif args.workload == "q6":
-        prog, cols, bpr = tpch.q6_program(), tpch.Q6_COLUMNS, tpch.Q6_BYTES_PER_ROW
-        name = "TPC-H Q6"
+        stream.append((args.workload, prog, li.batch(cols), bpr, "ClickBench " + args.workload[3:]))
     else:
-        prog = tpch.q1_program(codes)
-        cols = tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8
-        bpr = tpch.Q1_BYTES_PER_ROW_CODES if codes else tpch.Q1_BYTES_PER_ROW_UTF8
-        name = "TPC-H Q1" + (" (1-byte flag codes)" if codes else " (utf8 flags)")
-    if not clickbench_run:
+        keys = ["q1", "q6"] if mixed else [args.workload]
         li = tpch.DeviceLineitem(rows, device=local_rank, row0=rank * rows,
-                                 utf8_flags=(args.workload == "q1"), code_flags=codes)
-    scan = ShardedScan(prog, resolver, device=local_rank)
-    batch = li.batch(cols)
+                                 utf8_flags=("q1" in keys), code_flags=("q1_codes" in keys + also))
+        for k in keys:
+            prog, cols, bpr, name = tpch_workload(k)
+            stream.append((k, prog, li.batch(cols), bpr, name))
+    scans = [ShardedScan(prog, resolver, device=local_rank) for _, prog, _, _, _ in stream]
     # a result of millions of groups stays in HBM on one GPU (its row count is read back)
     on_device = args.workload in ("cb_userid", "cb_phrase") and world == 1
 
@@ -174,46 +226,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    result = None
-    # The executor builds the step program's kernel at the first large scan and settles how it runs it (register-held
-    # groups on or off) on the second: with fewer than two warm-up steps asked for, those passes run here, untimed,
-    # like the generation of the table.
-    for _ in range(max(0, 2 - args.warmup)):
-        scan.run(batch, gather_device=gather_dev, keep_on_device=on_device)
-    for _ in range(args.warmup):
-        result = scan.run(batch, gather_device=gather_dev, keep_on_device=on_device)
-    scan.local.EnableProfile(True)
-    scan.local.ReadProfile()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = scan.run(batch, gather_device=gather_dev, keep_on_device=on_device)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches, algo_bytes = scan.local.ReadProfile()
-    built, build_ms, spec_launches = scan.local.SpecializationStats()
+    def timed(scans_, batches, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` timed ones; one step runs every program of the stream once."""
+        results = [None] * len(scans_)
+        # The executor builds the step program's kernel at the first large scan and settles how it runs it
+        # (register-held groups on or off) on the second: with fewer than two warm-up steps asked for, those passes run
+        # here, untimed, like the generation of the table.
+        for _ in range(max(0, 2 - warmup) + warmup):
+            for i, s in enumerate(scans_):
+                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device)
+        for s in scans_:
+            s.local.EnableProfile(True)
+            s.local.ReadProfile()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for i, s in enumerate(scans_):
+                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        profiles = [s.local.ReadProfile() for s in scans_]
+        for s in scans_:
+            s.local.EnableProfile(False)
+        return elapsed, profiles, results
+
+    elapsed, profiles, results = timed(scans, [b for _, _, b, _, _ in stream], args.steps, args.warmup)
+    built, build_ms, spec_launches = scans[0].local.SpecializationStats()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    also_out = {}
+    for k in also:  # the other half of the metric on the same resident table (N = 1 only)
+        prog, cols, bpr, name = tpch_workload(k)
+        s = ShardedScan(prog, resolver, device=local_rank)
+        e, prof, _ = timed([s], [li.batch(cols)], args.steps, args.warmup)
+        kernel_ms, launches, algo_bytes = prof[0]
+        also_out[k] = {"workload": f"{name}, the same {rows}-row resident table", "value": rows * args.steps / e, "unit": "rows/s",
+                       "ms_per_step": 1e3 * e / args.steps, "algorithmic_bytes_per_row": bpr,
+                       "roofline": roofline_of(k, prog, kernel_ms, launches, algo_bytes, s.local.SpecializationStats()[2])}
+        if not args.no_cpu_baseline:
+            also_out[k]["cpu_baseline"] = cpu_baseline(k, seconds_target=8.0, all_cores_seconds=4.0)
+
     if rank == 0:
-        # HBM traffic of the scan kernel: measured in a separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), kept as
-        # a ratio to the algorithmic bytes of the same launch; null when no such measurement is committed.
-        traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)) as f:
-                pmc = json.load(f).get(args.workload)
-            if pmc and "note" not in pmc and launches:
-                traffic = pmc["ratio_to_algorithmic"] * (algo_bytes / launches)
-        except OSError:
-            pass
-        from ydb_amd.shard import last_group_by
-        keyed = bool(last_group_by(prog).keys)
+        result = results[0]
         groups = result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0)
-        total_rows = rows * world * args.steps
-        avg_kernel_s = (kernel_ms / 1e3) / max(1, launches)
-        achieved = (algo_bytes / max(1, launches)) / avg_kernel_s / 1e9 if launches else 0.0
+        total_rows = rows * world * args.steps * len(stream)
+        wl_key, prog, _, bpr, name = stream[0]
+        kernel_ms, launches, algo_bytes = profiles[0]
+        names = " then ".join(n for _, _, _, _, n in stream)
         out = {
             "metric": "rows/sec scanned + % HBM roofline, TPC-H Q1/Q6 SF100 at 1/2/4/8 MI355X",
             "value": total_rows / elapsed,
@@ -227,24 +289,36 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{name}, {table} per GPU ({rows} rows), whole shard as one HBM-resident batch",
-                       "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr,
+            "config": {"workload": f"{names}, {table} per GPU ({rows} rows), whole shard as one HBM-resident batch" +
+                                   (" (one step = every program of the stream once; value counts the rows each program scanned)" if mixed else ""),
+                       "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr if not mixed else sum(b for _, _, _, b, _ in stream),
                        "groups": groups,
                        "kernels_built_at_run_time": built, "kernel_build_ms_before_the_timed_steps": build_ms,
+                       "float_sum_tolerance": "relative 1e-12 against the CPU oracle up to 1e5 rows, 1e-10 at millions of rows "
+                                              "(the reference's own sequential sum is off by n * 2^-53), checked in tests/",
                        "parallelism": f"row-range shards x{world}, partial aggregates merged by " +
-                                      ("hash-partitioned point-to-point exchange" if world > 1 and groups > ShardedScan.ALL_TO_ALL_GROUPS
+                                      ("hash-partitioned exchange" if world > 1 and groups > ShardedScan.ALL_TO_ALL_GROUPS
                                        else "RCCL all-gather") + " + merge program"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         # the scan kernel built at run time for this program (same source as the generic
-                         # ScanKeyedKernel / ScanNoKeyKernel, the program's tables as constants) when one ran
-                         "kernel": (("ssa_spec_keyed" if keyed else "ssa_spec_nokey") if spec_launches
-                                    else ("ScanKeyedKernel" if keyed else "ScanNoKeyKernel")),
-                         "avg_kernel_ms": 1e3 * avg_kernel_s, "launches": launches,
-                         "algorithmic_bytes_per_launch": algo_bytes // max(1, launches)},
+            # the dominant kernel: the first program of the stream (Q1's keyed scan)
+            "roofline": roofline_of(wl_key, prog, kernel_ms, launches, algo_bytes, spec_launches),
         }
+        if mixed:
+            out["programs"] = {}
+            for (k, p, _, b, n), (kms, nl, ab), s in zip(stream, profiles, scans):
+                out["programs"][k] = {"workload": n, "algorithmic_bytes_per_row": b,
+                                      "roofline": roofline_of(k, p, kms, nl, ab, s.local.SpecializationStats()[2])}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            if mixed:
+                parts = {k: cpu_baseline(k, seconds_target=8.0, all_cores_seconds=4.0) for k, _, _, _, _ in stream}
+                # the stream scans every row once per program: harmonic combination of the programs' rates
+                v = len(parts) / sum(1.0 / p["value"] for p in parts.values()) if all(p.get("value") for p in parts.values()) else None
+                out["cpu_baseline"] = {"value": v, "unit": "rows/s", "cores": 1, "kind": "port",
+                                       "sample": "per program: " + "; ".join(f"{k}: {p['sample']}" for k, p in parts.items()),
+                                       "programs": parts}
+            else:
+                out["cpu_baseline"] = cpu_baseline(args.workload)
+        if also_out:
+            out["also"] = also_out
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -110,3 +110,62 @@ def test_high_cardinality_group_by_at_scale():
     assert len(np.unique(keys)) == len(keys)
     total = _scan(Program().group_by([Aggregate(130, AGG.SUM, [tpch.L_QUANTITY])]), ["l_quantity"], li)["130"].values[0]
     assert abs(float(np.sum(out["121"].values)) - total) <= 1e-9 * total
+
+
+def test_mixed_q1_q6_stream_over_one_resident_shard():
+    """The stream of the sharded SF1000 configuration at 64 M rows: Q1 and Q6 alternate over one resident table, each
+    with its own program handle; every result of the stream equals the result of a single run in a fresh handle."""
+    from ydb_amd import tpch
+    from ydb_amd.program import ProgramContainer
+    li = tpch.DeviceLineitem(ROWS, utf8_flags=True, code_flags=False)
+    q1, q6 = tpch.q1_program(False), tpch.q6_program()
+    want1 = _scan(q1, tpch.Q1_COLUMNS_UTF8, li)
+    want6 = _scan(q6, tpch.Q6_COLUMNS, li)
+    pc1, pc6 = ProgramContainer(), ProgramContainer()
+    assert pc1.Init(tpch.LINEITEM_RESOLVER, q1)[0] and pc6.Init(tpch.LINEITEM_RESOLVER, q6)[0]
+    b1, b6 = li.batch(tpch.Q1_COLUMNS_UTF8), li.batch(tpch.Q6_COLUMNS)
+    for _ in range(4):
+        got1 = pc1.Export(pc1.ApplyDevice(b1))
+        got6 = pc6.Export(pc6.ApplyDevice(b6))
+        compare_batches(got1, want1, key_names=["l_returnflag", "l_linestatus"], float_sum_names=["130", "131", "132", "133", "136"], rtol=1e-12)
+        assert got6["130"].values[0] == want6["130"].values[0]   # key-less: fixed grid and reduction order
+
+
+@pytest.mark.parametrize("rows", [600_037_902, 750_000_000])
+def test_full_shard_sizes(rows):
+    """TPC-H SF100 (one GPU) and SF1000 / 8 (one GPU of eight) as one resident batch: the properties that need no host copy
+    of the data -- group counts add up to the key-less count of the filter, two half shards merge to the whole, Q6 is
+    the sum of its halves, the result is repeatable."""
+    from ydb_amd import shard, tpch
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
+    sums = ["130", "131", "132", "133", "136"]
+    keys = ["l_returnflag", "l_linestatus"]
+    q1, q6 = tpch.q1_program(False), tpch.q6_program()
+    li = tpch.DeviceLineitem(rows, utf8_flags=True, code_flags=False)
+    whole1 = _scan(q1, tpch.Q1_COLUMNS_UTF8, li)
+    again1 = _scan(q1, tpch.Q1_COLUMNS_UTF8, li)
+    compare_batches(again1, whole1, key_names=keys, float_sum_names=sums, rtol=1e-12)
+    whole6 = _scan(q6, tpch.Q6_COLUMNS, li)["130"].values[0]
+    assert _scan(q6, tpch.Q6_COLUMNS, li)["130"].values[0] == whole6
+    p = (Program().assign_const(100, "Int32", tpch.Q1_DATE).assign_func(110, F.CMP_LESS_EQUAL, [tpch.L_SHIPDATE, 100]).filter(110)
+         .group_by([Aggregate(120, AGG.COUNT, [])]))
+    passing = int(_scan(p, ["l_shipdate"], li)["120"].values[0])
+    assert int(np.sum(whole1["138"].values)) == passing and 0 < passing < rows
+    assert len(whole1["138"].values) == 4
+    del li
+    half = rows // 2
+    parts, q6_halves = [], []
+    for row0, n in ((0, half), (half, rows - half)):
+        h = tpch.DeviceLineitem(n, row0=row0, utf8_flags=True, code_flags=False)
+        parts.append(_scan(q1, tpch.Q1_COLUMNS_UTF8, h))
+        q6_halves.append(_scan(q6, tpch.Q6_COLUMNS, h)["130"].values[0])
+        del h
+    mp, mr = shard.merge_program(q1, tpch.LINEITEM_RESOLVER)
+    pc = ProgramContainer()
+    assert pc.Init(mr, mp)[0]
+    merged = pc.ApplyProgram(shard.partial_batch(parts, q1, tpch.LINEITEM_RESOLVER))
+    compare_batches(merged, whole1, key_names=keys, float_sum_names=sums, rtol=1e-12)
+    for name in ("134", "135", "137", "138"):   # counts are exact
+        assert sorted(int(v) for v in merged[name].values) == sorted(int(v) for v in whole1[name].values)
+    assert abs((q6_halves[0] + q6_halves[1]) - whole6) <= 1e-12 * abs(whole6)
