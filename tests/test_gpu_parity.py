@@ -620,3 +620,47 @@ def test_unsafe_float_to_integer_casts(jit, monkeypatch):
              F.CAST_TO_UINT64, F.CAST_TO_BOOLEAN]
     ops = [("f", c, [src]) for c in casts for src in (1, 2)]
     both_chunked([(1, "d"), (2, "f")], ops, {"d": d, "f": f})
+
+
+@pytest.mark.parametrize("length", [1, 2, 4, 8, 3])
+@pytest.mark.parametrize("typ", ["string", "binary"])
+def test_string_keys_of_one_length_take_the_fixed_width_path(length, typ):
+    # 70 000 rows and up: string keys whose probe (first, second, last offset) says "one length" are scanned as
+    # fixed-width values while every offset is checked; the result is the serialized-key result all the same
+    rng = np.random.default_rng(4400 + length)
+    n = 150_000
+    alphabet = [("%c" % (65 + i)) * length for i in range(5)]
+    s = [alphabet[i] for i in rng.integers(0, len(alphabet), n)]
+    if typ == "binary":
+        s = [x.encode() for x in s]
+    k = Col(rng.integers(0, 3, n).astype(np.int16), valid=rng.random(n) > 0.2)   # a nullable key next to it: raw slot values
+    v = Col(rng.integers(-100, 100, n).astype(np.int32), valid=rng.random(n) > 0.1)
+    f = rng.random(n)
+    keep = rng.random(n) < 0.7
+    p = (Program().filter(5)
+         .group_by([Aggregate(10, AGG.SUM, [3]), Aggregate(11, AGG.COUNT, []), Aggregate(12, AGG.MIN, [4]), Aggregate(13, AGG.SOME, [3]),
+                    Aggregate(14, AGG.COUNT, [3])], keys=[1, 2]))
+    res = [(1, "s"), (2, "k"), (3, "v"), (4, "f"), (5, "keep")]
+    got, exp = both(res, p, {"s": Col(s, type=typ), "k": k, "v": v, "f": f, "keep": keep})
+    compare_batches(got, exp, key_names=["s", "k"])
+    # one string key alone (a single one-byte string is NOT the lookup-table path of a one-byte integer key)
+    p = Program().group_by([Aggregate(10, AGG.SOME, [3]), Aggregate(11, AGG.COUNT, [3]), Aggregate(12, AGG.MAX, [4])], keys=[1])
+    got, exp = both(res, p, {"s": Col(s, type=typ), "k": k, "v": v, "f": f, "keep": keep})
+    compare_batches(got, exp, key_names=["s"])
+
+
+@pytest.mark.parametrize("where", [1, 77_777, 149_998])
+def test_string_keys_that_only_look_like_one_length(where):
+    # same first, second and last offsets as 150 000 one-byte strings, but two neighbours are "" and "AB": the scan
+    # finds the odd offset and the step is run again the general way
+    rng = np.random.default_rng(4500 + where)
+    n = 150_000
+    s = [("A", "N", "R")[i] for i in rng.integers(0, 3, n)]
+    s[where], s[where + 1] = "", "AB"
+    v = rng.integers(-100, 100, n).astype(np.int64)
+    p = Program().group_by([Aggregate(10, AGG.SUM, [2]), Aggregate(11, AGG.COUNT, [])], keys=[1])
+    for _ in range(2):  # the second run of the same handle does not try again
+        got, exp = both([(1, "s"), (2, "v")], p, {"s": s, "v": v})
+        compare_batches(got, exp, key_names=["s"])
+    assert sorted(x for x in exp["s"].to_pylist()) == sorted([b"", b"A", b"AB", b"N", b"R"]) or \
+        sorted(exp["s"].to_pylist()) == sorted(["", "A", "AB", "N", "R"])

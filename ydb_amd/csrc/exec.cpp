@@ -184,13 +184,18 @@ void Executor::ProfileEnd(const char* kernel, int64_t algoBytes) {
     Profile.LastKernel = kernel;
 }
 
-Status Executor::CheckScanStatus(bool* tableFull) {
+Status Executor::CheckScanStatus(bool* tableFull, bool* notUniform) {
     uint32_t st = 0;
     if (tableFull) *tableFull = false;
+    if (notUniform) *notUniform = false;
     SSA_HIP(hipMemcpyAsync(&st, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
     SSA_HIP(hipStreamSynchronize(StreamHandle));
     if (st == 0) return Status::OK();
     SSA_HIP(hipMemsetAsync(StatusWord->Ptr, 0, sizeof(st), StreamHandle));
+    if ((st & SCAN_NOT_UNIFORM) && notUniform) {  // the scan's results are void: the caller runs the step another way
+        *notUniform = true;
+        return Status::OK();
+    }
     if (st & SCAN_DIV_BY_ZERO) return Status::Invalid("divide by zero");
     if (st & SCAN_CAST_OVERFLOW) return Status::Invalid("Integer value not in range");
     if (st & SCAN_OVERFLOW) return Status::Invalid("overflow");
@@ -845,6 +850,10 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
         a.cols[c].val_bit_off = 0;
         a.cols[c].valid_bit_off = 0;
     }
+    for (int i = 0; i < kMaxOffsetChecks; ++i) {
+        a.checks[i].offsets = nullptr;
+        a.checks[i].first = 0;
+    }
     std::memcpy(image.data(), &a, sizeof(a));
     std::memcpy(reinterpret_cast<char*>(image.data()) + sizeof(ScanArgs), sinkImage, sinkBytes);
     SpecKernel k;
@@ -1367,6 +1376,122 @@ Status Executor::GatherRows(const Column& src, const BufferPtr& rowIdx, int64_t 
 // assigns and filters run fused with a two-level hash aggregation; the table is then turned into one
 // output row per group, aggregates first, keys after them.
 Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out) {
+    // String keys whose strings all have one length of 1, 2, 4 or 8 bytes (flags, codes, fixed-width identifiers) are
+    // scanned as fixed-width keys: the key column becomes the chars buffer read as `len`-byte values, the keys pack
+    // exactly and the kernel is the one of integer keys.  The scan still reads the offsets and checks every one of them
+    // (OffsetCheck); a batch that turns out otherwise is run again the general way.
+    KeyedHint& hint0 = KeyedHints[&step];
+    if (!hint0.UniformKeysFailed && in.Rows >= kUniformKeysMinRows && !(plan.NeedsFilteredPositions && plan.HasFilter) &&
+        !std::getenv("SSA_NO_UNIFORM_KEYS")) {
+        bool done = false;
+        SSA_RETURN_NOT_OK(RunKeyedUniform(step, plan, in, out, done));
+        if (done) return Status::OK();
+        hint0.UniformKeysFailed = true;
+    }
+    std::vector<OffsetCheck> none;
+    bool notUniform = false;
+    return RunKeyedScan(step, plan, in, out, none, &notUniform);
+}
+
+Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out, bool& done) {
+    done = false;
+    struct Rewrite {
+        size_t Key;
+        int Column;
+        uint32_t First, Len;
+        std::string Shadow;
+    };
+    std::vector<Rewrite> rewrites;
+    int keyBits = 0;
+    for (size_t k = 0; k < plan.Keys.size(); ++k) {
+        const KeyPlan& kp = plan.Keys[k];
+        if (kp.InputColumn < 0) return Status::OK();
+        if (!IsStringLike(kp.Spec.type)) {
+            keyBits += 8 * TypeWidth(kp.Spec.type);
+            continue;
+        }
+        rewrites.push_back(Rewrite{k, kp.InputColumn, 0, 0, std::string("\x01fixed:") + std::to_string(k)});
+    }
+    if (rewrites.empty() || rewrites.size() > size_t(kMaxOffsetChecks) || in.Cols.size() + rewrites.size() > 64) return Status::OK();
+    // first, second and last offset of every such column: the strings can only all have one length when
+    // offsets[rows] - offsets[0] == rows * (offsets[1] - offsets[0])
+    std::vector<int32_t> probe(rewrites.size() * 3, 0);
+    for (size_t i = 0; i < rewrites.size(); ++i) {
+        const Column& col = in.Cols[size_t(rewrites[i].Column)];
+        if (!col.Values || !col.Chars) return Status::OK();
+        const int32_t* offs = static_cast<const int32_t*>(col.ValuesPtr());
+        if (reinterpret_cast<uintptr_t>(offs) & 15) return Status::OK();
+        SSA_HIP(hipMemcpyAsync(&probe[3 * i], offs, 8, hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipMemcpyAsync(&probe[3 * i + 2], offs + in.Rows, 4, hipMemcpyDeviceToHost, StreamHandle));
+    }
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    for (size_t i = 0; i < rewrites.size(); ++i) {
+        const int64_t first = probe[3 * i], len = int64_t(probe[3 * i + 1]) - first, last = probe[3 * i + 2];
+        if (first < 0 || (len != 1 && len != 2 && len != 4 && len != 8) || last - first != len * in.Rows) return Status::OK();
+        const Column& col = in.Cols[size_t(rewrites[i].Column)];
+        if (size_t(last) > col.Chars->Size) return Status::OK();
+        rewrites[i].First = uint32_t(first);
+        rewrites[i].Len = uint32_t(len);
+        keyBits += int(8 * len);
+    }
+    if (keyBits > 119) return Status::OK();
+
+    // the batch with the chars buffers as extra fixed-width columns, the step with its keys renamed to them
+    Batch shadow = in;
+    TProgramStep fixedStep = step;
+    std::vector<OffsetCheck> checks;
+    for (const Rewrite& r : rewrites) {
+        const Column& src = in.Cols[size_t(r.Column)];
+        Column col;
+        col.Field.Name = r.Shadow;
+        col.Field.Type = r.Len == 1 ? T_U8 : r.Len == 2 ? T_U16 : r.Len == 4 ? T_U32 : T_U64;
+        col.Length = in.Rows;
+        col.Values = Buffer::Wrap(static_cast<char*>(src.Chars->Ptr) + r.First, size_t(in.Rows) * r.Len);
+        shadow.Cols.push_back(col);
+        const std::string original = step.GroupByKeys[r.Key].ColumnName;
+        fixedStep.GroupByKeys[r.Key].ColumnName = r.Shadow;
+        for (auto& p : fixedStep.Projection) {
+            if (p.ColumnName == original) p.ColumnName = r.Shadow;
+        }
+        checks.push_back(OffsetCheck{static_cast<const int32_t*>(src.ValuesPtr()), r.First, r.Len});
+    }
+    StepPlan fixedPlan;
+    if (!CompileStep(fixedStep, shadow.Schema(), CM_FULL, fixedPlan, /*serializedKeys=*/true).ok()) return Status::OK();
+    if (fixedPlan.Kind != StepPlan::AGG_KEYED) return Status::OK();
+    BatchPtr res;
+    bool notUniform = false;
+    SSA_RETURN_NOT_OK(RunKeyedScan(step, fixedPlan, shadow, res, checks, &notUniform));
+    if (notUniform) return Status::OK();
+    // the key columns back as strings: the emitted values are the chars, the offsets are multiples of the length
+    for (Column& col : res->Cols) {
+        for (const Rewrite& r : rewrites) {
+            if (col.Field.Name != r.Shadow) continue;
+            const Column& src = in.Cols[size_t(r.Column)];
+            const int64_t n = res->Rows;
+            Column str;
+            str.Field = src.Field;
+            str.Field.Nullable = false;
+            str.Length = n;
+            str.Values = Buffer::Alloc(size_t(n + 1) * 4 + 16);
+            if (!str.Values) return Status::Hip("out of device memory");
+            SSA_HIP(LaunchIotaI32(static_cast<int32_t*>(str.Values->Ptr), n + 1, int32_t(r.Len), StreamHandle));
+            str.Chars = col.Values;
+            if (!str.Chars) {
+                str.Chars = Buffer::Alloc(16);
+                if (!str.Chars) return Status::Hip("out of device memory");
+            }
+            col = str;
+        }
+    }
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    out = res;
+    done = true;
+    return Status::OK();
+}
+
+Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
+                              const std::vector<OffsetCheck>& checks, bool* notUniform) {
+    *notUniform = false;
     if (plan.NeedsFilteredPositions && plan.HasFilter) {
         // The result depends on where the rows stand in the filtered batch: filter first, as the reference does
         // (TProgramStep::ApplyFilters, program.cpp:798-832), then aggregate the compacted columns.
@@ -1394,7 +1519,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
                 compact.Cols[size_t(ci)].Field = in.Cols[size_t(ci)].Field;
             }
         }
-        return RunKeyed(step, rest, compact, out);
+        return RunKeyedScan(step, rest, compact, out, checks, notUniform);
     }
     const int naggsUser = int(plan.Aggs.size());
     const int nkeys = int(plan.Keys.size());
@@ -1498,6 +1623,11 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
         Status st = FillScanArgs(plan, in, sinkLds, hashed ? SCAN_KEYED_HASHED : SCAN_KEYED_EXACT, args, cfg, algoBytes);
         ScanRowsPerThread = kRowsPerThread;
         if (!st.ok()) return st;
+        args.nchecks = int32_t(checks.size());
+        for (size_t i = 0; i < checks.size(); ++i) {
+            args.checks[i] = checks[i];
+            algoBytes += (in.Rows + 1) * 4;  // the offsets are read (and checked), not staged
+        }
         sink = KeyedSink{};
         sink.use_hot = 1;
         sink.naggs = naggs;
@@ -1629,7 +1759,8 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
                          t[2] + t[6], t[6], t[3], t[4], t[5], t[7]);
         }
         bool tableFull = false;
-        SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull));
+        SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull, notUniform));
+        if (*notUniform) return Status::OK();
         if (timedRun && !tableFull) {  // (the stream has been synchronised by the status check)
             float ms = 0;
             if (hipEventElapsedTime(&ms, EvTuneA, EvTuneB) == hipSuccess && ms > 0) {

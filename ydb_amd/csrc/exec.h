@@ -145,6 +145,9 @@ private:
     Status ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
     Status RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out);
     Status RunKeyed(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out);
+    Status RunKeyedUniform(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out, bool& done);
+    Status RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
+                        const std::vector<OffsetCheck>& checks, bool* notUniform);
     Status RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& in, BatchPtr& out);
     Status RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,
                            int64_t& selected);
@@ -154,7 +157,7 @@ private:
     hipFunction_t SpecializedKernel(const char* header, const char* entry, const std::string& defines, const ScanArgs& args,
                                     const void* sinkImage, size_t sinkBytes, int64_t rows, LaunchCfg& cfg);
     hipError_t LaunchSpecialized(hipFunction_t fn, const ScanArgs& args, const void* sink, size_t sinkBytes, const LaunchCfg& cfg);
-    Status CheckScanStatus(bool* tableFull = nullptr);
+    Status CheckScanStatus(bool* tableFull = nullptr, bool* notUniform = nullptr);
     Status CompactColumn(const Column& src, int64_t rows, const BufferPtr& bitmap, const BufferPtr& tileOffsets,
                          int64_t selected, Column& dst);
     Status MaterializeScalar(const OutColumn& oc, int64_t rows, Column& dst);
@@ -163,6 +166,7 @@ private:
     void ProfileBegin();
     void ProfileEnd(const char* kernel, int64_t algoBytes);
 
+    static constexpr int64_t kUniformKeysMinRows = 65536;  // below, the probe's host round trip outweighs the gain
     int Device;
     int ScanRowsPerThread = kRowsPerThread;  // rows per thread of the kernel FillScanArgs / SpecializedKernel plan for
     hipStream_t StreamHandle = nullptr;
@@ -179,6 +183,7 @@ private:
         // work when they do not (a selective filter in front of thirty groups: 0.6x).  A kernel built for the step is
         // timed once each way on its first large scans and the faster way is kept.
         int HotChoice = -1;      // -1 undecided, 0 off, 1 on
+        bool UniformKeysFailed = false;  // a batch of this step had string keys of differing lengths: no further attempts
         double MsPerRowOn = 0, MsPerRowOff = 0;
     };
     std::map<const TProgramStep*, KeyedHint> KeyedHints;

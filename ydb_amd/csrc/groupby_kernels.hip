@@ -190,6 +190,10 @@ __global__ __launch_bounds__(kBlock) void CombineDecimalKernel(const uint64_t* l
     }
 }
 
+__global__ __launch_bounds__(kBlock) void IotaI32Kernel(int32_t* out, int64_t n, int32_t step) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) out[i] = int32_t(i) * step;
+}
+
 struct G128 {
     uint64_t lo, hi;
 };
@@ -279,6 +283,12 @@ hipError_t LaunchGatherFixed(const void* src, const uint8_t* srcValid, int64_t s
         default: return hipErrorInvalidValue;
     }
 #undef SSA_GATHER
+    return hipGetLastError();
+}
+
+hipError_t LaunchIotaI32(int32_t* out, int64_t n, int32_t step, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(IotaI32Kernel, dim3(GridFor(n)), dim3(kBlock), 0, st, out, n, step);
     return hipGetLastError();
 }
 

@@ -164,6 +164,8 @@ hipError_t LaunchGatherFixed(const void* src, const uint8_t* src_valid, int64_t 
 // Validity bits of the gathered rows as one byte per row (no bitmap: all valid).
 hipError_t LaunchGatherValidity(const uint8_t* src_valid, int64_t src_valid_off, const uint64_t* rows, int64_t n,
                                 uint8_t* dst_valid_bytes, hipStream_t st);
+// out[i] = i * step
+hipError_t LaunchIotaI32(int32_t* out, int64_t n, int32_t step, hipStream_t st);
 hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, int64_t n, int32_t* out_lens, hipStream_t st);
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);

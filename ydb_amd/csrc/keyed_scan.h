@@ -438,7 +438,10 @@ __device__ __forceinline__ void ScanKeyedBody() {
 #pragma unroll
         for (int k = 0; k < kHotAggs; ++k) hot[g][k] = 0;
     }
-    const bool useHot = L >= kHotGroups && s.use_hot != 0 && !(m.S().debug_flags & 8);
+    // (The generic kernel for hashed keys goes without them: it has no registers left, and a spilled lane table is not
+    // restored in the lanes that are inactive at the reload -- the v_readlane decode below would read stale values.)
+    constexpr bool kHotPossible = kStatic || !kHashed;
+    const bool useHot = kHotPossible && L >= kHotGroups && s.use_hot != 0 && !(m.S().debug_flags & 8);
     // keys of the register-held groups as this wave knows them (a free marker never equals a key)
     uint64_t hotLo[kHotGroups], hotHi[kHotGroups];
 #pragma unroll

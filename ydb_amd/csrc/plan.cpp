@@ -100,6 +100,7 @@ struct Compiler {
     std::vector<ExprPtr> ColExprs;                     // per input column (lazy)
     int NextTemp = 0;
     int NumOuts = 0;
+    bool SerializedKeys = false;
 
     Compiler(const TProgramStep& step, const std::vector<FieldDesc>& input, StepPlan& plan)
         : Step(step), Input(input), Plan(plan) {}
@@ -1102,9 +1103,9 @@ struct Compiler {
             // Aggregator::chooseAggregationMethod (ydb/library/arrow_clickhouse/Aggregator.cpp:132-226): null keys form
             // their own groups only in the nullable_keys{64,128,256} methods; the `serialized` fallback reads the raw
             // value under a null slot.
-            const bool nullAware = hasNullableKey && allFixed && (keyBytes <= 28);
+            const bool nullAware = hasNullableKey && allFixed && (keyBytes <= 28) && !SerializedKeys;
             // key8 lookup-table path does not look at argument validity (IAggregateFunction.h:258-296,384-459).
-            const bool key8Path = !hasNullableKey && keyExprs.size() == 1 && TypeWidth(keyExprs[0]->Type) == 1;
+            const bool key8Path = !hasNullableKey && keyExprs.size() == 1 && TypeWidth(keyExprs[0]->Type) == 1 && !SerializedKeys;
 
             std::vector<int> decimalSums, nanTagged, zeroTagged;
             for (size_t i = 0; i < Step.GroupBy.size(); ++i) {
@@ -1430,9 +1431,10 @@ std::string StepPlan::DebugString() const {
     return s + "]}";
 }
 
-Status CompileStep(const TProgramStep& step, const std::vector<FieldDesc>& input, ECompileMode mode, StepPlan& out) {
+Status CompileStep(const TProgramStep& step, const std::vector<FieldDesc>& input, ECompileMode mode, StepPlan& out, bool serializedKeys) {
     out = StepPlan();
     Compiler c(step, input, out);
+    c.SerializedKeys = serializedKeys;
     return c.Run(mode);
 }
 

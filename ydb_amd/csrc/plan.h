@@ -108,6 +108,9 @@ enum ECompileMode {
 };
 
 // Compile `step` against the input schema.
-Status CompileStep(const TProgramStep& step, const std::vector<FieldDesc>& input, ECompileMode mode, StepPlan& out);
+// `serializedKeys`: the GROUP BY takes the reference's `serialized` method whatever the key types are (the caller has
+// replaced string keys by fixed-width stand-ins): no null-aware keys, no single-byte-key lookup table.
+Status CompileStep(const TProgramStep& step, const std::vector<FieldDesc>& input, ECompileMode mode, StepPlan& out,
+                   bool serializedKeys = false);
 
 }  // namespace ssa

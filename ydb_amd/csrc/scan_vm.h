@@ -220,6 +220,7 @@ struct Machine {
     uint32_t boundsFirst, boundsLast;
     int64_t boundsTile;
     bool anyCharsStage;                      // some string column has a head area
+    uint32_t offsBad;                        // non-zero: an offset of a column scanned as fixed-width values is off (OffsetCheck)
     int ncols;
     int64_t nrows;
     int ncode;
@@ -256,6 +257,7 @@ struct Machine {
         SSA_UNROLL_STATIC
         for (int col = 0; col < S().ncols; ++col) anyCharsStage = anyCharsStage || S().lds_chars_off[col] >= 0;
         charsPending = false;
+        offsBad = 0;
         // The tables above come from memory.  Using them here makes the compiler wait for those loads now: left pending,
         // its wait lands before their first use inside the tile loop -- between the copies of a tile, which it would
         // serialise (the explicit waits of BeginTile are invisible to it).
@@ -354,7 +356,53 @@ struct Machine {
             }
         }
         if (haveBounds) StageStringHeads(slice0, true);
+        // Offsets of string columns scanned as fixed-width values: lane t takes offsets U * t .. U * t + U - 1 of the wave's
+        // slice straight into registers (16 bytes per load).  A kernel built for the program issues these loads together
+        // with the copies above; the generic kernels, which have no registers to spare (a spilled lane table is not
+        // restored in the lanes that are inactive at the reload), load and compare one column at a time afterwards.
+        const int64_t ckRow = slice0 + int64_t(U) * lane;
+        auto loadOffsets = [&](int i, uint32_t* v) {
+            const int32_t* offs = a.checks[i].offsets + ckRow;
+            if (full) {
+                if constexpr (U % 4 == 0) {
+#pragma unroll
+                    for (int j = 0; j < U; j += 4) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(offs + j, 16));
+                        v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < U; ++j) v[j] = uint32_t(offs[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) v[j] = ckRow + j < nrows ? uint32_t(offs[j]) : 0u;
+            }
+        };
+        auto compareOffsets = [&](int i, const uint32_t* v) {
+            const uint32_t first = a.checks[i].first, len = S().checks[i].len;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t want = first + len * uint32_t(ckRow + j);
+                offsBad |= (full || ckRow + j < nrows) ? (v[j] ^ want) : 0u;
+            }
+        };
+#ifdef SSA_SPEC
+        uint32_t ck[kMaxOffsetChecks][U];
+#pragma unroll
+        for (int i = 0; i < S().nchecks; ++i) loadOffsets(i, ck[i]);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SSA_SPEC
+#pragma unroll
+        for (int i = 0; i < S().nchecks; ++i) compareOffsets(i, ck[i]);
+#else
+        for (int i = 0; i < a.nchecks; ++i) {
+            uint32_t v[U];
+            loadOffsets(i, v);
+            compareOffsets(i, v);
+        }
+#endif
         asm volatile("" ::"v"(nextFirst), "v"(nextLast));  // (the compiler's own wait for these two loads belongs here too)
         if (haveBounds) charsPending = false;  // the head copies were part of that wait
         if (anyCharsStage && !haveBounds) StageStringHeads(slice0, false);
@@ -1179,6 +1227,7 @@ struct Machine {
     }
 
     __device__ __forceinline__ void ReportErrors() {
+        if (offsBad != 0) err |= SCAN_NOT_UNIFORM;
         if (err != 0 && a.status != nullptr) atomicOr(a.status, err);
     }
 };

@@ -194,6 +194,7 @@ constexpr int kMaxAggs = 16;
 constexpr int kMaxKeys = 6;
 constexpr int kMaxOuts = 12;
 constexpr int kMaxPatternBytes = 256;  // all string constants of one program, concatenated
+constexpr int kMaxOffsetChecks = 4;     // string columns scanned as fixed-width values (see OffsetCheck)
 
 // Error bits a scan kernel can raise (OR-ed into ScanArgs::status).
 enum ScanStatus : uint32_t {
@@ -203,6 +204,7 @@ enum ScanStatus : uint32_t {
     SCAN_TABLE_FULL = 4,       // group-by spill table ran out of slots (host retries with a bigger one)
     SCAN_OVERFLOW = 8,         // checked integer arithmetic -> Status::Invalid("overflow")
     SCAN_NAN_ORDER = 16,       // a NaN reached a float MIN / MAX whose result would depend on the reference's visiting order
+    SCAN_NOT_UNIFORM = 32,     // a string column scanned as fixed-width values has strings of another length (host re-runs the step)
 };
 
 // OP_ROWIDX variants.  The reference's aggregator visits the rows of a batch grouped by ONE single-byte key in four
@@ -304,6 +306,15 @@ enum SinkKind : int32_t {
     SINK_AGG_KEYED = 3,   // LDS-staged hash aggregation with a global spill table
 };
 
+// A string column whose strings all have `len` bytes is scanned as a column of `len`-byte values (its chars buffer);
+// the scan still reads the column's offsets and checks offsets[row] == first + len * row for every row, raising
+// SCAN_NOT_UNIFORM otherwise.  (offsets[nrows] is checked by the host.)
+struct OffsetCheck {
+    const int32_t* offsets;  // 16-byte aligned
+    uint32_t first;          // offsets[0]
+    uint32_t len;
+};
+
 struct ScanArgs {
     int64_t nrows;
     int32_t ncols;
@@ -324,6 +335,8 @@ struct ScanArgs {
     int32_t lds_sink_off;           // first byte available to the sink (group-by table)
     int32_t lds_end_off[kMaxCols];  // staged string column c: one kEndSlotBytes slot per wave (end offset of the wave's last row; match words), or -1
     int32_t debug_flags;            // diagnostics only: 1 = skip staging, 2 = skip evaluation (timing experiments)
+    int32_t nchecks;
+    OffsetCheck checks[kMaxOffsetChecks];
 };
 
 }  // namespace ssa
