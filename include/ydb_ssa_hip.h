@@ -110,6 +110,28 @@ int ssa_program_build_filter(ssa_program_t* program, size_t step_index, const st
 int ssa_batch_import(ssa_program_t* program, const struct ArrowArray* in, const struct ArrowSchema* in_schema,
                      ssa_batch_t** out, char** err);
 
+/*
+ * Column blobs as stored.  Replaces NArrow::NSerialization::TNativeSerializer::DoDeserialize
+ * (ydb/core/formats/arrow/serializer/native.cpp:18-40 for a whole IPC stream written by DoSerializeFull, :60-81 for the
+ * lone RecordBatch message written by DoSerializePayload and read back with the chunk's schema): the blob crosses PCIe
+ * compressed and its buffers are decoded on the GPU into the columns of a resident batch.  `schema` (a struct
+ * ArrowSchema, may be NULL for a whole stream) is the schema of the chunk; a stream's own schema must agree with it in
+ * column count and types.  Body compression: none and LZ4_FRAME (the reference's default, serializer/native.h:54-57);
+ * a ZSTD body, dictionary-encoded and nested columns are SSA_UNSUPPORTED (the shim keeps the CPU deserializer for
+ * those).  Damaged metadata, buffers that do not decode to their announced length and string offsets that run past
+ * the data are SSA_INVALID (the reference returns SerializationError).  ssa_batches_from_blobs decodes `nblobs` blobs
+ * of one schema with one kernel launch for all their buffers (one wavefront per compressed buffer) and fills out[0 ..
+ * nblobs) -- the portions of a scan; on failure no batch is returned.
+ */
+int ssa_batch_from_blob(ssa_program_t* program, const uint8_t* blob, size_t size, const struct ArrowSchema* schema,
+                        ssa_batch_t** out, char** err);
+/* Host only (needs no GPU): the metadata of a blob as text -- rows, codec, per column its type id, null count, the
+ * stored lengths of its buffers and, for LZ4 frames, the announced length and block count -- or NULL and *err.  The
+ * checks are those ssa_batch_from_blob makes before it touches the device. */
+char* ssa_blob_describe(const uint8_t* blob, size_t size, const struct ArrowSchema* schema, char** err);
+int ssa_batches_from_blobs(ssa_program_t* program, const uint8_t* const* blobs, const size_t* sizes, size_t nblobs,
+                           const struct ArrowSchema* schema, ssa_batch_t** out, char** err);
+
 /* Column already in device memory (not copied, not owned; must outlive the batch).  The library reads it on its own
  * HIP stream: whatever produced the column (a copy, a kernel on another stream) must have completed before the batch is
  * used. */

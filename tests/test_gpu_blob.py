@@ -1,0 +1,124 @@
+"""Column blobs decoded on the GPU (ssa_batch_from_blob / ssa_batches_from_blobs) against the columns Arrow wrote them
+from (tests/golden/ipc) and against the CPU oracle reading the same blob; then a program over the decoded batch."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from test_host_blob import CASES, IPC, schema_batch
+from test_oracle_ipc import SCHEMA, check_columns
+
+pytestmark = pytest.mark.gpu
+
+
+def container():
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import Program
+    pc = ProgramContainer()
+    ok, err = pc.Init([(i + 1, n) for i, (n, _) in enumerate(SCHEMA)], Program().project([1]))
+    assert ok, err
+    return pc
+
+
+def as_columns(exported):
+    """Export() result -> the shape check_columns takes."""
+    out = {}
+    for name, c in exported.items():
+        col = {"type": c.type, "valid": np.asarray(c.valid, dtype=np.bool_)}
+        if c.type in ("string", "binary"):
+            vals = [bytes(v) if v is not None else b"" for v in c.values]
+            col["offsets"] = np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.int32)
+            col["chars"] = b"".join(vals)
+        elif c.type == "decimal128":
+            col["values"] = np.asarray(c.values, dtype=np.uint64).reshape(-1)
+        elif c.type == "bool":
+            col["values"] = np.asarray(c.values).astype(np.uint8)
+        else:
+            col["values"] = np.asarray(c.values)
+        out[name] = col
+    return out
+
+
+@pytest.mark.parametrize("case", [c for c in CASES["cases"] if c["codec"] != "zstd"], ids=lambda c: c["name"])
+def test_blob_decodes_to_the_columns_arrow_wrote(case):
+    from oracle import ipc_oracle
+    pc = container()
+    blob = open(os.path.join(IPC, case["name"] + ".bin"), "rb").read()
+    payload = case["form"] == "payload"
+    dev = pc.ImportBlob(blob, schema_batch() if payload else None)
+    assert dev.rows == case["rows"]
+    got = as_columns(pc.Export(dev))
+    check_columns(got, np.load(os.path.join(IPC, case["expected"] + ".npz")), case["rows"])
+    # and byte for byte what the oracle reads, null slots included
+    exp = ipc_oracle.read_blob(blob, SCHEMA if payload else None)
+    for name, typ in SCHEMA:
+        if typ in ("string", "binary"):
+            assert got[name]["chars"] == exp[name]["chars"][exp[name]["offsets"][0]:exp[name]["offsets"][-1]] or case["rows"] == 0
+        else:
+            valid = exp[name]["valid"]
+            g, e = np.asarray(got[name]["values"]), np.asarray(exp[name]["values"])
+            if typ == "decimal128":
+                g, e, valid = g.reshape(-1, 2), e.reshape(-1, 2), valid
+            assert np.array_equal(g[valid], e[valid]), name
+
+
+def test_many_blobs_in_one_call():
+    pc = container()
+    names = [c["name"] for c in CASES["cases"] if c["codec"] == "lz4" and c["form"] == "stream"] * 3
+    blobs = [open(os.path.join(IPC, n + ".bin"), "rb").read() for n in names]
+    devs = pc.ImportBlobs(blobs)
+    assert len(devs) == len(blobs)
+    by_name = {c["name"]: c for c in CASES["cases"]}
+    for n, d in zip(names, devs):
+        check_columns(as_columns(pc.Export(d)), np.load(os.path.join(IPC, by_name[n]["expected"] + ".npz")), by_name[n]["rows"])
+
+
+def test_zstd_is_declined_and_damage_is_an_error():
+    from ydb_amd import _lib
+    from ydb_amd.program import SsaError
+    pc = container()
+    with pytest.raises(SsaError) as e:
+        pc.ImportBlob(open(os.path.join(IPC, "small_zstd_stream.bin"), "rb").read())
+    assert e.value.code == _lib.SSA_UNSUPPORTED and "ZSTD" in str(e.value)
+    blob = bytearray(open(os.path.join(IPC, "blocks_lz4_stream.bin"), "rb").read())
+    rng = np.random.default_rng(9)
+    outcomes = {"ok": 0, "invalid": 0}
+    for _ in range(40):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 30))):
+            b[rng.integers(2000, len(b))] = rng.integers(0, 256)   # somewhere in the compressed body
+        try:
+            pc.Export(pc.ImportBlob(bytes(b)))
+            outcomes["ok"] += 1     # (a flipped literal byte decodes fine, to other data)
+        except SsaError as err:
+            assert err.code in (_lib.SSA_INVALID, _lib.SSA_UNSUPPORTED), err
+            outcomes["invalid"] += 1
+    assert outcomes["invalid"] > 0
+    # the handle still works
+    good = pc.ImportBlob(bytes(blob))
+    assert good.rows == 30000
+
+
+def test_program_over_a_decoded_blob():
+    from cases import compare_batches
+    from oracle import ssa_oracle
+    from ydb_amd.arrow_c import Col
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
+    exp_cols = np.load(os.path.join(IPC, "blocks.npz"))
+    resolver = [(i + 1, n) for i, (n, _) in enumerate(SCHEMA)]
+    ids = {n: i for i, n in resolver}
+    p = (Program().assign_const(100, "Int64", 25).assign_func(101, F.CMP_LESS, [ids["i64"], 100]).filter(101)
+         .group_by([Aggregate(110, AGG.SUM, [ids["f64"]]), Aggregate(111, AGG.COUNT, [ids["i32n"]]), Aggregate(112, AGG.MAX, [ids["u16"]])],
+                   keys=[ids["u8"], ids["s"]]))
+    pc = ProgramContainer()
+    assert pc.Init(resolver, p)[0]
+    dev = pc.ImportBlob(open(os.path.join(IPC, "blocks_lz4_stream.bin"), "rb").read())
+    got = pc.Export(pc.ApplyDevice(dev))
+    so, sc = exp_cols["s.offsets"], exp_cols["s.chars"].tobytes()
+    host = {"i64": exp_cols["i64.values"], "f64": exp_cols["f64.values"], "u16": exp_cols["u16.values"], "u8": exp_cols["u8.values"],
+            "i32n": Col(exp_cols["i32n.values"], valid=exp_cols["i32n.valid"]),
+            "s": Col([sc[so[i]:so[i + 1]].decode() for i in range(len(so) - 1)], type="string")}
+    exp = ssa_oracle.Oracle(resolver, p).apply(host)
+    compare_batches(got, exp, key_names=["u8", "s"], float_sum_names=["110"])

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = [
     "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
     "ssa_filter_combine_sequential_and", "ssa_filter_info", "ssa_filter_runs", "ssa_filter_bits", "ssa_filter_filtered_count",
     "ssa_filter_apply", "ssa_filter_destroy", "ssa_filter_from_program_noalloc",
+    "ssa_batch_from_blob", "ssa_batches_from_blobs", "ssa_blob_describe",
 ]
 
 _lib = None
@@ -117,6 +118,12 @@ def load() -> ctypes.CDLL:
     lib.ssa_filter_from_runs.restype = i32
     lib.ssa_filter_from_program.argtypes = [vp, sz, vp, P(vp), P(vp)]
     lib.ssa_filter_from_program.restype = i32
+    lib.ssa_batch_from_blob.argtypes = [vp, vp, sz, vp, P(vp), P(vp)]
+    lib.ssa_batch_from_blob.restype = i32
+    lib.ssa_blob_describe.argtypes = [vp, sz, vp, P(vp)]
+    lib.ssa_blob_describe.restype = vp
+    lib.ssa_batches_from_blobs.argtypes = [vp, vp, vp, sz, vp, vp, P(vp)]
+    lib.ssa_batches_from_blobs.restype = i32
     lib.ssa_filter_from_program_noalloc.argtypes = [vp, sz, vp, vp, P(i64), P(vp)]
     lib.ssa_filter_from_program_noalloc.restype = i32
     lib.ssa_filter_predicate.argtypes = [vp, vp, P(ArrowArray), P(ArrowSchema), i32, P(vp), P(vp)]

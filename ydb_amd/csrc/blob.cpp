@@ -1,0 +1,210 @@
+// Column blobs -> HBM-resident record batches.
+//
+// The GPU counterpart of NArrow::NSerialization::TNativeSerializer::DoDeserialize
+// (ydb/core/formats/arrow/serializer/native.cpp:18-81): the blob crosses PCIe as stored (compressed), its buffers are
+// decoded on the device straight into the column buffers of an ssa_batch_t.  Codecs: none and LZ4_FRAME (the
+// reference's default, native.h:54-57); ZSTD is declined with SSA_UNSUPPORTED.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "exec.h"
+#include "ipc.h"
+
+namespace ssa {
+
+#define SSA_HIP(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (void)hipGetLastError();                                                                   \
+            return Status::Hip(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+        }                                                                                              \
+    } while (0)
+
+#define SSA_RETURN_NOT_OK(expr)     \
+    do {                            \
+        Status s_ = (expr);         \
+        if (!s_.ok()) return s_;    \
+    } while (0)
+
+namespace {
+
+struct PendingBuffer {
+    size_t Blob;       // which blob
+    IpcBuffer Where;   // inside that blob's body
+    size_t MinBytes;   // bytes the column needs from it (0: whatever it holds)
+    BufferPtr* Target; // receives the decoded buffer
+    int64_t* Bytes;    // receives its length (may be null)
+};
+
+}  // namespace
+
+Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<FieldDesc>& schema,
+                             std::vector<BatchPtr>& out) {
+    (void)hipSetDevice(Device);
+    out.clear();
+    const size_t nb = blobs.size();
+    std::vector<IpcBatch> parsed(nb);
+    std::vector<size_t> base(nb, 0);   // offset of each blob in the device copy
+    size_t total = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        if (!blobs[i].first && blobs[i].second) return Status::Invalid("null blob");
+        SSA_RETURN_NOT_OK(ParseIpcBlob(blobs[i].first, blobs[i].second, schema, parsed[i]));
+        if (parsed[i].Codec == IPC_ZSTD) return Status::Unsupported("ZSTD body compression of an IPC blob (LZ4_FRAME and uncompressed bodies are decoded)");
+        base[i] = total;
+        total += (blobs[i].second + 255) & ~size_t(255);
+    }
+    // the blobs as stored, one copy each over PCIe
+    BufferPtr dblob = Buffer::Alloc(total + 256);
+    if (!dblob) return Status::Hip("out of device memory");
+    for (size_t i = 0; i < nb; ++i) {
+        if (blobs[i].second) {
+            SSA_HIP(hipMemcpyAsync(static_cast<char*>(dblob->Ptr) + base[i], blobs[i].first, blobs[i].second, hipMemcpyHostToDevice, StreamHandle));
+        }
+    }
+
+    std::vector<BatchPtr> batches(nb);
+    std::vector<PendingBuffer> pending;
+    std::vector<int64_t> dataBytes;  // per string column: bytes of its data buffer
+    size_t nstrings = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        for (auto& c : parsed[i].Columns) nstrings += IsStringLike(c.Field.Type);
+    }
+    dataBytes.assign(nstrings, 0);
+    size_t stringIdx = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        auto b = std::make_shared<Batch>();
+        b->Rows = parsed[i].Rows;
+        b->Cols.resize(parsed[i].Columns.size());
+        for (size_t c = 0; c < parsed[i].Columns.size(); ++c) {
+            const IpcColumn& ic = parsed[i].Columns[c];
+            Column& col = b->Cols[c];
+            col.Field = ic.Field;
+            col.Field.Nullable = false;
+            col.Length = ic.Length;
+            col.NullCount = ic.NullCount;
+            const size_t rows = size_t(ic.Length);
+            if (ic.NullCount > 0) {
+                if (ic.Validity.Length == 0) return Status::Invalid("column '" + ic.Field.Name + "' counts nulls but has no validity buffer");
+                pending.push_back({i, ic.Validity, (rows + 7) / 8, &col.Validity, nullptr});
+                col.Field.Nullable = true;
+            }
+            size_t need;
+            if (IsStringLike(ic.Field.Type)) need = (rows + 1) * 4;
+            else if (ic.Field.Type == T_BOOL) need = (rows + 7) / 8;
+            else need = rows * size_t(TypeWidth(ic.Field.Type));
+            if (rows == 0 && IsStringLike(ic.Field.Type) && ic.Values.Length == 0) {
+                col.Values = Buffer::Alloc(16);  // a single zero offset
+                if (!col.Values) return Status::Hip("out of device memory");
+                SSA_HIP(hipMemsetAsync(col.Values->Ptr, 0, 16, StreamHandle));
+            } else {
+                pending.push_back({i, ic.Values, need, &col.Values, nullptr});
+            }
+            if (IsStringLike(ic.Field.Type)) {
+                pending.push_back({i, ic.Data, 0, &col.Chars, &dataBytes[stringIdx]});
+                ++stringIdx;
+            }
+        }
+        batches[i] = b;
+    }
+
+    // every buffer: a plain copy, or an LZ4 frame for the decode kernel
+    std::vector<Lz4FrameTask> tasks;
+    std::vector<Lz4BlockRef> blocks;
+    uint32_t maxBlock = 0;
+    for (PendingBuffer& pb : pending) {
+        const IpcBatch& ib = parsed[pb.Blob];
+        const uint8_t* host = blobs[pb.Blob].first;
+        const size_t bufPos = ib.BodyOffset + size_t(pb.Where.Offset);  // inside the blob
+        int64_t rawLen = pb.Where.Length;     // bytes to copy as they are
+        size_t rawPos = bufPos;
+        int64_t outLen = rawLen;
+        bool frame = false;
+        if (ib.Codec == IPC_LZ4_FRAME && pb.Where.Length > 0) {
+            if (pb.Where.Length < 8) return Status::Invalid("compressed buffer without its length prefix");
+            int64_t ulen;
+            std::memcpy(&ulen, host + bufPos, 8);
+            if (ulen == -1) {  // stored as is
+                rawPos = bufPos + 8;
+                rawLen = pb.Where.Length - 8;
+                outLen = rawLen;
+            } else {
+                if (ulen < 0 || ulen > (int64_t(1) << 40)) return Status::Invalid("compressed buffer announces an impossible length");
+                frame = true;
+                outLen = ulen;
+            }
+        }
+        if (size_t(outLen) < pb.MinBytes) return Status::Invalid("a buffer of the blob is shorter than its column needs");
+        BufferPtr dst = Buffer::Alloc(size_t(outLen) + 32);  // (strings are read in 16-byte pieces: padding behind the bytes)
+        if (!dst) return Status::Hip("out of device memory");
+        *pb.Target = dst;
+        if (pb.Bytes) *pb.Bytes = outLen;
+        if (outLen == 0) continue;
+        if (!frame) {
+            SSA_HIP(hipMemcpyAsync(dst->Ptr, static_cast<const char*>(dblob->Ptr) + base[pb.Blob] + rawPos, size_t(rawLen), hipMemcpyDeviceToDevice,
+                                   StreamHandle));
+            continue;
+        }
+        std::vector<Lz4BlockRef> frameBlocks;
+        uint32_t blockMax = 0;
+        bool linked = true;
+        SSA_RETURN_NOT_OK(ParseLz4Frame(host, blobs[pb.Blob].second, bufPos + 8, size_t(pb.Where.Length - 8), frameBlocks, blockMax, linked));
+        Lz4FrameTask t{};
+        t.first_block = blocks.size();
+        t.nblocks = uint32_t(frameBlocks.size());
+        t.linked = linked ? 1u : 0u;
+        t.dst = static_cast<uint8_t*>(dst->Ptr);
+        t.dst_bytes = uint64_t(outLen);
+        for (Lz4BlockRef& r : frameBlocks) {
+            r.Src += base[pb.Blob];
+            if (!r.Stored) maxBlock = std::max(maxBlock, r.SrcBytes);
+            blocks.push_back(r);
+        }
+        tasks.push_back(t);
+    }
+    if (maxBlock > 90u * 1024u) return Status::Unsupported("LZ4 frame with blocks of more than 64 KB");
+    if (!tasks.empty()) {
+        BufferPtr dtasks = Buffer::Alloc(tasks.size() * sizeof(Lz4FrameTask));
+        BufferPtr dblocks = Buffer::Alloc(std::max<size_t>(1, blocks.size()) * sizeof(Lz4BlockRef));
+        if (!dtasks || !dblocks) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemcpyAsync(dtasks->Ptr, tasks.data(), tasks.size() * sizeof(Lz4FrameTask), hipMemcpyHostToDevice, StreamHandle));
+        if (!blocks.empty()) {
+            SSA_HIP(hipMemcpyAsync(dblocks->Ptr, blocks.data(), blocks.size() * sizeof(Lz4BlockRef), hipMemcpyHostToDevice, StreamHandle));
+        }
+        ProfileBegin();
+        SSA_HIP(LaunchLz4Decode(static_cast<const uint8_t*>(dblob->Ptr), static_cast<const Lz4FrameTask*>(dtasks->Ptr), int64_t(tasks.size()),
+                                static_cast<const Lz4BlockRef*>(dblocks->Ptr), maxBlock, static_cast<uint32_t*>(StatusWord->Ptr), StreamHandle));
+        int64_t produced = 0;
+        for (auto& t : tasks) produced += int64_t(t.dst_bytes);
+        ProfileEnd("Lz4DecodeKernel", produced);
+        // (the host vectors above are read by the copies: wait before they go out of scope)
+        uint32_t st = 0;
+        SSA_HIP(hipMemcpyAsync(&st, StatusWord->Ptr, 4, hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        if (st != 0) {
+            SSA_HIP(hipMemsetAsync(StatusWord->Ptr, 0, 4, StreamHandle));
+            return Status::Invalid("corrupt LZ4 data in an IPC blob");
+        }
+    } else {
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+    }
+    // RecordBatch::Validate of the reference: offsets of a string column must describe its data buffer
+    stringIdx = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        for (Column& col : batches[i]->Cols) {
+            if (!IsStringLike(col.Field.Type)) continue;
+            const int64_t bytes = dataBytes[stringIdx++];
+            if (col.Length == 0) continue;
+            int32_t ends[2] = {0, 0};
+            SSA_HIP(hipMemcpyAsync(&ends[0], col.Values->Ptr, 4, hipMemcpyDeviceToHost, StreamHandle));
+            SSA_HIP(hipMemcpyAsync(&ends[1], static_cast<const int32_t*>(col.Values->Ptr) + col.Length, 4, hipMemcpyDeviceToHost, StreamHandle));
+            SSA_HIP(hipStreamSynchronize(StreamHandle));
+            if (ends[0] < 0 || ends[1] < ends[0] || int64_t(ends[1]) > bytes) return Status::Invalid("validation error: string offsets run past the data buffer");
+        }
+    }
+    out = batches;
+    return Status::OK();
+}
+
+}  // namespace ssa

@@ -9,6 +9,7 @@
 
 #include "../../include/ydb_ssa_hip.h"
 #include "exec.h"
+#include "ipc.h"
 #include "jit.h"
 #include "program.h"
 #include "vm_ops.h"
@@ -264,6 +265,77 @@ int ssa_batch_import(ssa_program_t* program, const ArrowArray* in, const ArrowSc
     if (!st.ok()) return Fail(st, err);
     *out = new ssa_batch{batch};
     return SSA_OK;
+}
+
+int ssa_batches_from_blobs(ssa_program_t* program, const uint8_t* const* blobs, const size_t* sizes, size_t nblobs,
+                           const ArrowSchema* schema, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    if (!program || (nblobs && (!blobs || !sizes || !out))) return Fail(Status::Invalid("null argument"), err);
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    std::vector<FieldDesc> fields;
+    if (schema) {
+        Status st = SchemaFields(schema, fields);
+        if (!st.ok()) return Fail(st, err);
+    }
+    std::vector<std::pair<const uint8_t*, size_t>> list;
+    for (size_t i = 0; i < nblobs; ++i) list.emplace_back(blobs[i], sizes[i]);
+    std::vector<BatchPtr> batches;
+    Status st = program->Exec->ImportBlobs(list, fields, batches);
+    if (!st.ok()) return Fail(st, err);
+    for (size_t i = 0; i < nblobs; ++i) out[i] = new ssa_batch{batches[i]};
+    return SSA_OK;
+}
+
+char* ssa_blob_describe(const uint8_t* blob, size_t size, const ArrowSchema* schema, char** err) {
+    if (err) *err = nullptr;
+    std::vector<FieldDesc> fields;
+    if (schema) {
+        Status st = SchemaFields(schema, fields);
+        if (!st.ok()) {
+            Fail(st, err);
+            return nullptr;
+        }
+    }
+    IpcBatch b;
+    Status st = ParseIpcBlob(blob, size, fields, b);
+    if (!st.ok()) {
+        Fail(st, err);
+        return nullptr;
+    }
+    std::string text = "rows=" + std::to_string(b.Rows) + " codec=" + (b.Codec == IPC_RAW ? "none" : b.Codec == IPC_LZ4_FRAME ? "lz4_frame" : "zstd") +
+                       " body=" + std::to_string(b.BodyLength) + "\n";
+    for (const IpcColumn& c : b.Columns) {
+        text += c.Field.Name + ":" + std::to_string(c.Field.Type) + " nulls=" + std::to_string(c.NullCount) + " buffers=" +
+                std::to_string(c.Validity.Length) + "," + std::to_string(c.Values.Length) + "," + std::to_string(c.Data.Length);
+        if (b.Codec == IPC_LZ4_FRAME) {
+            for (const IpcBuffer* buf : {&c.Validity, &c.Values, &c.Data}) {
+                if (buf->Length <= 8) continue;
+                int64_t ulen;
+                std::memcpy(&ulen, blob + b.BodyOffset + buf->Offset, 8);
+                if (ulen < 0) continue;
+                std::vector<Lz4BlockRef> blocks;
+                uint32_t blockMax = 0;
+                bool linked = false;
+                st = ParseLz4Frame(blob, size, b.BodyOffset + size_t(buf->Offset) + 8, size_t(buf->Length - 8), blocks, blockMax, linked);
+                if (!st.ok()) {
+                    Fail(st, err);
+                    return nullptr;
+                }
+                text += " frame(" + std::to_string(ulen) + " bytes, " + std::to_string(blocks.size()) + " blocks of " + std::to_string(blockMax) +
+                        (linked ? ", linked)" : ", independent)");
+            }
+        }
+        text += "\n";
+    }
+    return DupString(text);
+}
+
+int ssa_batch_from_blob(ssa_program_t* program, const uint8_t* blob, size_t size, const ArrowSchema* schema, ssa_batch_t** out, char** err) {
+    return ssa_batches_from_blobs(program, &blob, &size, 1, schema, out, err);
 }
 
 int ssa_batch_from_device(const ssa_device_column* cols, size_t ncols, int64_t rows, ssa_batch_t** out, char** err) {

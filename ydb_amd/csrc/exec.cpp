@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <climits>
 #include <cstdio>
@@ -61,13 +62,24 @@ void* DevPool::Alloc(size_t bytes, int* device) {
             void* p = it->second.back();
             it->second.pop_back();
             InUse += b;
+            Cached -= b;
             return p;
         }
     }
+    // (SSA_TEST_FAIL_ALLOC=n, tests only: the n-th hipMalloc of the process fails once, as if the device were full)
+    static std::atomic<long> mallocs{0};
+    auto tryMalloc = [&](void** out) {
+        const long nth = ++mallocs;
+        const char* fail = std::getenv("SSA_TEST_FAIL_ALLOC");
+        hipError_t e = (fail && std::atol(fail) == nth) ? hipErrorOutOfMemory : hipMalloc(out, b);
+        // a failed call leaves its error pending in the runtime: the next launch on this thread would report it
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e;
+    };
     void* p = nullptr;
-    if (hipMalloc(&p, b) != hipSuccess) {
+    if (tryMalloc(&p) != hipSuccess) {
         Trim();
-        if (hipMalloc(&p, b) != hipSuccess) return nullptr;
+        if (tryMalloc(&p) != hipSuccess) return nullptr;
     }
     std::lock_guard<std::mutex> g(Lock);
     InUse += b;
@@ -77,17 +89,26 @@ void* DevPool::Alloc(size_t bytes, int* device) {
 void DevPool::Free(void* p, size_t bytes, int device) {
     if (!p) return;
     const size_t b = BucketSize(bytes ? bytes : 1);
-    std::lock_guard<std::mutex> g(Lock);
-    InUse -= b;
-    FreeLists[{device, b}].push_back(p);
+    {
+        std::lock_guard<std::mutex> g(Lock);
+        InUse -= b;
+        // keep at most kMaxCachedBytes of free blocks: what is beyond goes back to the device
+        if (Cached + b <= kMaxCachedBytes) {
+            FreeLists[{device, b}].push_back(p);
+            Cached += b;
+            return;
+        }
+    }
+    (void)hipFree(p);  // (hipFree finds the owning device from the address)
 }
 
 void DevPool::Trim() {
     std::lock_guard<std::mutex> g(Lock);
     for (auto& kv : FreeLists) {
-        for (void* p : kv.second) (void)hipFree(p);  // (hipFree finds the owning device from the address)
+        for (void* p : kv.second) (void)hipFree(p);
         kv.second.clear();
     }
+    Cached = 0;
 }
 
 Buffer::~Buffer() {

@@ -34,6 +34,8 @@ private:
     std::mutex Lock;
     std::map<std::pair<int, size_t>, std::vector<void*>> FreeLists;  // (device, block size) -> free blocks
     size_t InUse = 0;
+    size_t Cached = 0;  // bytes in FreeLists
+    static constexpr size_t kMaxCachedBytes = size_t(64) << 30;  // a scan of an SF100 shard frees and takes again a few GB
 };
 
 struct Buffer {
@@ -103,6 +105,11 @@ public:
 
     Status ImportBatch(const ArrowArray* array, const ArrowSchema* schema, BatchPtr& out);
     Status ExportBatch(const Batch& batch, ArrowArray* outArray, ArrowSchema* outSchema);
+
+    // TNativeSerializer::DoDeserialize on the device: IPC blobs (a whole stream, or a lone RecordBatch message read with
+    // `schema`) -> HBM-resident batches, one per blob; all compressed buffers are decoded by one kernel launch.
+    Status ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<FieldDesc>& schema,
+                       std::vector<BatchPtr>& out);
 
     // TProgram::ApplyTo: every step in order.
     Status ApplyProgram(const TProgram& program, const BatchPtr& in, BatchPtr& out);

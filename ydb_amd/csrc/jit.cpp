@@ -4,14 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace ssa {
@@ -76,20 +82,236 @@ uint64_t Fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
     return h;
 }
 
+using Clock = std::chrono::steady_clock;
+
+// One (kernel variant, constant image, target) and what is known about it.  The map is keyed by the entry's full
+// bytes -- header, entry point, defines, target and image -- so that two programs can never share a kernel by accident.
+struct Entry {
+    enum EState { NONE, BUILDING, READY, FAILED } State = NONE;
+    int64_t SeenRows = 0;                      // rows of the scans that asked so far
+    std::string Why;                           // FAILED: the reason (not retried)
+    std::shared_ptr<std::vector<char>> Code;   // READY: the code object, shared by the devices
+    struct Loaded {
+        hipModule_t Module = nullptr;
+        hipFunction_t Function = nullptr;
+    };
+    std::map<int, Loaded> PerDevice;
+    Clock::time_point LastUse;
+};
+
+struct Job {
+    std::string Key, MainHeader, Defines, Arch;
+    std::vector<uint32_t> Image;
+};
+
 struct State {
-    std::mutex Lock;
+    std::mutex Lock;              // the maps below; never held while the compiler runs
+    std::mutex RtcLock;           // loading hiprtc
     Rtc R;
-    std::map<std::pair<int, uint64_t>, hipFunction_t> Functions;  // (device, key) -> kernel; modules are never unloaded
-    std::map<uint64_t, std::vector<char>> Code;                   // key -> code object (shared by the devices)
-    std::map<uint64_t, std::string> Failed;                       // key -> reason (not retried)
-    std::map<uint64_t, int64_t> SeenRows;                         // key -> rows of the scans that asked so far
-    std::atomic<int64_t> Compiled{0}, Launches{0}, BuildMicros{0};
+    std::unordered_map<std::string, Entry> Entries;
     std::map<int, std::string> Arch;  // device -> target name
+    std::atomic<int64_t> Compiled{0}, Launches{0}, BuildMicros{0}, Evicted{0}, FromDisk{0};
+    // background builds
+    std::mutex QueueLock;
+    std::condition_variable QueueCv;
+    std::deque<Job> Queue;
+    std::thread Worker;
+    bool WorkerStarted = false, Stop = false;
+
+    ~State() {
+        {
+            std::lock_guard<std::mutex> g(QueueLock);
+            Stop = true;
+            Queue.clear();
+        }
+        QueueCv.notify_all();
+        if (Worker.joinable()) Worker.join();
+    }
 };
 
 State& St() {
     static State s;
     return s;
+}
+
+constexpr size_t kMaxBuiltKernels = 256;        // READY entries kept (each holds a code object and a module per device)
+constexpr size_t kMaxEntries = 8192;            // entries of any state
+constexpr auto kEvictIdle = std::chrono::seconds(30);  // a kernel used this recently may still have launches in flight
+
+std::string CacheFile(const std::string& key) {
+    const char* dir = std::getenv("SSA_JIT_CACHE_DIR");
+    if (!dir || !dir[0]) return std::string();
+    char name[64];
+    std::snprintf(name, sizeof(name), "/ssa_%016llx%016llx.co", static_cast<unsigned long long>(Fnv(key.data(), key.size())),
+                  static_cast<unsigned long long>(Fnv(key.data(), key.size(), 0x9E3779B97F4A7C15ull)));
+    return std::string(dir) + name;
+}
+
+// Code objects on disk (only when SSA_JIT_CACHE_DIR names a directory): [key length][key][code length][code].  The key
+// stored in the file is compared in full, the file name is only a hash of it.
+bool LoadFromDisk(const std::string& key, std::vector<char>& code) {
+    const std::string path = CacheFile(key);
+    if (path.empty()) return false;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    uint64_t klen = 0, clen = 0;
+    if (std::fread(&klen, 8, 1, f) == 1 && klen == key.size()) {
+        std::string stored(klen, '\0');
+        if (std::fread(&stored[0], 1, klen, f) == klen && stored == key && std::fread(&clen, 8, 1, f) == 1 && clen > 0 && clen < (1ull << 30)) {
+            code.resize(clen);
+            ok = std::fread(code.data(), 1, clen, f) == clen;
+        }
+    }
+    std::fclose(f);
+    return ok;
+}
+
+void SaveToDisk(const std::string& key, const std::vector<char>& code) {
+    const std::string path = CacheFile(key);
+    if (path.empty()) return;
+    const std::string tmp = path + ".tmp" + std::to_string(reinterpret_cast<uintptr_t>(&code));
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint64_t klen = key.size(), clen = code.size();
+    const bool ok = std::fwrite(&klen, 8, 1, f) == 1 && std::fwrite(key.data(), 1, klen, f) == klen && std::fwrite(&clen, 8, 1, f) == 1 &&
+                    std::fwrite(code.data(), 1, clen, f) == clen;
+    std::fclose(f);
+    if (ok) std::rename(tmp.c_str(), path.c_str()); else std::remove(tmp.c_str());
+}
+
+// Runs the compiler.  Called without State::Lock.
+bool Compile(const Job& job, std::vector<char>& code, std::string& why) {
+    State& st = St();
+    if (LoadFromDisk(job.Key, code)) {
+        ++st.FromDisk;
+        return true;
+    }
+    {
+        std::lock_guard<std::mutex> g(st.RtcLock);
+        if (!st.R.Load(why)) return false;
+    }
+    // translation unit: the constant image, the variant's defines, then the kernel header
+    std::ostringstream src;
+    src << "#define SSA_SPEC 1\n" << job.Defines;
+    src << "alignas(16) static constexpr unsigned int kSpecImage[] = {";
+    for (size_t i = 0; i < job.Image.size(); ++i) {
+        if (i % 16 == 0) src << "\n";
+        src << job.Image[i] << "u,";
+    }
+    src << "\n};\n#include \"" << job.MainHeader << "\"\n";
+    const std::string text = src.str();
+    if (const char* dump = std::getenv("SSA_JIT_DUMP")) {  // diagnostics: the translation unit, for offline inspection
+        if (FILE* f = std::fopen(dump, "w")) {
+            std::fwrite(text.data(), 1, text.size(), f);
+            std::fclose(f);
+        }
+    }
+    // one compilation at a time (a queue of builds, not of scans: nobody scans under this lock)
+    static std::mutex compileLock;
+    std::lock_guard<std::mutex> cg(compileLock);
+    hiprtcProgram prog = nullptr;
+    if (st.R.CreateProgram(&prog, text.c_str(), "ssa_spec.hip", kEmbeddedCount, const_cast<const char**>(kEmbeddedSources),
+                           const_cast<const char**>(kEmbeddedNames)) != HIPRTC_SUCCESS) {
+        why = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const auto t0 = Clock::now();
+    const std::string archOpt = "--offload-arch=" + job.Arch;
+    // The step program's loops are unrolled by pragma with the whole interpreter inlined in their bodies: the
+    // default size limit of pragma-forced unrolling (16 K instructions before folding) is too small for that
+    // and, once exceeded, silently leaves the generic interpreter in the built kernel.
+    // No contraction of a multiply and a following add into one fused operation: in the straight-line code of a
+    // built kernel two instructions of the step program sit next to each other, and the reference rounds after
+    // each of them (a * b + c differed in the last bit on a quarter of the rows).  Where a fused operation is
+    // wanted (the register-held groups) the source asks for it by name.
+    const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm", "-ffp-contract=off",
+                          "-mllvm", "-pragma-unroll-threshold=1048576"};
+    const hiprtcResult rc = st.R.CompileProgram(prog, int(sizeof(opts) / sizeof(opts[0])), opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        (void)st.R.GetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) (void)st.R.GetProgramLog(prog, &log[0]);
+        (void)st.R.DestroyProgram(&prog);
+        why = "run-time compilation failed: " + log.substr(0, 2000);
+        return false;
+    }
+    size_t n = 0;
+    (void)st.R.GetCodeSize(prog, &n);
+    code.resize(n);
+    if (n) (void)st.R.GetCode(prog, code.data());
+    (void)st.R.DestroyProgram(&prog);
+    ++st.Compiled;
+    st.BuildMicros += int64_t(std::chrono::duration<double, std::micro>(Clock::now() - t0).count());
+    SaveToDisk(job.Key, code);
+    return true;
+}
+
+// Compiles and publishes the outcome in the entry (which is in state BUILDING and therefore stays in the map).
+void BuildAndPublish(const Job& job) {
+    std::vector<char> code;
+    std::string why;
+    const bool ok = Compile(job, code, why);
+    State& st = St();
+    std::lock_guard<std::mutex> g(st.Lock);
+    auto it = st.Entries.find(job.Key);
+    if (it == st.Entries.end()) return;
+    Entry& e = it->second;
+    if (ok) {
+        e.Code = std::make_shared<std::vector<char>>(std::move(code));
+        e.State = Entry::READY;
+    } else {
+        e.Why = why;
+        e.State = Entry::FAILED;
+    }
+    e.LastUse = Clock::now();
+}
+
+void WorkerLoop() {
+    State& st = St();
+    for (;;) {
+        Job job;
+        {
+            std::unique_lock<std::mutex> g(st.QueueLock);
+            st.QueueCv.wait(g, [&] { return st.Stop || !st.Queue.empty(); });
+            if (st.Stop) return;
+            job = std::move(st.Queue.front());
+            st.Queue.pop_front();
+        }
+        BuildAndPublish(job);
+    }
+}
+
+// Called with State::Lock held: drops the least recently used kernels beyond the bounds.  A kernel is only unloaded
+// after kEvictIdle without a request for it, so that no launch of it can still be queued on a stream.
+void EvictIfNeeded(State& st) {
+    size_t ready = 0;
+    for (auto& kv : st.Entries) ready += kv.second.State == Entry::READY;
+    if (ready <= kMaxBuiltKernels && st.Entries.size() <= kMaxEntries) return;
+    const auto now = Clock::now();
+    std::vector<std::pair<Clock::time_point, const std::string*>> order;
+    for (auto& kv : st.Entries) {
+        if (kv.second.State == Entry::BUILDING) continue;
+        if (now - kv.second.LastUse < kEvictIdle) continue;
+        order.emplace_back(kv.second.LastUse, &kv.first);
+    }
+    std::sort(order.begin(), order.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    for (auto& o : order) {
+        if (ready <= kMaxBuiltKernels * 3 / 4 && st.Entries.size() <= kMaxEntries * 3 / 4) break;
+        auto it = st.Entries.find(*o.second);
+        if (it->second.State == Entry::READY) {
+            for (auto& d : it->second.PerDevice) {
+                if (d.second.Module) {
+                    (void)hipSetDevice(d.first);
+                    (void)hipModuleUnload(d.second.Module);
+                }
+            }
+            --ready;
+        }
+        st.Entries.erase(it);
+        ++st.Evicted;
+    }
 }
 
 }  // namespace
@@ -100,7 +322,7 @@ KernelJit& KernelJit::Instance() {
 }
 
 void KernelJit::Stats(int64_t& built, double& buildMs, int64_t& launches) const {
-    built = St().Compiled.load();
+    built = St().Compiled.load() + St().FromDisk.load();
     buildMs = double(St().BuildMicros.load()) / 1e3;
     launches = St().Launches.load();
 }
@@ -115,114 +337,92 @@ bool JitEnabled() {
 bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const void* image, size_t imageBytes,
                     const std::string& defines, uint32_t ldsBytes, int64_t rows, SpecKernel& out, std::string& why) {
     State& st = St();
-    std::lock_guard<std::mutex> g(st.Lock);
-    std::string& arch = st.Arch[device];
-    if (arch.empty()) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
-            why = "no device properties";
-            return false;
-        }
-        arch = prop.gcnArchName;
-    }
-    uint64_t key = Fnv(mainHeader, std::strlen(mainHeader));
-    key = Fnv(entry, std::strlen(entry), key);
-    key = Fnv(defines.data(), defines.size(), key);
-    key = Fnv(image, imageBytes, key);
-    key = Fnv(arch.data(), arch.size(), key);
-
+    why.clear();
+    Job job;
+    bool buildHere = false;
     hipFunction_t fn = nullptr;
-    auto hit = st.Functions.find({device, key});
-    if (hit != st.Functions.end()) {
-        fn = hit->second;
-    } else {
-        auto bad = st.Failed.find(key);
-        if (bad != st.Failed.end()) {
-            why = bad->second;
-            return false;
-        }
-        const char* mode = std::getenv("SSA_JIT");
-        int64_t& seen = st.SeenRows[key];
-        seen += rows;
-        if (!(mode && mode[0] == '1') && seen < kJitMinRows) {
-            why.clear();
-            return false;
-        }
-        auto have = st.Code.find(key);
-        if (have == st.Code.end()) {
-            if (!st.R.Load(why)) {
-                st.Failed[key] = why;
+    {
+        std::unique_lock<std::mutex> g(st.Lock);
+        std::string& arch = st.Arch[device];
+        if (arch.empty()) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+                (void)hipGetLastError();
+                why = "no device properties";
                 return false;
             }
-            // translation unit: the constant image, the variant's defines, then the kernel header
-            std::ostringstream src;
-            src << "#define SSA_SPEC 1\n" << defines;
-            src << "alignas(16) static constexpr unsigned int kSpecImage[] = {";
-            const uint32_t* words = static_cast<const uint32_t*>(image);
-            for (size_t i = 0; i < imageBytes / 4; ++i) {
-                if (i % 16 == 0) src << "\n";
-                src << words[i] << "u,";
+            arch = prop.gcnArchName;
+        }
+        std::string key;
+        key.reserve(imageBytes + defines.size() + 96);
+        key.append(mainHeader).push_back('\0');
+        key.append(entry).push_back('\0');
+        key.append(defines).push_back('\0');
+        key.append(arch).push_back('\0');
+        key.append(static_cast<const char*>(image), imageBytes);
+        Entry& e = st.Entries[key];
+        e.LastUse = Clock::now();
+        if (e.State == Entry::FAILED) {
+            why = e.Why;
+            return false;
+        }
+        if (e.State == Entry::BUILDING) return false;  // another thread, or the worker, is at it: the generic kernel runs meanwhile
+        if (e.State == Entry::NONE) {
+            const char* mode = std::getenv("SSA_JIT");
+            const bool now = mode && mode[0] == '1';
+            e.SeenRows += rows;
+            if (!now && e.SeenRows < kJitMinRows) return false;
+            e.State = Entry::BUILDING;
+            job.Key = key;
+            job.MainHeader = mainHeader;
+            job.Defines = defines;
+            job.Arch = arch;
+            job.Image.assign(static_cast<const uint32_t*>(image), static_cast<const uint32_t*>(image) + imageBytes / 4);
+            // A scan that is large by itself waits for its kernel (the build costs what the generic kernel needs for
+            // some ten billion rows, and whoever scans that much at once will be back); scans that only add up to
+            // the threshold -- the batches of a shard -- never wait: a worker thread builds while they keep running
+            // the generic kernel.
+            const char* async = std::getenv("SSA_JIT_ASYNC");
+            buildHere = now || rows >= kJitMinRows || (async && async[0] == '0');
+            EvictIfNeeded(st);
+            if (!buildHere) {
+                std::lock_guard<std::mutex> q(st.QueueLock);
+                if (!st.WorkerStarted) {
+                    st.Worker = std::thread(WorkerLoop);
+                    st.WorkerStarted = true;
+                }
+                st.Queue.push_back(std::move(job));
+                st.QueueCv.notify_one();
+                return false;
             }
-            src << "\n};\n#include \"" << mainHeader << "\"\n";
-            const std::string text = src.str();
-            if (const char* dump = std::getenv("SSA_JIT_DUMP")) {  // diagnostics: the translation unit, for offline inspection
-                if (FILE* f = std::fopen(dump, "w")) {
-                    std::fwrite(text.data(), 1, text.size(), f);
-                    std::fclose(f);
+        }
+        if (!buildHere) {  // READY
+            Entry::Loaded& l = e.PerDevice[device];
+            if (!l.Function) {
+                (void)hipSetDevice(device);
+                hipError_t err = hipModuleLoadData(&l.Module, e.Code->data());
+                if (err == hipSuccess) err = hipModuleGetFunction(&l.Function, l.Module, entry);
+                if (err != hipSuccess) {
+                    (void)hipGetLastError();
+                    e.Why = std::string("cannot load the compiled kernel: ") + hipGetErrorString(err);
+                    e.State = Entry::FAILED;
+                    why = e.Why;
+                    return false;
                 }
             }
-            hiprtcProgram prog = nullptr;
-            if (st.R.CreateProgram(&prog, text.c_str(), "ssa_spec.hip", kEmbeddedCount, const_cast<const char**>(kEmbeddedSources),
-                                   const_cast<const char**>(kEmbeddedNames)) != HIPRTC_SUCCESS) {
-                why = "hiprtcCreateProgram failed";
-                st.Failed[key] = why;
-                return false;
-            }
-            const auto t0 = std::chrono::steady_clock::now();
-            const std::string archOpt = "--offload-arch=" + arch;
-            // The step program's loops are unrolled by pragma with the whole interpreter inlined in their bodies: the
-            // default size limit of pragma-forced unrolling (16 K instructions before folding) is too small for that
-            // and, once exceeded, silently leaves the generic interpreter in the built kernel.
-            // No contraction of a multiply and a following add into one fused operation: in the straight-line code of a
-            // built kernel two instructions of the step program sit next to each other, and the reference rounds after
-            // each of them (a * b + c differed in the last bit on a quarter of the rows).  Where a fused operation is
-            // wanted (the register-held groups) the source asks for it by name.
-            const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm", "-ffp-contract=off",
-                                  "-mllvm", "-pragma-unroll-threshold=1048576"};
-            const hiprtcResult rc = st.R.CompileProgram(prog, int(sizeof(opts) / sizeof(opts[0])), opts);
-            if (rc != HIPRTC_SUCCESS) {
-                size_t n = 0;
-                (void)st.R.GetProgramLogSize(prog, &n);
-                std::string log(n, '\0');
-                if (n) (void)st.R.GetProgramLog(prog, &log[0]);
-                (void)st.R.DestroyProgram(&prog);
-                why = "run-time compilation failed: " + log.substr(0, 2000);
-                st.Failed[key] = why;
-                return false;
-            }
-            size_t n = 0;
-            (void)st.R.GetCodeSize(prog, &n);
-            std::vector<char> code(n);
-            if (n) (void)st.R.GetCode(prog, code.data());
-            (void)st.R.DestroyProgram(&prog);
-            ++st.Compiled;
-            st.BuildMicros += int64_t(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-            have = st.Code.emplace(key, std::move(code)).first;
+            fn = l.Function;
         }
-        (void)hipSetDevice(device);
-        hipModule_t mod = nullptr;
-        hipError_t e = hipModuleLoadData(&mod, have->second.data());
-        if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, entry);
-        if (e != hipSuccess) {
-            why = std::string("cannot load the compiled kernel: ") + hipGetErrorString(e);
-            st.Failed[key] = why;
-            return false;
-        }
-        st.Functions[{device, key}] = fn;
+    }
+    if (buildHere) {
+        BuildAndPublish(job);  // the lock is not held: other programs' scans go on
+        return Get(device, mainHeader, entry, image, imageBytes, defines, ldsBytes, 0, out, why);
     }
     out.Function = fn;
     int n = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, ldsBytes) != hipSuccess || n <= 0) n = 1;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, ldsBytes) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        n = 1;
+    }
     out.BlocksPerCU = n;
     return true;
 }

@@ -5,8 +5,13 @@
 // step's tables fixed as constants (see the SSA_SPEC notes in scan_vm.h): loops unroll, the interpreter's dispatch
 // folds away and what is left is the straight-line code of that one program.  Compilation goes through hiprtc, loaded
 // with dlopen so that the library itself does not depend on it.  Compiled kernels are kept in the memory of the
-// process only (keyed by a hash of the constant image and the kernel variant); nothing is written to or read from
-// disk.  Whenever anything here fails the caller keeps using the generic kernel.
+// process, keyed by the full bytes of the constant image and the kernel variant (no two programs can share a kernel by
+// a hash collision); the least recently used ones are unloaded beyond 256 kernels.  Nothing is written to or read
+// from disk unless SSA_JIT_CACHE_DIR names a directory: then code objects are kept there across processes (the file
+// carries the whole key and is compared with it).  The compiler never runs under the cache's lock: a scan that is
+// large by itself (kJitMinRows rows) builds on its own thread and waits, scans that only add up to the threshold hand
+// the build to a worker thread and keep running the generic kernel until it is ready (SSA_JIT_ASYNC=0: always wait).
+// Whenever anything here fails the caller keeps using the generic kernel.
 #pragma once
 #include <hip/hip_runtime_api.h>
 

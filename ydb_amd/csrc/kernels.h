@@ -178,6 +178,27 @@ constexpr size_t kNoAllocScratchBytes = kNoAllocTotalOffset + 256;
 void* NoAllocScratchFor(int device, hipError_t* error);
 hipError_t LaunchSumTileCounts(const uint32_t* counts, int64_t ntiles, unsigned long long* total, hipStream_t st);
 
+// ---- compressed IPC bodies ---------------------------------------------------------------------------------
+// One block of an LZ4 frame (https://github.com/lz4/lz4/blob/dev/doc/lz4_Frame_format.md).
+struct Lz4BlockRef {
+    uint64_t Src;        // offset of the block's data inside the blob
+    uint32_t SrcBytes;
+    uint32_t Stored;     // 1: the block is stored uncompressed
+};
+// One frame = one buffer of a column.
+struct Lz4FrameTask {
+    uint64_t first_block;  // index of the frame's first block in the block array
+    uint32_t nblocks;
+    uint32_t linked;       // matches may reach into the previous block
+    uint8_t* dst;
+    uint64_t dst_bytes;    // the length the buffer announces
+};
+// Decodes every frame (one wavefront each) from the blob in device memory (256-byte aligned, 64 bytes of padding
+// behind it); maxBlockBytes = the largest compressed block among them.  A frame that does not decode to its announced
+// length raises SCAN_BAD_BLOB in *status.
+hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t maxBlockBytes,
+                           uint32_t* status, hipStream_t st);
+
 constexpr int kMaxShardKeys = 8;  // key columns of a sharding hash / a predicate border
 
 // ---- TColumnFilter on the device ----------------------------------------------------------------------

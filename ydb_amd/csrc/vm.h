@@ -204,6 +204,7 @@ enum ScanStatus : uint32_t {
     SCAN_TABLE_FULL = 4,       // group-by spill table ran out of slots (host retries with a bigger one)
     SCAN_OVERFLOW = 8,         // checked integer arithmetic -> Status::Invalid("overflow")
     SCAN_NAN_ORDER = 16,       // a NaN reached a float MIN / MAX whose result would depend on the reference's visiting order
+    SCAN_BAD_BLOB = 64,        // a compressed buffer of an IPC blob does not decode to the length it announces
     SCAN_NOT_UNIFORM = 32,     // a string column scanned as fixed-width values has strings of another length (host re-runs the step)
 };
 

@@ -155,6 +155,23 @@ class ProgramContainer:
         self._check(rc, err)
         return DeviceBatch(self._lib, out.value)
 
+    def ImportBlobs(self, blobs: Sequence[bytes], schema: Optional[HostBatch] = None) -> List[DeviceBatch]:
+        """TNativeSerializer::DoDeserialize on the GPU: IPC blobs (whole streams, or lone RecordBatch messages read with
+        `schema`: a HostBatch whose schema is the chunk's) -> resident batches, one launch for all compressed buffers."""
+        n = len(blobs)
+        keep = [ctypes.create_string_buffer(bytes(b), len(b)) for b in blobs]
+        ptrs = (ctypes.c_void_p * max(1, n))(*[ctypes.cast(k, ctypes.c_void_p).value for k in keep])
+        sizes = (ctypes.c_size_t * max(1, n))(*[len(b) for b in blobs])
+        outs = (ctypes.c_void_p * max(1, n))()
+        err = ctypes.c_void_p()
+        rc = self._lib.ssa_batches_from_blobs(self._h, ptrs, sizes, n, ctypes.byref(schema.schema) if schema is not None else None, outs,
+                                              ctypes.byref(err))
+        self._check(rc, err)
+        return [DeviceBatch(self._lib, outs[i]) for i in range(n)]
+
+    def ImportBlob(self, blob: bytes, schema: Optional[HostBatch] = None) -> DeviceBatch:
+        return self.ImportBlobs([blob], schema)[0]
+
     def ApplyDevice(self, batch: DeviceBatch) -> DeviceBatch:
         out, err = ctypes.c_void_p(), ctypes.c_void_p()
         rc = self._lib.ssa_program_apply_device(self._h, batch._h, ctypes.byref(out), ctypes.byref(err))
