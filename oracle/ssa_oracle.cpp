@@ -1537,6 +1537,20 @@ static DatumPtr AggregateNoKeys(Agg fn, const DatumPtr& argIn, int64_t rows) {
     }
     if (fn == AG_MIN || fn == AG_MAX) {
         // min_max (compute/kernels/aggregate_basic_internal.h:207-228): floats fold with fmin / fmax from +-inf
+        if (IsStr(t)) {
+            // Arrow 5.0's min_max has no string kernel: the call falls through to ch.min / ch.max (program.cpp:97-103),
+            // a SingleValueDataString state: the first value, then bytewise `<` / `>`
+            // (AggregateFunctionMinMaxAny.h:160-341)
+            DatumPtr out = NewArray(t, 1);
+            out->scalar = true;
+            out->ok.assign(1, 0);
+            for (int64_t r = 0; r < arg->n; ++r) {
+                if (!arg->Valid(r)) continue;
+                if (!out->ok.empty()) { out->s[0] = arg->s[r]; out->ok.clear(); continue; }
+                if (fn == AG_MIN ? arg->s[r] < out->s[0] : arg->s[r] > out->s[0]) out->s[0] = arg->s[r];
+            }
+            return out;
+        }
         if (!(IsNum(t) || IsTemporal(t))) throw Error(std::string("min/max over ") + TyName(t) + " is unsupported");
         DatumPtr out = NewArray(t, 1);
         out->scalar = true;
@@ -1560,13 +1574,14 @@ static DatumPtr AggregateNoKeys(Agg fn, const DatumPtr& argIn, int64_t rows) {
     if (fn == AG_SOME) {
         // no Arrow function of that name: ch.any = the first non-null value
         // (ydb/library/arrow_clickhouse/AggregateFunctions/AggregateFunctionMinMaxAny.h:526-534)
-        if (!(IsNum(t) || IsTemporal(t))) throw Error(std::string("some() over ") + TyName(t) + " is unsupported");
+        if (!(IsNum(t) || IsTemporal(t) || IsStr(t))) throw Error(std::string("some() over ") + TyName(t) + " is unsupported");
         DatumPtr out = NewArray(t, 1);
         out->scalar = true;
         out->ok.assign(1, 0);
         for (int64_t r = 0; r < arg->n; ++r) {
             if (!arg->Valid(r)) continue;
-            if (StoreOf(t) == S_I) out->i[0] = arg->i[r]; else if (StoreOf(t) == S_U) out->u[0] = arg->u[r]; else out->f[0] = arg->f[r];
+            if (IsStr(t)) out->s[0] = arg->s[r];
+            else if (StoreOf(t) == S_I) out->i[0] = arg->i[r]; else if (StoreOf(t) == S_U) out->u[0] = arg->u[r]; else out->f[0] = arg->f[r];
             out->ok.clear();
             break;
         }
@@ -1587,6 +1602,7 @@ struct GroupState {
     std::vector<uint64_t> u;
     std::vector<double> f;
     std::vector<int64_t> hi;
+    std::vector<std::string> s;
     int64_t firstRow = 0;
 };
 
@@ -1644,7 +1660,7 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
         if (g.fn != AG_COUNT) {
             const int t = a ? a->ty : NONE;
             if (g.fn == AG_SUM && SumOutType(t) == NONE) throw Error(std::string("Function 'sum' has no kernel matching input types (") + TyName(t) + ")");
-            if (g.fn != AG_SUM && !(IsNum(t) || IsTemporal(t))) throw Error("Unsupported aggregate argument type");
+            if (g.fn != AG_SUM && !(IsNum(t) || IsTemporal(t) || IsStr(t))) throw Error("Unsupported aggregate argument type");
             if (g.fn == AG_SUM && t == DEC && key8) throw Error("Unsupported: decimal128 SUM on the lookup-table path");
         }
         args.push_back(a);
@@ -1658,6 +1674,7 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
         GroupState st;
         st.has.assign(na, 0);
         st.i.assign(na, 0); st.u.assign(na, 0); st.f.assign(na, 0); st.hi.assign(na, 0);
+        st.s.assign(na, std::string());
         st.firstRow = r;
         return st;
     };
@@ -1668,6 +1685,13 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
         // addBatch skips rows whose argument is null (IAggregateFunction.h:199-221) -- except on the key8 path
         if (a && !key8 && !a->Valid(r)) return;
         if (fn == AG_COUNT) { ++st.u[k]; st.has[k] = 1; return; }
+        if (IsStr(a->ty)) {  // SingleValueDataString (AggregateFunctionMinMaxAny.h:160-341): bytewise compares
+            const std::string& v = a->s[r];
+            if (!st.has[k]) st.s[k] = v;
+            else if (fn == AG_MIN ? v < st.s[k] : fn == AG_MAX ? v > st.s[k] : false) st.s[k] = v;
+            st.has[k] = 1;
+            return;
+        }
         const Store s = StoreOf(a->ty);
         switch (fn) {
             case AG_SUM:  // AggregateFunctionSum.h:31-47: sequential adds in row order, integers wrap
@@ -1697,6 +1721,11 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
         const Agg fn = step.groupBy[k].fn;
         if (!from.has[k]) return;
         if (fn == AG_COUNT) { st.u[k] += from.u[k]; st.has[k] = 1; return; }
+        if (IsStr(args[k]->ty)) {
+            if (!st.has[k] || (fn == AG_MIN ? from.s[k] < st.s[k] : fn == AG_MAX ? from.s[k] > st.s[k] : false)) st.s[k] = from.s[k];
+            st.has[k] = 1;
+            return;
+        }
         const Store s = StoreOf(args[k]->ty);
         switch (fn) {
             case AG_SUM:
@@ -1751,12 +1780,20 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
             if (r >= unrolled) continue;
             auto& sub = streams[size_t(r % 4)];
             while (sub.size() <= g) sub.push_back(newState(r));
-            for (size_t k = 0; k < na; ++k) addRow(sub[g], k, r);
+            for (size_t k = 0; k < na; ++k) {
+                // string states allocate from the arena: those aggregates take the plain loop, in row order
+                // (IAggregateFunction.h:396-402, 258-296)
+                const bool plain = step.groupBy[k].fn != AG_COUNT && args[k] && IsStr(args[k]->ty);
+                addRow(plain ? groups[g] : sub[g], k, r);
+            }
         }
         for (size_t g = 0; g < groups.size(); ++g) {
             for (int j = 0; j < 4; ++j) {
                 if (streams[size_t(j)].size() <= g) continue;
-                for (size_t k = 0; k < na; ++k) mergeState(groups[g], streams[size_t(j)][g], k);
+                for (size_t k = 0; k < na; ++k) {
+                    const bool plain = step.groupBy[k].fn != AG_COUNT && args[k] && IsStr(args[k]->ty);
+                    if (!plain) mergeState(groups[g], streams[size_t(j)][g], k);
+                }
             }
         }
         for (int64_t r = unrolled; r < rows; ++r) {
@@ -1785,6 +1822,7 @@ static Batch AggregateKeyed(const Step& step, const Batch& in) {
             const bool valid = fn == AG_COUNT || st.has[k];
             if (!valid) { anyNull = true; continue; }
             if (ot == DEC) { col->u[g] = st.u[k]; col->hi[g] = st.hi[k]; continue; }
+            if (IsStr(ot)) { col->s[g] = st.s[k]; continue; }
             switch (StoreOf(ot)) {
                 case S_I: col->i[g] = st.i[k]; break;
                 case S_U: col->u[g] = st.u[k]; break;

@@ -242,6 +242,29 @@ def check_logic_bool(case, run):
     assert [int(v) for v in pylist(out["res1"])] == e["invert_x"]
 
 
+def check_read_aggregate_strings(case, run):
+    n = case["rows"]
+    batch = {"num": col("int32", list(range(n))), "str": Col([str(i) for i in range(n)], type="string"),
+             "bin": Col([str(i).encode() for i in range(n)], type="binary")}
+    res = [(1, "num"), (2, "str"), (3, "bin")]
+    for cid, typ in ((2, "string"), (3, "binary"), (1, "int32")):
+        for label in ("all", "filtered_on_column_equal_1"):
+            p = Program()
+            if label != "all":
+                p.assign_const(50, "Int32", 1).assign_func(51, F.CMP_EQUAL, [1, 50]).filter(51)
+            p.group_by([Aggregate(100, AGG.MIN, [cid]), Aggregate(101, AGG.MAX, [cid]), Aggregate(102, AGG.SOME, [cid]),
+                        Aggregate(103, AGG.COUNT, [cid])]).project([100, 101, 102, 103])
+            out = run(res, p, batch)
+            e = case["expect"][label]
+            assert list(out.keys()) == ["100", "101", "102", "103"]
+            assert [out[k].type for k in ("100", "101", "102")] == [typ] * 3 and out["103"].type == "uint64"
+
+            def text(v):
+                return v.decode() if isinstance(v, bytes) else str(v)
+            got = [text(pylist(out[k])[0]) for k in ("100", "101", "102")] + [pylist(out["103"])[0]]
+            assert got == [str(e["min"]), str(e["max"]), str(e["some"]), e["count"]], (typ, label, got)
+
+
 GOLDEN_CHECKS = {
     "add_less_filter": check_add_less_filter, "const_add_filter": check_const_add_filter, "min_max_nokeys": check_min_max_nokeys,
     "sum_nokeys": check_sum_nokeys, "group_by_sum": check_group_by_sum, "group_by_min_max_some": check_group_by_min_max_some,
@@ -249,7 +272,7 @@ GOLDEN_CHECKS = {
     "yql_add_generated_name": check_yql_add_generated_name, "str_length": check_str_length,
     "yql_string_kernels": check_yql_string_kernels, "aggregator_group_counts": check_aggregator_group_counts,
     "count_with_nulls": check_count_with_nulls, "arith_int32": check_arith_int32, "compare_int32": check_compare_int32,
-    "logic_bool": check_logic_bool,
+    "logic_bool": check_logic_bool, "read_aggregate_strings": check_read_aggregate_strings,
 }
 
 

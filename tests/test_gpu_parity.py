@@ -664,3 +664,30 @@ def test_string_keys_that_only_look_like_one_length(where):
         compare_batches(got, exp, key_names=["s"])
     assert sorted(x for x in exp["s"].to_pylist()) == sorted([b"", b"A", b"AB", b"N", b"R"]) or \
         sorted(exp["s"].to_pylist()) == sorted(["", "A", "AB", "N", "R"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 1000, 80_000])
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_string_min_max_some(n, jit, monkeypatch):
+    # SingleValueDataString (AggregateFunctionMinMaxAny.h:160-341): the first value, then bytewise `<` / `>`
+    monkeypatch.setenv("SSA_JIT", jit)
+    rng = np.random.default_rng(4600 + n)
+    words = ["", "a", "ab", "abc", "b", "zz", "Zz", "\xff\x01", "the quick brown fox", "the quick brown fo", "the quick brown fox!", "日本語", "日本"]
+    s = Col([words[i] for i in rng.integers(0, len(words), n)], valid=rng.random(n) > 0.25, type="string")
+    b = Col([words[i].encode() for i in rng.integers(0, len(words), n)], type="binary")
+    k32 = rng.integers(0, 40, n).astype(np.int32)
+    k8 = rng.integers(0, 4, n).astype(np.int8)
+    v = rng.integers(-5, 5, n).astype(np.int64)
+    keep = rng.random(n) < 0.8
+    res = [(1, "s"), (2, "b"), (3, "k32"), (4, "k8"), (5, "v"), (6, "keep")]
+    batch = {"s": s, "b": b, "k32": k32, "k8": k8, "v": v, "keep": keep}
+    aggs = [Aggregate(10, AGG.MIN, [1]), Aggregate(11, AGG.MAX, [1]), Aggregate(12, AGG.SOME, [1]), Aggregate(13, AGG.MIN, [2]),
+            Aggregate(14, AGG.MAX, [2]), Aggregate(15, AGG.SOME, [2]), Aggregate(16, AGG.COUNT, [1]), Aggregate(17, AGG.SUM, [5])]
+    for keys, names in (([3], ["k32"]), ([4], ["k8"]), ([3, 4], ["k32", "k8"]), ([2], ["b"]), ([], [])):
+        for filtered in (False, True):
+            p = Program()
+            if filtered:
+                p.filter(6)
+            p.group_by(aggs, keys=keys)
+            got, exp = both(res, p, batch)
+            compare_batches(got, exp, key_names=names)

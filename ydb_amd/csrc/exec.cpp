@@ -1933,6 +1933,45 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     return Status::OK();
 }
 
+// A key-less step with a string MIN / MAX: the keyed sink with no key columns -- every row in one group.  Without rows
+// there is no group, while the key-less aggregation still yields its one row (nulls, and zero counts).
+Status Executor::RunNoKeyAsOneGroup(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out) {
+    std::vector<OffsetCheck> none;
+    bool notUniform = false;
+    SSA_RETURN_NOT_OK(RunKeyedScan(step, plan, in, out, none, &notUniform));
+    if (out->Rows == 1) return Status::OK();
+    if (out->Rows != 0) return Status::Invalid("internal: key-less aggregation produced more than one group");
+    auto one = std::make_shared<Batch>();
+    one->Rows = 1;
+    for (const OutColumn& oc : plan.Outs) {
+        Column col;
+        col.Field.Name = oc.Name;
+        col.Field.Type = oc.Type;
+        col.Field.Precision = oc.Precision;
+        col.Field.Scale = oc.Scale;
+        col.Length = 1;
+        const bool isCount = plan.Aggs[size_t(oc.Index)].Spec.kind == AGG_COUNT;
+        col.Values = Buffer::Alloc(64);
+        if (!col.Values) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemsetAsync(col.Values->Ptr, 0, 64, StreamHandle));
+        if (IsStringLike(oc.Type)) {
+            col.Chars = Buffer::Alloc(32);
+            if (!col.Chars) return Status::Hip("out of device memory");
+        }
+        if (!isCount) {
+            col.Validity = Buffer::Alloc(32);
+            if (!col.Validity) return Status::Hip("out of device memory");
+            SSA_HIP(hipMemsetAsync(col.Validity->Ptr, 0, 32, StreamHandle));
+            col.NullCount = 1;
+            col.Field.Nullable = true;
+        }
+        one->Cols.push_back(std::move(col));
+    }
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    out = one;
+    return Status::OK();
+}
+
 Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out) {
     StepPlan plan;
     SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FULL, plan));
@@ -1941,6 +1980,7 @@ Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPt
         case StepPlan::PROJECT:
             return RunProject(step, plan, in, out);
         case StepPlan::AGG_NOKEY:
+            if (plan.HasStringMinMax) return RunNoKeyAsOneGroup(step, plan, *in, out);
             return RunNoKey(plan, *in, out);
         case StepPlan::AGG_KEYED:
             return RunKeyed(step, plan, *in, out);

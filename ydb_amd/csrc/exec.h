@@ -152,6 +152,7 @@ private:
     Status ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
     Status RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out);
     Status RunKeyed(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out);
+    Status RunNoKeyAsOneGroup(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out);
     Status RunKeyedUniform(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out, bool& done);
     Status RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
                         const std::vector<OffsetCheck>& checks, bool* notUniform);

@@ -74,7 +74,30 @@ __device__ __host__ inline uint64_t TableIdentity(int kind) {
         case AGG_MIN_U: return ~0ull;
         case AGG_MIN_F: return 0xFFF0000000000000ull;  // ordered(+inf)
         case AGG_MAX_F: return 0x000FFFFFFFFFFFFFull;  // ordered(-inf)
+        case AGG_MIN_S: case AGG_MAX_S: return ~0ull;  // no row
         default: return 0;
+    }
+}
+
+// MIN / MAX over a string column: the accumulator holds the row of the smallest / largest string seen, replaced by a
+// compare-and-swap whenever `row`'s string beats it (bytewise, then by length: std::string_view's order; equal strings
+// keep the smaller row).  The strings are read from the column in memory.  Works on LDS and HBM accumulators alike.
+__device__ __noinline__ void StringBestUpdate(const DevColumn& col, bool isMin, uint64_t* p, uint64_t row) {
+    const int32_t* offs = static_cast<const int32_t*>(col.values);
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(p);
+    const int32_t b1 = offs[row], n1 = offs[row + 1] - b1;
+    unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (cur == row) return;
+        if (cur != ~0ull) {
+            const int32_t b2 = offs[cur], n2 = offs[cur + 1] - b2;
+            const int c = StrCompare(col.chars + b1, n1, col.chars + b2, n2);
+            const bool better = c == 0 ? row < cur : (isMin ? c < 0 : c > 0);
+            if (!better) return;
+        }
+        const unsigned long long prev = atomicCAS(slot, cur, static_cast<unsigned long long>(row));
+        if (prev == cur) return;
+        cur = prev;
     }
 }
 
@@ -456,7 +479,8 @@ __device__ __forceinline__ void ScanKeyedBody() {
     const uint32_t tKeyFk = s.keys[ki].fetch_kind, tKeyPayload = s.keys[ki].fetch_payload;
     const int ai = lane < kMaxAggs ? lane : 0;
     const uint32_t tAggKind = uint32_t(s.aggs[ai].kind), tAggReg = uint32_t(s.aggs[ai].reg), tAggCheck = uint32_t(s.aggs[ai].check_valid);
-    const uint32_t tAggFk = s.aggs[ai].fetch_kind, tAggPayload = s.aggs[ai].fetch_payload, tAggFlags = uint32_t(s.aggs[ai].flags);
+    const uint32_t tAggFk = s.aggs[ai].fetch_kind, tAggPayload = s.aggs[ai].fetch_payload, tAggFlags = uint32_t(s.aggs[ai].flags),
+                   tAggStrCol = uint32_t(s.aggs[ai].str_col);
     const int hi_ = lane < kHotAggs ? lane : 0;
     const uint32_t tHotKind = (lane < kHotAggs && !(m.S().debug_flags & 32)) ? uint32_t(s.hot_kind[hi_]) : 0u;
     const uint32_t tHotOff = uint32_t(s.hot_off[hi_]);
@@ -812,6 +836,15 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
             uint64_t* accK = lAcc + size_t(k) * L * R;
             uint64_t* tabK = rs.t_acc + size_t(k) * (rs.table_mask + 1);
+            if (kind == AGG_MIN_S || kind == AGG_MAX_S) {
+                const DevColumn& strCol = a.cols[SSA_ROW(tAggStrCol, s.aggs[k].str_col, k)];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!((live >> u) & 1u)) continue;
+                    StringBestUpdate(strCol, kind == AGG_MIN_S, slot[u] >= 0 ? accK + slot[u] * R + rep : tabK + (-2 - slot[u]), x.v[u]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (!((live >> u) & 1u)) continue;
@@ -875,6 +908,12 @@ __device__ __forceinline__ void ScanKeyedBody() {
         for (int k = 0; k < naggs; ++k) {
             const int kind = s.aggs[k].kind;
             const uint64_t* src = lAcc + (size_t(k) * L + d) * R;
+            if (kind == AGG_MIN_S || kind == AGG_MAX_S) {
+                for (int r = 0; r < R; ++r) {
+                    if (src[r] != ~0ull) StringBestUpdate(a.cols[s.aggs[k].str_col], kind == AGG_MIN_S, rs.t_acc + size_t(k) * (rs.table_mask + 1) + g, src[r]);
+                }
+                continue;
+            }
             uint64_t v = src[0];
             for (int r = 1; r < R; ++r) v = TableCombine(kind, v, src[r]);
             if (v != TableIdentity(kind)) AccUpdate(kind, rs.t_acc + size_t(k) * (rs.table_mask + 1) + g, v);

@@ -1146,12 +1146,13 @@ struct Compiler {
                         if (IsSignedInt(at) || IsTemporal(at)) ap.Spec.kind = mn ? AGG_MIN_I : AGG_MAX_I;
                         else if (IsUnsignedInt(at)) ap.Spec.kind = mn ? AGG_MIN_U : AGG_MAX_U;
                         else if (IsFloat(at)) ap.Spec.kind = mn ? AGG_MIN_F : AGG_MAX_F;
+                        else if (IsStringLike(at)) ap.Spec.kind = mn ? AGG_MIN_S : AGG_MAX_S;
                         else return Status::Unsupported(std::string("min/max over ") + TypeName(at));
                         ap.OutType = at;
                         break;
                     }
                     case EAggregate::Some:
-                        if (!(IsNumeric(at) || IsTemporal(at))) return Status::Unsupported(std::string("some() over ") + TypeName(at));
+                        if (!(IsNumeric(at) || IsTemporal(at) || IsStringLike(at))) return Status::Unsupported(std::string("some() over ") + TypeName(at));
                         ap.Spec.kind = AGG_SOME;
                         ap.OutType = at;
                         break;
@@ -1160,12 +1161,14 @@ struct Compiler {
                 }
                 ap.Spec.arg_class = arg ? ClassOfType(at) : CLS_U;
                 ap.Spec.check_valid = ap.ArgNullable ? 1 : 0;
-                if (ap.Spec.kind == AGG_SOME) {
+                if (ap.Spec.kind == AGG_SOME || ap.Spec.kind == AGG_MIN_S || ap.Spec.kind == AGG_MAX_S) {
                     // first non-null in row order == the value at the smallest row index whose argument is
-                    // valid: aggregate MIN(row index) here, the executor gathers the value afterwards.
+                    // valid: aggregate MIN(row index) here, the executor gathers the value afterwards.  The smallest /
+                    // largest string likewise: the sink keeps the row index of the winner (SingleValueDataString,
+                    // AggregateFunctionMinMaxAny.h:160-341: the first value, then bytewise `<` / `>`).
                     if (ap.ArgInputColumn < 0 || Input[size_t(ap.ArgInputColumn)].Type != at) {
                         // (a widening cast of a column is still that column to the VM, but not to the gather)
-                        return Status::Unsupported("some() over a computed expression");
+                        return Status::Unsupported("some() / string min / max over a computed expression");
                     }
                     auto rowIdx = std::make_shared<Expr>();
                     rowIdx->Kind = Expr::UNARY;
@@ -1173,11 +1176,18 @@ struct Compiler {
                     rowIdx->L = arg;
                     rowIdx->Type = T_U64;
                     rowIdx->Nullable = arg->Nullable;
-                    if (key8Path && !Step.GroupByKeys.empty()) {
+                    // (string states take the plain row-order loop of the lookup-table path: IAggregateFunction.h:396-402)
+                    if (key8Path && !Step.GroupByKeys.empty() && !IsStringLike(at)) {
                         rowIdx->A = ROWIDX_LOOKUP_ORDER;
                         Plan.NeedsFilteredPositions = true;
                     }
-                    ap.Spec.kind = AGG_MIN_U;
+                    if (ap.Spec.kind == AGG_SOME) {
+                        ap.Spec.kind = AGG_MIN_U;
+                        if (IsStringLike(at)) Plan.HasStringMinMax = true;  // (the key-less sink fetches fixed-width values only)
+                    } else {
+                        ap.Spec.str_col = ColSlot(Strip(arg.get()), st);
+                        Plan.HasStringMinMax = true;
+                    }
                     ap.Spec.arg_class = CLS_U;
                     ap.SomeInputColumn = ap.ArgInputColumn;
                     ap.Spec.reg = addRegOut(rowIdx);

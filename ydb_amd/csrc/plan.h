@@ -93,6 +93,7 @@ struct StepPlan {
     // The step groups by one single-byte key and an aggregate's result depends on the positions of the rows in the
     // FILTERED batch (RowIdxFlags): a step with filters is run on the compacted batch, as the reference does.
     bool NeedsFilteredPositions = false;
+    bool HasStringMinMax = false;  // MIN / MAX / SOME over a string column: only the keyed sink has them (a key-less step runs as one group)
     int NumRegsUsed = 0;
     // sink description
     std::vector<OutColumn> Outs;      // output batch columns in order

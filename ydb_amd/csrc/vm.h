@@ -275,6 +275,7 @@ enum AggKind : int32_t {
     AGG_MIN_U, AGG_MAX_U,
     AGG_MIN_F, AGG_MAX_F,
     AGG_SOME,      // first non-null in row order
+    AGG_MIN_S, AGG_MAX_S,  // strings, bytewise: the accumulator is the row index of the winning string (argument = row index)
 };
 
 struct AggSpec {
@@ -285,7 +286,7 @@ struct AggSpec {
     uint32_t fetch_kind;    // pre-decoded operand (FetchKind, payload) for `reg`
     uint32_t fetch_payload;
     int32_t flags;      // AggFlags
-    int32_t reserved;
+    int32_t str_col;    // AGG_MIN_S / AGG_MAX_S: column slot of the string argument
 };
 enum AggFlags : int32_t {
     AGG_NAN_UNSUPPORTED = 1,  // float MIN / MAX: a NaN argument raises SCAN_NAN_ORDER instead of being skipped
