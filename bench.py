@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scan-pushdown benchmark: rows/s of the SSA program executor over an HBM-resident lineitem.
 
-    python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q6|mixed|cb_*] [--rows R]
+    python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q1_dict|q6|mixed|cb_*] [--rows R]
 
 One step = one pass of the program (TPC-H Q1 by default: filter, two computed columns, nine aggregates
 grouped by (l_returnflag, l_linestatus)) over this rank's SF100 lineitem shard, result on the host.  With
@@ -9,8 +9,8 @@ N > 1 (one process per GPU, launched by torch.distributed.run) every rank scans 
 row range and the partial aggregates are merged through one RCCL all-gather plus a merge program, all
 inside the timed region; `value` is the rows all ranks scanned divided by the slowest rank's time.
 
-At N = 1 the default run also times the other half of the metric on the same resident table -- TPC-H Q6 and Q1 over
-1-byte flag codes -- and reports them under "also", each with its own roofline and CPU baseline.
+At N = 1 the default run also times the other half of the metric on the same resident table -- TPC-H Q6, Q1 over
+1-byte flag codes and Q1 over dictionary-encoded flags -- and reports them under "also", each with its own roofline and CPU baseline.
 
 `--workload mixed` is the stream of the sharded SF1000 configuration: Q1 and Q6 alternate over one resident shard of
 SF1000 / 8 = 750 M rows; one step = one Q1 pass plus one Q6 pass.
@@ -52,6 +52,8 @@ def cpu_baseline(workload: str, seconds_target: float = 15.0, all_cores_seconds:
         resolver = clickbench.HITS_RESOLVER
     else:
         codes = workload == "q1_codes"
+        if workload == "q1_dict":  # the reference decodes the dictionary when it loads the chunk: its executor sees utf8 flags
+            workload = "q1"
         if workload == "q6":
             prog, cols = tpch.q6_program(), tpch.Q6_COLUMNS
         else:
@@ -124,6 +126,8 @@ def tpch_workload(workload: str):
     from ydb_amd import tpch
     if workload == "q6":
         return tpch.q6_program(), tpch.Q6_COLUMNS, tpch.Q6_BYTES_PER_ROW, "TPC-H Q6"
+    if workload == "q1_dict":  # the utf8 program over dictionary-encoded flag columns: one code byte per flag and row
+        return tpch.q1_program(False), tpch.Q1_COLUMNS_DICT, tpch.Q1_BYTES_PER_ROW_CODES, "TPC-H Q1 (dictionary-encoded utf8 flags)"
     codes = workload == "q1_codes"
     return (tpch.q1_program(codes), tpch.Q1_COLUMNS_CODES if codes else tpch.Q1_COLUMNS_UTF8,
             tpch.Q1_BYTES_PER_ROW_CODES if codes else tpch.Q1_BYTES_PER_ROW_UTF8,
@@ -152,12 +156,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q6", "mixed", "cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv",
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1_codes", "q1_dict", "q6", "mixed", "cb_q1", "cb_q2", "cb_q3", "cb_q6", "cb_adv",
                                                          "cb_userid", "cb_phrase", "cb_q20"])
     ap.add_argument("--rows", type=int, default=0,
                     help="rows per GPU (default: TPC-H SF100 lineitem; SF1000 / 8 for mixed; ClickBench hits for cb_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="N = 1, workload q1: do not time Q6 and Q1-codes as well")
+    ap.add_argument("--no-also", action="store_true", help="N = 1, workload q1: do not time Q6, Q1-codes and Q1-dictionary as well")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses cuda:0 and the exchange runs over gloo (checks the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -191,7 +195,7 @@ def main():
 
     mixed = args.workload == "mixed"
     clickbench_run = args.workload.startswith("cb_")
-    also = ["q6", "q1_codes"] if (args.workload == "q1" and world == 1 and not args.no_also) else []
+    also = ["q6", "q1_codes", "q1_dict"] if (args.workload == "q1" and world == 1 and not args.no_also) else []
     rows = args.rows or (SF1000_SHARD_ROWS if mixed else tpch.SF100_ROWS)
     resolver = tpch.LINEITEM_RESOLVER
     table = "SF1000 / 8 lineitem shard" if mixed else "SF100-sized lineitem shard"
@@ -212,7 +216,7 @@ def main():
     else:
         keys = ["q1", "q6"] if mixed else [args.workload]
         li = tpch.DeviceLineitem(rows, device=local_rank, row0=rank * rows,
-                                 utf8_flags=("q1" in keys), code_flags=("q1_codes" in keys + also))
+                                 utf8_flags=("q1" in keys), code_flags=bool({"q1_codes", "q1_dict"} & set(keys + also)))
         for k in keys:
             prog, cols, bpr, name = tpch_workload(k)
             stream.append((k, prog, li.batch(cols), bpr, name))

@@ -138,15 +138,27 @@ int ssa_batches_from_blobs(ssa_program_t* program, const uint8_t* const* blobs, 
 struct ssa_device_column {
     const char* name;
     int32_t type;          /* enum ssa_type */
-    int32_t reserved;
-    const void* values;    /* fixed width: values; BOOL: bitmap; STRING/BINARY: int32 offsets (rows + 1) */
+    int32_t index_type;    /* 0: a plain column.  An integer enum ssa_type: a dictionary-encoded STRING / BINARY column
+                            * (arrow::DictionaryArray, which the reference decodes when it loads a chunk,
+                            * ydb/core/formats/arrow/dictionary/conversion.h:13-15): `values` holds one code of this
+                            * type per row, `chars` / `dict_offsets` / `dict_size` the dictionary.  Programs give the
+                            * results of the decoded column; predicates and GROUP BY keys are worked on the codes.  A
+                            * code outside [0, dict_size) reads as a null. */
+    const void* values;    /* fixed width: values; BOOL: bitmap; STRING/BINARY: int32 offsets (rows + 1); dictionary: codes */
     const uint8_t* validity; /* bitmap, NULL = no nulls */
-    const uint8_t* chars;  /* STRING/BINARY bytes; the allocation must be readable for 16 bytes past chars_size (the
-                            * scans read strings in 16-byte pieces) */
+    const uint8_t* chars;  /* STRING/BINARY bytes (of the dictionary's entries when index_type != 0); the allocation must
+                            * be readable for 16 bytes past chars_size (the scans read strings in 16-byte pieces) */
     int64_t chars_size;
     int64_t null_count;    /* -1 = unknown */
+    const int32_t* dict_offsets; /* dictionary: int32 offsets of the entries into chars (dict_size + 1), else NULL */
+    int64_t dict_size;     /* dictionary: number of entries */
 };
 int ssa_batch_from_device(const struct ssa_device_column* cols, size_t ncols, int64_t rows, ssa_batch_t** out, char** err);
+/* Process-wide counters of the work on dictionary-encoded columns (no counterpart in the reference, which decodes
+ * every such column when it loads it, ydb/core/formats/arrow/transformer/dictionary.cpp:9-11): program steps and
+ * filters that ran over the codes, and whole columns that had to be decoded (a gather through the codes) because a step
+ * used them as values. */
+void ssa_dictionary_stats(int64_t* steps_on_codes, int64_t* columns_decoded);
 
 /* TProgram::ApplyTo on an HBM-resident batch; the result stays in HBM. */
 int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_batch_t** out, char** err);

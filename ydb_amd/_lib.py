@@ -21,12 +21,14 @@ class DeviceColumn(ctypes.Structure):
     _fields_ = [
         ("name", ctypes.c_char_p),
         ("type", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("index_type", ctypes.c_int32),
         ("values", ctypes.c_void_p),
         ("validity", ctypes.c_void_p),
         ("chars", ctypes.c_void_p),
         ("chars_size", ctypes.c_int64),
         ("null_count", ctypes.c_int64),
+        ("dict_offsets", ctypes.c_void_p),
+        ("dict_size", ctypes.c_int64),
     ]
 
 
@@ -41,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "ssa_device_count", "ssa_version", "ssa_free_string", "ssa_program_create", "ssa_program_destroy",
     "ssa_program_debug_string", "ssa_program_source_columns", "ssa_program_early_filter_columns",
     "ssa_program_step_count", "ssa_program_explain", "ssa_program_apply", "ssa_program_build_filter", "ssa_batch_import",
-    "ssa_batch_from_device", "ssa_program_apply_device", "ssa_batch_export", "ssa_batch_rows",
+    "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_batch_export", "ssa_batch_rows",
     "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
     "ssa_gen_lineitem",
     "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
@@ -93,6 +95,8 @@ def load() -> ctypes.CDLL:
     lib.ssa_batch_import.restype = i32
     lib.ssa_batch_from_device.argtypes = [P(DeviceColumn), sz, i64, P(vp), P(vp)]
     lib.ssa_batch_from_device.restype = i32
+    lib.ssa_dictionary_stats.argtypes = [P(i64), P(i64)]
+    lib.ssa_dictionary_stats.restype = None
     lib.ssa_program_apply_device.argtypes = [vp, vp, P(vp), P(vp)]
     lib.ssa_program_apply_device.restype = i32
     lib.ssa_batch_export.argtypes = [vp, vp, P(ArrowArray), P(ArrowSchema), P(vp)]

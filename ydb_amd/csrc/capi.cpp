@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -349,19 +350,40 @@ int ssa_batch_from_device(const ssa_device_column* cols, size_t ncols, int64_t r
         col.Field.Type = c.type;
         col.Length = rows;
         if (c.type < T_BOOL || c.type > T_DEC128) return Fail(Status::Invalid("bad column type"), err);
-        const int w = IsStringLike(c.type) ? 4 : TypeWidth(c.type);
-        size_t bytes = (c.type == T_BOOL) ? size_t((rows + 7) / 8) : size_t(rows + (IsStringLike(c.type) ? 1 : 0)) * w;
-        col.Values = Buffer::Wrap(const_cast<void*>(c.values), bytes);
         if (c.validity && c.null_count != 0) {
             col.Validity = Buffer::Wrap(const_cast<uint8_t*>(c.validity), size_t((rows + 7) / 8));
             col.Field.Nullable = true;
         }
         col.NullCount = c.validity ? c.null_count : 0;
+        if (c.index_type != 0) {  // dictionary-encoded: values = codes, chars / dict_offsets = the dictionary
+            if (!IsStringLike(c.type)) return Fail(Status::Unsupported("dictionary of non-string values"), err);
+            if (!IsInt(c.index_type)) return Fail(Status::Invalid("dictionary index type"), err);
+            if (c.dict_size < 0 || (c.dict_size > 0 && !c.dict_offsets)) return Fail(Status::Invalid("dictionary without offsets"), err);
+            auto dict = std::make_shared<DictInfo>();
+            dict->IndexType = c.index_type;
+            dict->Entries.Field.Type = c.type;
+            dict->Entries.Field.Name = col.Field.Name;
+            dict->Entries.Length = c.dict_size;
+            dict->Entries.Values = Buffer::Wrap(const_cast<int32_t*>(c.dict_offsets), size_t(c.dict_size + 1) * 4);
+            dict->Entries.Chars = Buffer::Wrap(const_cast<uint8_t*>(c.chars), size_t(c.chars_size) + 16);
+            col.Values = Buffer::Wrap(const_cast<void*>(c.values), size_t(rows) * TypeWidth(c.index_type));
+            col.Dict = dict;
+            batch->Cols.push_back(std::move(col));
+            continue;
+        }
+        const int w = IsStringLike(c.type) ? 4 : TypeWidth(c.type);
+        size_t bytes = (c.type == T_BOOL) ? size_t((rows + 7) / 8) : size_t(rows + (IsStringLike(c.type) ? 1 : 0)) * w;
+        col.Values = Buffer::Wrap(const_cast<void*>(c.values), bytes);
         if (IsStringLike(c.type)) col.Chars = Buffer::Wrap(const_cast<uint8_t*>(c.chars), size_t(c.chars_size) + 16);
         batch->Cols.push_back(std::move(col));
     }
     *out = new ssa_batch{batch};
     return SSA_OK;
+}
+
+void ssa_dictionary_stats(int64_t* steps_on_codes, int64_t* columns_decoded) {
+    if (steps_on_codes) *steps_on_codes = ssa::gDictStepsOnCodes.load();
+    if (columns_decoded) *columns_decoded = ssa::gDictColumnsDecoded.load();
 }
 
 int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_batch_t** out, char** err) {
@@ -401,7 +423,9 @@ int ssa_sharding_hash(ssa_program_t* program, const ssa_batch_t* batch, const ch
     std::vector<std::string> names;
     for (size_t i = 0; i < n_keys; ++i) names.emplace_back(key_columns[i] ? key_columns[i] : "");
     BufferPtr hashes;
-    Status st = program->Exec->ShardingHash(*batch->Batch, names, seed, hashes);
+    BatchPtr plain;  // dictionary columns as the strings they stand for
+    Status st = program->Exec->DecodedBatch(batch->Batch, plain);
+    if (st.ok()) st = program->Exec->ShardingHash(*plain, names, seed, hashes);
     if (!st.ok()) return Fail(st, err);
     if (batch->Batch->Rows > 0 && out_hashes) {
         if (hipMemcpyAsync(out_hashes, hashes->Ptr, size_t(batch->Batch->Rows) * 8, hipMemcpyDeviceToHost, program->Exec->Stream()) != hipSuccess ||
@@ -424,7 +448,9 @@ int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const c
     for (size_t i = 0; i < n_keys; ++i) names.emplace_back(key_columns[i] ? key_columns[i] : "");
     BatchPtr result;
     std::vector<uint32_t> rows;
-    Status st = program->Exec->ShardingSplit(*batch->Batch, names, shards_count, result, rows);
+    BatchPtr plain;
+    Status st = program->Exec->DecodedBatch(batch->Batch, plain);
+    if (st.ok()) st = program->Exec->ShardingSplit(*plain, names, shards_count, result, rows);
     if (!st.ok()) return Fail(st, err);
     if (out_shard_rows) std::memcpy(out_shard_rows, rows.data(), rows.size() * sizeof(uint32_t));
     *out = new ssa_batch{result};
@@ -497,7 +523,9 @@ int ssa_filter_predicate(ssa_program_t* program, const ssa_batch_t* batch, const
     std::vector<BorderValue> keys;
     for (auto& kv : row) keys.push_back(BorderValue{kv.first, kv.second});
     FilterPtr f;
-    st = program->Exec->FilterPredicate(*batch->Batch, keys, compare_type, f);
+    BatchPtr plain;
+    st = program->Exec->DecodedBatch(batch->Batch, plain);
+    if (st.ok()) st = program->Exec->FilterPredicate(*plain, keys, compare_type, f);
     if (!st.ok()) return Fail(st, err);
     *out = new ssa_filter{f};
     return SSA_OK;

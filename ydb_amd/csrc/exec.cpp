@@ -132,9 +132,11 @@ BufferPtr Buffer::Wrap(void* p, size_t bytes) {
     return b;
 }
 
+int Column::StorageType() const { return Dict ? Dict->IndexType : Field.Type; }
+
 const void* Column::ValuesPtr() const {
     if (!Values) return nullptr;
-    const int w = IsStringLike(Field.Type) ? 4 : TypeWidth(Field.Type);
+    const int w = Dict ? TypeWidth(Dict->IndexType) : IsStringLike(Field.Type) ? 4 : TypeWidth(Field.Type);
     return static_cast<const char*>(Values->Ptr) + ElemOffset * w;
 }
 
@@ -363,41 +365,59 @@ Status Executor::ImportBatch(const ArrowArray* array, const ArrowSchema* schema,
         }
 
         if (dictArr) {
-            // Dictionary-encoded strings: the SSA executor of the reference only ever sees decoded columns
-            // (ydb/core/formats/arrow/dictionary/conversion.h:13-15); decode here with the same result.
+            // Dictionary-encoded strings stay encoded in HBM: the codes and, once, the dictionary.  The reference's executor
+            // only ever sees the decoded column (ydb/core/formats/arrow/dictionary/conversion.h:13-15); steps over the
+            // codes produce that column's results (dict.cpp).
             if (!IsStringLike(type)) return Status::Unsupported("dictionary of non-string values");
             int32_t itype, p2, s2;
             if (!ParseFormat(s->format, itype, p2, s2) || !IsInt(itype)) return Status::Unsupported("dictionary index type");
+            if (dictArr->n_buffers < 3) return Status::Invalid("dictionary without offsets / data buffers");
+            if (dictArr->null_count > 0) return Status::Unsupported("dictionary with null entries");
             const int iw = TypeWidth(itype);
             const char* idx = static_cast<const char*>(a->buffers[1]) + off * iw;
-            const int32_t* doffs = static_cast<const int32_t*>(dictArr->buffers[1]) + dictArr->offset;
-            const char* dchars = static_cast<const char*>(dictArr->buffers[2]);
-            std::vector<int32_t> offs(size_t(n) + 1, 0);
-            std::string chars;
+            const int64_t m = dictArr->length;
             for (int64_t i = 0; i < n; ++i) {
                 const bool valid = validBits.empty() || ((validBits[size_t(i >> 3)] >> (i & 7)) & 1);
-                if (valid) {
-                    int64_t k = 0;
-                    switch (itype) {
-                        case T_I8: k = reinterpret_cast<const int8_t*>(idx)[i]; break;
-                        case T_U8: k = reinterpret_cast<const uint8_t*>(idx)[i]; break;
-                        case T_I16: k = reinterpret_cast<const int16_t*>(idx)[i]; break;
-                        case T_U16: k = reinterpret_cast<const uint16_t*>(idx)[i]; break;
-                        case T_I32: k = reinterpret_cast<const int32_t*>(idx)[i]; break;
-                        case T_U32: k = reinterpret_cast<const uint32_t*>(idx)[i]; break;
-                        case T_I64: k = reinterpret_cast<const int64_t*>(idx)[i]; break;
-                        default: k = int64_t(reinterpret_cast<const uint64_t*>(idx)[i]); break;
-                    }
-                    if (k < 0 || k >= dictArr->length) return Status::Invalid("dictionary index out of range");
-                    chars.append(dchars + doffs[k], size_t(doffs[k + 1] - doffs[k]));
+                if (!valid) continue;
+                int64_t k = 0;
+                switch (itype) {
+                    case T_I8: k = reinterpret_cast<const int8_t*>(idx)[i]; break;
+                    case T_U8: k = reinterpret_cast<const uint8_t*>(idx)[i]; break;
+                    case T_I16: k = reinterpret_cast<const int16_t*>(idx)[i]; break;
+                    case T_U16: k = reinterpret_cast<const uint16_t*>(idx)[i]; break;
+                    case T_I32: k = reinterpret_cast<const int32_t*>(idx)[i]; break;
+                    case T_U32: k = reinterpret_cast<const uint32_t*>(idx)[i]; break;
+                    case T_I64: k = reinterpret_cast<const int64_t*>(idx)[i]; break;
+                    default: k = int64_t(reinterpret_cast<const uint64_t*>(idx)[i]); break;
                 }
-                offs[size_t(i) + 1] = int32_t(chars.size());
+                if (k < 0 || k >= m) return Status::Invalid("dictionary index out of range");
             }
-            col.Values = Buffer::Alloc((size_t(n) + 1) * 4);
-            col.Chars = Buffer::Alloc(chars.size() + 16);
-            if (!col.Values || !col.Chars) return Status::Hip("out of device memory");
-            SSA_HIP(hipMemcpy(col.Values->Ptr, offs.data(), offs.size() * 4, hipMemcpyHostToDevice));
-            if (!chars.empty()) SSA_HIP(hipMemcpy(col.Chars->Ptr, chars.data(), chars.size(), hipMemcpyHostToDevice));
+            auto dict = std::make_shared<DictInfo>();
+            dict->IndexType = itype;
+            dict->Entries.Field.Type = type;
+            dict->Entries.Field.Name = col.Field.Name;
+            dict->Entries.Length = m;
+            {
+                const int32_t* doffs = static_cast<const int32_t*>(dictArr->buffers[1]);
+                const char* dchars = static_cast<const char*>(dictArr->buffers[2]);
+                std::vector<int32_t> rebased(size_t(m) + 1, 0);
+                int32_t first = 0, last = 0;
+                if (doffs) {
+                    first = doffs[dictArr->offset];
+                    last = doffs[dictArr->offset + m];
+                    for (int64_t e = 0; e <= m; ++e) rebased[size_t(e)] = doffs[dictArr->offset + e] - first;
+                }
+                if (last < first) return Status::Invalid("dictionary offsets decrease");
+                dict->Entries.Values = Buffer::Alloc((size_t(m) + 1) * 4 + 16);
+                dict->Entries.Chars = Buffer::Alloc(size_t(last - first) + 16);
+                if (!dict->Entries.Values || !dict->Entries.Chars) return Status::Hip("out of device memory");
+                SSA_HIP(hipMemcpy(dict->Entries.Values->Ptr, rebased.data(), rebased.size() * 4, hipMemcpyHostToDevice));
+                if (last > first) SSA_HIP(hipMemcpy(dict->Entries.Chars->Ptr, dchars + first, size_t(last - first), hipMemcpyHostToDevice));
+            }
+            col.Values = Buffer::Alloc(size_t(n) * iw + 16);
+            if (!col.Values) return Status::Hip("out of device memory");
+            if (n > 0) SSA_HIP(hipMemcpy(col.Values->Ptr, idx, size_t(n) * iw, hipMemcpyHostToDevice));
+            col.Dict = dict;
         } else if (IsStringLike(type)) {
             if (a->n_buffers < 3) return Status::Invalid("string column without offsets / data buffers");
             const int32_t* offs = static_cast<const int32_t*>(a->buffers[1]);
@@ -496,8 +516,22 @@ void InitSchema(ArrowSchema* s, const std::string& format, const std::string& na
 
 }  // namespace
 
-Status Executor::ExportBatch(const Batch& batch, ArrowArray* outArray, ArrowSchema* outSchema) {
+Status Executor::ExportBatch(const Batch& encoded, ArrowArray* outArray, ArrowSchema* outSchema) {
     (void)hipSetDevice(Device);
+    // a dictionary column leaves as the plain column it stands for (what the reference's executor would have produced)
+    Batch decoded;
+    bool anyDict = false;
+    for (const Column& c : encoded.Cols) anyDict = anyDict || bool(c.Dict);
+    if (anyDict) {
+        decoded = encoded;
+        for (Column& c : decoded.Cols) {
+            if (!c.Dict) continue;
+            Column plain;
+            SSA_RETURN_NOT_OK(DecodeColumn(c, decoded.Rows, plain));
+            c = plain;
+        }
+    }
+    const Batch& batch = anyDict ? decoded : encoded;
     SSA_HIP(hipStreamSynchronize(StreamHandle));
     InitSchema(outSchema, "+s", "", false);
     auto* sp = static_cast<ExportedSchema*>(outSchema->private_data);
@@ -688,6 +722,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
         if (d.validity) algoBytes += (in.Rows + 7) / 8;
     }
     for (size_t i = 0; i < plan.Consts.size(); ++i) args.consts[i] = plan.Consts[i];
+    for (size_t i = 0; i < StepTables.size() && i < size_t(kMaxLookupTables); ++i) args.tables[i] = StepTables[i];
     if (plan.Code.size() > size_t(kMaxCode)) return Status::Unsupported("step too long for one scan program");
     std::memcpy(args.pattern, plan.PatternBytes.data(), plan.PatternBytes.size());
     args.nregs = plan.NumRegsUsed;
@@ -875,6 +910,7 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
         a.checks[i].offsets = nullptr;
         a.checks[i].first = 0;
     }
+    for (int i = 0; i < kMaxLookupTables; ++i) a.tables[i] = LookupTable{nullptr, nullptr, 0};
     std::memcpy(image.data(), &a, sizeof(a));
     std::memcpy(reinterpret_cast<char*>(image.data()) + sizeof(ScanArgs), sinkImage, sinkBytes);
     SpecKernel k;
@@ -1000,7 +1036,8 @@ Status Executor::CompactColumn(const Column& src, int64_t rows, const BufferPtr&
     dst = Column();
     dst.Field = src.Field;
     dst.Length = selected;
-    const int type = src.Field.Type;
+    dst.Dict = src.Dict;  // a dictionary column is compacted as its codes
+    const int type = src.StorageType();
     if (IsStringLike(type)) {
         BufferPtr lens = Buffer::Alloc(size_t(selected + 1) * 4 + 16);
         dst.Values = Buffer::Alloc(size_t(selected + 1) * 4 + 16);
@@ -1401,7 +1438,7 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     // scanned as fixed-width keys: the key column becomes the chars buffer read as `len`-byte values, the keys pack
     // exactly and the kernel is the one of integer keys.  The scan still reads the offsets and checks every one of them
     // (OffsetCheck); a batch that turns out otherwise is run again the general way.
-    KeyedHint& hint0 = KeyedHints[&step];
+    KeyedHint& hint0 = KeyedHints[HintOverride ? HintOverride : &step];
     if (!hint0.UniformKeysFailed && in.Rows >= kUniformKeysMinRows && !(plan.NeedsFilteredPositions && plan.HasFilter) &&
         !std::getenv("SSA_NO_UNIFORM_KEYS")) {
         bool done = false;
@@ -1604,7 +1641,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         for (int& src : aggSrc) src = newIndex[size_t(src)];
     }
 
-    KeyedHint& hint = KeyedHints[&step];
+    KeyedHint& hint = KeyedHints[HintOverride ? HintOverride : &step];
     const uint64_t maxCap = std::max<uint64_t>(1024, NextPow2(uint64_t(in.Rows) * 2 + 2));
     uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(hint.TableCap, 1024), maxCap);
 
@@ -1973,8 +2010,15 @@ Status Executor::RunNoKeyAsOneGroup(const TProgramStep& step, const StepPlan& pl
 }
 
 Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out) {
+    for (const Column& c : in->Cols) {
+        if (c.Dict) return ApplyStepDict(step, in, out);
+    }
+    return ApplyStepPlain(step, in, out);
+}
+
+Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out) {
     StepPlan plan;
-    SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FULL, plan));
+    SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FULL, plan, ForceSerializedKeys));
     switch (plan.Kind) {
         case StepPlan::PASS_THROUGH:
         case StepPlan::PROJECT:
@@ -2012,6 +2056,9 @@ Status Executor::FilterFromStepNoAlloc(const TProgramStep& step, const Batch& in
     }
     if (!NoAllocScratch || !StatusWord) return Status::Hip("the static scratch buffer of this device is not available");
     if (!outBits && in.Rows > 0) return Status::Invalid("null output bitmap");
+    for (const Column& c : in.Cols) {
+        if (c.Dict) return Status::Unsupported("a dictionary-encoded column (decoding it would allocate)");
+    }
     StepPlan plan;
     SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_FILTER_ONLY, plan));
     if (in.Rows == 0) return Status::OK();
@@ -2036,8 +2083,10 @@ Status Executor::FilterFromStepNoAlloc(const TProgramStep& step, const Batch& in
     return Status::OK();
 }
 
-Status Executor::BuildFilter(const TProgramStep& step, const BatchPtr& in, std::vector<uint8_t>& bits, int64_t& selected) {
+Status Executor::BuildFilter(const TProgramStep& step, const BatchPtr& inEncoded, std::vector<uint8_t>& bits, int64_t& selected) {
     (void)hipSetDevice(Device);
+    BatchPtr in;
+    SSA_RETURN_NOT_OK(DecodedBatch(inEncoded, in));
     StepPlan plan;
     SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FILTER_ONLY, plan));
     BufferPtr bitmap, tileOffsets;

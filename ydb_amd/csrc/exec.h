@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -49,6 +50,11 @@ struct Buffer {
 };
 using BufferPtr = std::shared_ptr<Buffer>;
 
+struct DictInfo;
+struct DictLowering;
+// Process-wide counters: steps / filters that ran over dictionary codes; whole dictionary columns decoded by a gather.
+extern std::atomic<int64_t> gDictStepsOnCodes, gDictColumnsDecoded;
+
 struct Column {
     FieldDesc Field;         // name, type, nullable (validity present), scalar flag + value
     int64_t Length = 0;
@@ -59,7 +65,31 @@ struct Column {
     int64_t ElemOffset = 0;  // element offset of row 0 inside Values (fixed width / offsets)
     int32_t ValBitOff = 0;   // BOOL: bit offset of row 0 inside Values
     int32_t ValidBitOff = 0;
+    // Dictionary-encoded string / binary column: Values holds the codes (of Dict->IndexType), Field.Type stays the
+    // logical type, Chars is unused.
+    std::shared_ptr<DictInfo> Dict;
     const void* ValuesPtr() const;  // address of row 0
+    int StorageType() const;        // type of the elements of Values: the code type of a dictionary column
+};
+
+// The dictionary of an encoded column, shared by the batches that carry the column, and what has been worked out
+// about it: equal entries (a GROUP BY on codes needs one code per distinct string), and the results of functions
+// evaluated once per entry.
+struct DictInfo {
+    Column Entries;              // the dictionary's values: a plain string / binary column
+    int32_t IndexType = T_I32;
+    std::mutex Lock;             // everything below
+    bool Analysed = false;
+    bool HasDuplicates = false;
+    int64_t EmptyCode = -1;      // smallest code of the empty string, -1 when no entry is empty
+    std::vector<int32_t> Canon;  // per code: the smallest code with the same bytes
+    std::shared_ptr<struct Batch> EntriesAndNull;  // one column: the entries and one null row (input of per-entry evaluation)
+    struct Table {
+        BufferPtr Payload, Valid;  // entries + 1 values (see LookupTable)
+        int32_t Type = T_NONE;
+        bool Nullable = false;
+    };
+    std::map<std::string, Table> Tables;  // function fingerprint -> its per-entry results
 };
 
 struct Batch {
@@ -144,12 +174,25 @@ public:
     // TColumnFilter::Apply: the rows the filter keeps, in order.
     Status FilterApply(const DeviceFilter& f, const BatchPtr& in, BatchPtr& out);
 
+    // `in` itself when it has no dictionary column, else a copy with those columns decoded (a gather through the codes)
+    Status DecodedBatch(const BatchPtr& in, BatchPtr& out);
+
     Status Sync();
     hipStream_t Stream() const { return StreamHandle; }
     KernelProfile Profile;
 
 private:
     Status ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
+    Status ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
+    // -- dictionary-encoded columns (dict.cpp) ---------------------------------------------------------------
+    Status ApplyStepDict(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
+    Status LowerDictStep(const TProgramStep& step, const BatchPtr& in, bool filterOnly, DictLowering& lowering);
+    Status FilterFromStepDict(const TProgramStep& step, const BatchPtr& in, FilterPtr& out);
+    Status FilterFromStepPlain(const TProgramStep& step, const BatchPtr& in, FilterPtr& out);
+    Status AnalyseDictionary(DictInfo& d);
+    Status DecodeColumn(const Column& src, int64_t rows, Column& dst);
+    Status DecodeCodes(const Column& codes, DictInfo& d, Column& dst);
+    Status EntryTable(DictInfo& d, const std::string& column, const TProgramStep& step, const TAssign& fn, DictInfo::Table& out);
     Status RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out);
     Status RunKeyed(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out);
     Status RunNoKeyAsOneGroup(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out);
@@ -181,6 +224,9 @@ private:
     hipEvent_t EvStart = nullptr, EvStop = nullptr;
     hipEvent_t EvTuneA = nullptr, EvTuneB = nullptr;
     BufferPtr StatusWord;   // device uint32
+    std::vector<LookupTable> StepTables;      // lookup tables of the step being run (FillScanArgs copies them)
+    bool ForceSerializedKeys = false;         // the step's string keys have been replaced by codes: still `serialized` semantics
+    const TProgramStep* HintOverride = nullptr;  // the step whose hints a rewritten copy uses
     void* NoAllocScratch = nullptr;  // this device's copy of the static scratch buffer (resolved at construction)
     // Sizing of the two hash-table levels of a keyed step, learnt from its previous run (performance only).
     struct KeyedHint {

@@ -122,6 +122,13 @@ Status Executor::FilterToRuns(const DeviceFilter& f, std::vector<uint32_t>& runs
 }
 
 Status Executor::FilterFromStep(const TProgramStep& step, const BatchPtr& in, FilterPtr& out) {
+    for (const Column& c : in->Cols) {
+        if (c.Dict) return FilterFromStepDict(step, in, out);
+    }
+    return FilterFromStepPlain(step, in, out);
+}
+
+Status Executor::FilterFromStepPlain(const TProgramStep& step, const BatchPtr& in, FilterPtr& out) {
     (void)hipSetDevice(Device);
     if (in->Rows > kMaxFilterRows) return Status::Unsupported("a filter of 2^31 rows or more");
     StepPlan plan;

@@ -178,6 +178,14 @@ constexpr size_t kNoAllocScratchBytes = kNoAllocTotalOffset + 256;
 void* NoAllocScratchFor(int device, hipError_t* error);
 hipError_t LaunchSumTileCounts(const uint32_t* counts, int64_t ntiles, unsigned long long* total, hipStream_t st);
 
+// ---- dictionary-encoded columns -----------------------------------------------------------------------------
+// rows[i] = code i as a row index of the dictionary, ~0 for a null or out-of-range code
+hipError_t LaunchWidenCodes(const void* idx, int type, int64_t n, uint64_t entries, const uint8_t* validity, int64_t validBitOff, uint64_t* rows,
+                            hipStream_t st);
+// a column of n values (any fixed-width type, or bit-packed booleans) as VM payloads + validity bytes: a lookup table
+hipError_t LaunchColumnToPayload(const void* values, int type, int64_t valBitOff, const uint8_t* validity, int64_t validBitOff, int64_t n,
+                                 uint64_t* payload, uint8_t* valid, hipStream_t st);
+
 // ---- compressed IPC bodies ---------------------------------------------------------------------------------
 // One block of an LZ4 frame (https://github.com/lz4/lz4/blob/dev/doc/lz4_Frame_format.md).
 struct Lz4BlockRef {

@@ -1048,7 +1048,13 @@ struct Compiler {
                     if (!e) return Status::Invalid("Not found column '" + arg.ColumnName + "' or duplicate");
                     args.push_back(e);
                 }
-                Status st = a.IsYqlKernel ? YqlFunction(a, args, res) : SimpleFunction(a, args, res);
+                Status st;
+                if (a.DictTable >= 0) {
+                    if (args.size() != 1 || !IsInt(args[0]->Type)) return Status::Invalid("internal: dictionary lookup over a column that is not integer codes");
+                    st = Unary(OP_LOOKUP, a.DictTable, 0, args[0], a.DictResultType, a.DictResultNullable, res);
+                } else {
+                    st = a.IsYqlKernel ? YqlFunction(a, args, res) : SimpleFunction(a, args, res);
+                }
                 if (!st.ok()) return st;
             }
             Env.emplace_back(a.GetName(), res);

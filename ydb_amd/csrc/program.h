@@ -93,6 +93,12 @@ struct TAssign {
     uint32_t KernelIdx = 0;
     std::optional<uint32_t> YqlOperationId;
 
+    // Set by the executor, never by the parser: the function has been evaluated once per entry of a dictionary and
+    // this assign reads the result through the dictionary codes in Arguments[0] (lookup table `DictTable` of the step).
+    int DictTable = -1;
+    int32_t DictResultType = T_NONE;
+    bool DictResultNullable = false;
+
     bool IsConstant() const { return Operation == EOperation::Constant; }
     bool IsOk() const { return Operation != EOperation::Unspecified || IsYqlKernel; }
     const std::string& GetName() const { return Column.ColumnName; }

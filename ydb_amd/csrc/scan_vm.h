@@ -1050,6 +1050,20 @@ struct Machine {
             A.ok = ok;
             break;
         }
+        case OP_LOOKUP: {
+            const uint64_t* payload = a.tables[fa].payload;
+            const uint8_t* valid = a.tables[fa].valid;
+            const uint64_t n = a.tables[fa].n;
+            uint32_t ok = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t e = (((A.ok >> u) & 1u) && A.v[u] < n) ? A.v[u] : n;  // (a negative code is a huge unsigned one)
+                A.v[u] = payload[e];
+                ok |= uint32_t(valid[e] != 0) << u;
+            }
+            A.ok = ok;
+            break;
+        }
         case OP_CMP: {
             uint32_t lt, eq, un;
             CompareMasks<U>(fa, A.v, B.v, lt, eq, un);

@@ -161,6 +161,7 @@ enum OpCode : int32_t {
     OP_FUNC,      // A = f(A, B)          a = TypeId of the operands, b = FuncId; unary functions ignore B
     OP_RFUNC,     // A = f(B, A)
     OP_SELECT,    // A = (A != 0) ? B : R[a]   value and validity of the chosen side (YQL BlockIf)
+    OP_LOOKUP,    // A = table a [A]: A holds a dictionary code; null and out-of-range codes read the table's last entry
 };
 
 // Functions of OP_FUNC: the custom-registry kernels of ydb/library/arrow_kernels/func_{gcd,lcm,modulo,modulo_or_zero,
@@ -195,6 +196,7 @@ constexpr int kMaxKeys = 6;
 constexpr int kMaxOuts = 12;
 constexpr int kMaxPatternBytes = 256;  // all string constants of one program, concatenated
 constexpr int kMaxOffsetChecks = 4;     // string columns scanned as fixed-width values (see OffsetCheck)
+constexpr int kMaxLookupTables = 8;     // per-dictionary-entry results a step reads through OP_LOOKUP
 
 // Error bits a scan kernel can raise (OR-ed into ScanArgs::status).
 enum ScanStatus : uint32_t {
@@ -317,6 +319,14 @@ struct OffsetCheck {
     uint32_t len;
 };
 
+// A function of one dictionary-encoded column (and constants) evaluated once per dictionary entry: entry e < n holds
+// the result for code e, entry n the result for a null (or out-of-range) code.  Values are VM payloads.
+struct LookupTable {
+    const uint64_t* payload;  // n + 1 entries
+    const uint8_t* valid;     // n + 1 entries, 1 = non-null
+    uint64_t n;
+};
+
 struct ScanArgs {
     int64_t nrows;
     int32_t ncols;
@@ -339,6 +349,7 @@ struct ScanArgs {
     int32_t debug_flags;            // diagnostics only: 1 = skip staging, 2 = skip evaluation (timing experiments)
     int32_t nchecks;
     OffsetCheck checks[kMaxOffsetChecks];
+    LookupTable tables[kMaxLookupTables];
 };
 
 }  // namespace ssa

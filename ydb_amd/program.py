@@ -236,11 +236,16 @@ class ProgramContainer:
 
 
 def device_batch(columns: Sequence[Tuple[str, int, int, int, int, int, int]], rows: int, keep=None) -> DeviceBatch:
-    """Wraps device pointers: (name, ssa_type, values_ptr, validity_ptr, chars_ptr, chars_size, null_count)."""
+    """Wraps device pointers: (name, ssa_type, values_ptr, validity_ptr, chars_ptr, chars_size, null_count) and, for a
+    dictionary-encoded string column, three more: (..., index_type, dict_offsets_ptr, dict_size) with values_ptr = the
+    codes and chars_ptr = the dictionary's bytes."""
     lib = _lib.load()
     arr = (_lib.DeviceColumn * len(columns))()
     names = []
-    for i, (name, typ, values, validity, chars, chars_size, null_count) in enumerate(columns):
+    for i, column in enumerate(columns):
+        name, typ, values, validity, chars, chars_size, null_count = column[:7]
+        if len(column) > 7:
+            arr[i].index_type, arr[i].dict_offsets, arr[i].dict_size = column[7], column[8], column[9]
         nb = name.encode()
         names.append(nb)
         arr[i].name = nb

@@ -168,6 +168,20 @@ class DeviceLineitem:
                 desc.append((name, T["string"], self.t["rf_offsets"].data_ptr(), 0, self.t["rf_chars"].data_ptr(), self.nrows, 0))
             elif name == "l_linestatus":
                 desc.append((name, T["string"], self.t["ls_offsets"].data_ptr(), 0, self.t["ls_chars"].data_ptr(), self.nrows, 0))
+            elif name in ("l_returnflag_dict", "l_linestatus_dict"):
+                # the flag as a dictionary-encoded string column: the 1-byte codes the generator wrote + their letters
+                import torch
+                rf = name == "l_returnflag_dict"
+                letters = b"ANR" if rf else b"FO"
+                key = "rf_dict" if rf else "ls_dict"
+                if key not in self.t:
+                    dev = self.t["l_shipdate"].device
+                    self.t[key] = (torch.tensor(list(letters) + [0] * 16, dtype=torch.uint8, device=dev),
+                                   torch.arange(len(letters) + 1, dtype=torch.int32, device=dev))
+                    torch.cuda.synchronize(dev)
+                chars, offs = self.t[key]
+                desc.append((name[:-5], T["string"], self.t["rf_code" if rf else "ls_code"].data_ptr(), 0, chars.data_ptr(),
+                             len(letters), 0, T["int8"], offs.data_ptr(), len(letters)))
             elif name == "l_returnflag_code":
                 desc.append((name, T["int8"], self.t["rf_code"].data_ptr(), 0, 0, 0, 0))
             elif name == "l_linestatus_code":
@@ -179,4 +193,5 @@ class DeviceLineitem:
 
 Q6_COLUMNS = ["l_shipdate", "l_discount", "l_quantity", "l_extendedprice"]
 Q1_COLUMNS_UTF8 = ["l_shipdate", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus"]
+Q1_COLUMNS_DICT = ["l_shipdate", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag_dict", "l_linestatus_dict"]
 Q1_COLUMNS_CODES = ["l_shipdate", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag_code", "l_linestatus_code"]
