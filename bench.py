@@ -273,6 +273,37 @@ def main():
         if not args.no_cpu_baseline:
             also_out[k]["cpu_baseline"] = cpu_baseline(k, seconds_target=8.0, all_cores_seconds=4.0)
 
+    if also and rows >= 64 << 20:
+        # The same Q1 over the table cut into 64 slices of 2^20 rows -- the batch size a column shard hands its program
+        # (program.h:423-433 runs the slices one by one) -- through ssa_program_apply_many: one result per slice, the
+        # slices scanned by one launch.
+        from ydb_amd.program import ProgramContainer
+        per, nslices = 1 << 20, 64
+        prog, cols, bpr, name = tpch_workload("q1")
+        pc = ProgramContainer(local_rank)
+        ok, err = pc.Init(resolver, prog)
+        if not ok:
+            raise SystemExit(err)
+        slices = [li.batch(cols, row0=i * per, rows=per) for i in range(nslices)]
+        for _ in range(3):
+            pc.ApplyDeviceMany(slices)
+        pc.EnableProfile(True)
+        pc.ReadProfile()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = pc.ApplyDeviceMany(slices)
+        barrier()
+        e = time.perf_counter() - t0
+        kernel_ms, launches, algo_bytes = pc.ReadProfile()
+        pc.EnableProfile(False)
+        also_out["q1_slices"] = {"workload": f"{name}, {nslices} slices of {per} rows of the resident table, one result per slice "
+                                             "(ssa_program_apply_many)",
+                                 "value": per * nslices * args.steps / e, "unit": "rows/s", "ms_per_step": 1e3 * e / args.steps,
+                                 "groups_per_slice": res[0].rows, "algorithmic_bytes_per_row": bpr,
+                                 "roofline": roofline_of("q1_slices", prog, kernel_ms, launches, algo_bytes, pc.SpecializationStats()[2])}
+        del res, slices
+
     if rank == 0:
         result = results[0]
         groups = result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0)

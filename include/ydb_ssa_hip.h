@@ -48,6 +48,11 @@ enum { SSA_PROGRAM_OLAP_WRAPPER = 1, SSA_PROGRAM_DIRECT_OPERATIONS = 2, SSA_DIRE
 /* Library / device set-up.  Returns the number of visible HIP devices or a negative ssa_status. */
 int ssa_device_count(void);
 const char* ssa_version(void);
+/* Ends the background builds of scan kernels: a build in progress is waited for, later scans run the kernels the
+ * library was built with.  Call it before the process exits when scans of small batches may have started a build in the
+ * last seconds (the compiler must not be at work while the process tears its libraries down); the Python mirror does
+ * so from an atexit hook.  No counterpart in the reference. */
+void ssa_shutdown(void);
 /* Frees a message returned through an `err` out-parameter. */
 void ssa_free_string(char* s);
 
@@ -162,6 +167,15 @@ void ssa_dictionary_stats(int64_t* steps_on_codes, int64_t* columns_decoded);
 
 /* TProgram::ApplyTo on an HBM-resident batch; the result stays in HBM. */
 int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_batch_t** out, char** err);
+/* TProgram::ApplyTo on each of `n` HBM-resident batches -- the slices of a table, which the reference runs one by one
+ * (ydb/core/formats/arrow/program.h:423-433) -- with one result per slice in out[0 .. n), not merged.  Slices of one
+ * schema whose step is an aggregation (GROUP BY over fixed-width keys or string keys of one length, or no keys) are
+ * scanned by one kernel launch with one host synchronisation for all of them; anything else runs slice by slice, with
+ * the same results.  On failure no batch is returned. */
+int ssa_program_apply_many(ssa_program_t* program, const ssa_batch_t* const* in, size_t n, ssa_batch_t** out, char** err);
+/* Process-wide counters: program steps ssa_program_apply_many ran over all their slices with one launch, and steps it
+ * ran slice by slice. */
+void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_slice);
 /* Download a batch into Arrow C Data structures. */
 int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, struct ArrowArray* out,
                      struct ArrowSchema* out_schema, char** err);

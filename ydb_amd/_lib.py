@@ -40,10 +40,10 @@ class LineitemColumns(ctypes.Structure):
 
 # Every symbol include/ydb_ssa_hip.h declares.
 EXPORTED_SYMBOLS = [
-    "ssa_device_count", "ssa_version", "ssa_free_string", "ssa_program_create", "ssa_program_destroy",
+    "ssa_device_count", "ssa_version", "ssa_shutdown", "ssa_free_string", "ssa_program_create", "ssa_program_destroy",
     "ssa_program_debug_string", "ssa_program_source_columns", "ssa_program_early_filter_columns",
     "ssa_program_step_count", "ssa_program_explain", "ssa_program_apply", "ssa_program_build_filter", "ssa_batch_import",
-    "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_batch_export", "ssa_batch_rows",
+    "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_program_apply_many", "ssa_apply_many_stats", "ssa_batch_export", "ssa_batch_rows",
     "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
     "ssa_gen_lineitem",
     "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
@@ -75,6 +75,10 @@ def load() -> ctypes.CDLL:
     vp, cp, i64, i32, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
     lib.ssa_device_count.restype = i32
     lib.ssa_version.restype = cp
+    lib.ssa_shutdown.argtypes = []
+    lib.ssa_shutdown.restype = None
+    import atexit
+    atexit.register(lib.ssa_shutdown)  # no kernel build may be running while the process unloads its libraries
     lib.ssa_free_string.argtypes = [vp]
     lib.ssa_program_create.argtypes = [vp, sz, i32, P(ctypes.c_uint32), P(cp), sz, P(ArrowArray), P(ArrowSchema), i32,
                                        P(vp), P(vp)]
@@ -97,6 +101,10 @@ def load() -> ctypes.CDLL:
     lib.ssa_batch_from_device.restype = i32
     lib.ssa_dictionary_stats.argtypes = [P(i64), P(i64)]
     lib.ssa_dictionary_stats.restype = None
+    lib.ssa_program_apply_many.argtypes = [vp, P(vp), sz, P(vp), P(vp)]
+    lib.ssa_program_apply_many.restype = i32
+    lib.ssa_apply_many_stats.argtypes = [P(i64), P(i64)]
+    lib.ssa_apply_many_stats.restype = None
     lib.ssa_program_apply_device.argtypes = [vp, vp, P(vp), P(vp)]
     lib.ssa_program_apply_device.restype = i32
     lib.ssa_batch_export.argtypes = [vp, vp, P(ArrowArray), P(ArrowSchema), P(vp)]

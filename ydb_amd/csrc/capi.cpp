@@ -400,6 +400,32 @@ int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_
     return SSA_OK;
 }
 
+int ssa_program_apply_many(ssa_program_t* program, const ssa_batch_t* const* in, size_t n, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    if (n > 0 && (!in || !out)) return Fail(Status::Invalid("null batch array"), err);
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    std::vector<BatchPtr> batches, results;
+    for (size_t i = 0; i < n; ++i) {
+        if (!in[i]) return Fail(Status::Invalid("null batch"), err);
+        batches.push_back(in[i]->Batch);
+    }
+    Status st = program->Exec->ApplyProgramMany(*program->Container.GetProgram(), batches, results);
+    if (!st.ok()) return Fail(st, err);
+    for (size_t i = 0; i < n; ++i) out[i] = new ssa_batch{results[i]};
+    return SSA_OK;
+}
+
+void ssa_shutdown(void) { ssa::KernelJit::Instance().Shutdown(); }
+
+void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_slice) {
+    if (steps_in_one_launch) *steps_in_one_launch = ssa::gManyStepsOneLaunch.load();
+    if (steps_slice_by_slice) *steps_slice_by_slice = ssa::gManyStepsPerSlice.load();
+}
+
 int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, ArrowArray* out, ArrowSchema* out_schema, char** err) {
     if (err) *err = nullptr;
     std::lock_guard<std::mutex> g(program->Lock);

@@ -868,6 +868,7 @@ Status Executor::FillScanArgs(const StepPlan& plan, const Batch& in, int sinkLds
     perCU = std::max(1, std::min(perCU, 8));
     int64_t grid = std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU);
     cfg.grid = int(grid);
+    cfg.max_grid = 256 * perCU;
     cfg.lds_bytes = uint32_t(lds);
     cfg.stream = StreamHandle;
     return Status::OK();
@@ -911,6 +912,8 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
         a.checks[i].first = 0;
     }
     for (int i = 0; i < kMaxLookupTables; ++i) a.tables[i] = LookupTable{nullptr, nullptr, 0};
+    a.slices = nullptr;
+    a.block_slice = nullptr;
     std::memcpy(image.data(), &a, sizeof(a));
     std::memcpy(reinterpret_cast<char*>(image.data()) + sizeof(ScanArgs), sinkImage, sinkBytes);
     SpecKernel k;
@@ -947,6 +950,7 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
     int perCU = std::max(1, std::min(want, k.BlocksPerCU));
     if (const char* pc = std::getenv("SSA_SPEC_BLOCKS_PER_CU")) perCU = std::max(1, std::min(8, std::atoi(pc)));  // experiments
     cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU));
+    cfg.max_grid = 256 * perCU;
     if (const char* g = std::getenv("SSA_SPEC_GRID")) cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), std::atoi(g)));  // experiments
     return k.Function;
 }
@@ -1547,9 +1551,103 @@ Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan,
     return Status::OK();
 }
 
+// The slices of a launch as the kernel reads them: each slice's column addresses, its share of the grid (in proportion
+// to its tiles, at least one workgroup) and its table.  `args` / `cfg` are those of the first slice; the other slices
+// must fit the LDS plan made for it (same types, validity where it has validity, aligned where its columns are staged).
+Status Executor::DescribeSlices(const StepPlan& plan, ManySlices& many, ScanArgs& args, int64_t tileRows, uint64_t cap, LaunchCfg& cfg,
+                                BufferPtr& descs, BufferPtr& map) {
+    const size_t n = many.In.size();
+    std::vector<int64_t> tiles(n);
+    int64_t totalTiles = 0;
+    for (size_t i = 0; i < n; ++i) {
+        tiles[i] = (many.In[i]->Rows + tileRows - 1) / tileRows;
+        totalTiles += tiles[i];
+    }
+    const int64_t wanted = std::max<int64_t>(1, std::min<int64_t>(totalTiles, std::max(cfg.max_grid, 1)));
+    many.HostDescs.assign(n, SliceDesc{});
+    many.HostMap.clear();
+    for (size_t i = 0; i < n; ++i) {
+        const Batch& b = *many.In[i];
+        SliceDesc& d = many.HostDescs[i];
+        d.nrows = b.Rows;
+        d.table_off = uint64_t(i) * cap;
+        int64_t blocks = tiles[i] == 0 ? 0 : std::max<int64_t>(1, std::min<int64_t>(tiles[i], wanted * tiles[i] / std::max<int64_t>(totalTiles, 1)));
+        d.first_block = int32_t(many.HostMap.size());
+        d.nblocks = int32_t(blocks);
+        for (int64_t k = 0; k < blocks; ++k) many.HostMap.push_back(int32_t(i));
+        if (b.Cols.size() != many.In[0]->Cols.size()) return Status::Unsupported("slices in one launch: differing schemas");
+        for (int c = 0; c < args.ncols; ++c) {
+            const Column& col = b.Cols[size_t(plan.SourceColumns[size_t(c)])];
+            DevColumn& dc = d.cols[c];
+            dc.values = col.ValuesPtr();
+            dc.validity = col.Validity ? static_cast<const uint8_t*>(col.Validity->Ptr) : nullptr;
+            dc.chars = col.Chars ? static_cast<const uint8_t*>(col.Chars->Ptr) : nullptr;
+            dc.type = col.Field.Type;
+            dc.chars_bytes = col.Chars ? int32_t(std::min<size_t>(col.Chars->Size, size_t(INT32_MAX))) : 0;
+            dc.val_bit_off = col.ValBitOff;
+            dc.valid_bit_off = col.ValidBitOff;
+            const DevColumn& first = args.cols[c];
+            if (dc.type != first.type || (dc.validity != nullptr) != (first.validity != nullptr) || col.Dict) {
+                return Status::Unsupported("slices in one launch: differing schemas");
+            }
+            if (args.lds_col_off[c] >= 0 && (reinterpret_cast<uintptr_t>(dc.values) & 15)) return Status::Unsupported("slices in one launch: an unaligned column");
+            if (args.lds_chars_off[c] >= 0 && (reinterpret_cast<uintptr_t>(dc.chars) & 15)) return Status::Unsupported("slices in one launch: an unaligned column");
+        }
+        if (i < many.Checks.size()) {
+            if (many.Checks[i].size() != size_t(args.nchecks)) return Status::Invalid("internal: offset checks of a slice");
+            for (size_t k = 0; k < many.Checks[i].size(); ++k) d.checks[k] = many.Checks[i][k];
+        } else if (args.nchecks != 0) {
+            return Status::Invalid("internal: offset checks of a slice");
+        }
+    }
+    if (many.HostMap.empty()) many.HostMap.push_back(0);  // (no rows at all: one workgroup that finds no tile)
+    descs = Buffer::Alloc(n * sizeof(SliceDesc) + 64);
+    map = Buffer::Alloc(many.HostMap.size() * 4 + 64);
+    if (!descs || !map) return Status::Hip("out of device memory");
+    SSA_HIP(hipMemcpyAsync(descs->Ptr, many.HostDescs.data(), n * sizeof(SliceDesc), hipMemcpyHostToDevice, StreamHandle));
+    SSA_HIP(hipMemcpyAsync(map->Ptr, many.HostMap.data(), many.HostMap.size() * 4, hipMemcpyHostToDevice, StreamHandle));
+    args.slices = static_cast<const SliceDesc*>(descs->Ptr);
+    args.block_slice = static_cast<const int32_t*>(map->Ptr);
+    cfg.grid = int(many.HostMap.size());
+    return Status::OK();
+}
+
+// Bytes a scan of `in` has to read: every source column of the plan once.
+static int64_t AlgorithmicBytes(const StepPlan& plan, const Batch& in) {
+    int64_t bytes = 0;
+    for (int ci : plan.SourceColumns) {
+        const Column& col = in.Cols[size_t(ci)];
+        if (IsStringLike(col.Field.Type)) {
+            bytes += (in.Rows + 1) * 4;
+            bytes += col.Chars ? int64_t(col.Chars->Size > 16 ? col.Chars->Size - 16 : 0) : 0;
+        } else if (col.Field.Type == T_BOOL) {
+            bytes += (in.Rows + 7) / 8;
+        } else {
+            bytes += in.Rows * TypeWidth(col.Field.Type);
+        }
+        if (col.Validity) bytes += (in.Rows + 7) / 8;
+    }
+    return bytes;
+}
+
+// `many`: the scan covers several slices of one schema in one launch (`in` is the first of them, the plan and the LDS
+// layout are made for it); the result holds the groups of all slices, slice after slice.
 Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
-                              const std::vector<OffsetCheck>& checks, bool* notUniform) {
+                              const std::vector<OffsetCheck>& checks, bool* notUniform, ManySlices* many) {
     *notUniform = false;
+    const size_t nslices = many ? many->In.size() : 1;
+    int64_t totalRows = in.Rows, maxRows = in.Rows;
+    if (many) {
+        totalRows = maxRows = 0;
+        for (const Batch* b : many->In) {
+            totalRows += b->Rows;
+            maxRows = std::max(maxRows, b->Rows);
+        }
+        if (plan.NeedsFilteredPositions && plan.HasFilter) return Status::Unsupported("slices in one launch: a step that filters first");
+        for (const AggPlan& ap : plan.Aggs) {
+            if (ap.SomeInputColumn >= 0) return Status::Unsupported("slices in one launch: an aggregate that gathers input rows");
+        }
+    }
     if (plan.NeedsFilteredPositions && plan.HasFilter) {
         // The result depends on where the rows stand in the filtered batch: filter first, as the reference does
         // (TProgramStep::ApplyFilters, program.cpp:798-832), then aggregate the compacted columns.
@@ -1594,6 +1692,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
     }
     const bool twoWords = hashed || keyBits > 63;
+    if (many && hashed) return Status::Unsupported("slices in one launch: string or wide keys");
 
     // Aggregates that read the same operand the same way share one accumulator (COUNT(a), COUNT(b) and COUNT(*) over
     // non-null columns are one counter).
@@ -1642,7 +1741,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     }
 
     KeyedHint& hint = KeyedHints[HintOverride ? HintOverride : &step];
-    const uint64_t maxCap = std::max<uint64_t>(1024, NextPow2(uint64_t(in.Rows) * 2 + 2));
+    const uint64_t maxCap = std::max<uint64_t>(1024, NextPow2(uint64_t(maxRows) * 2 + 2));
     uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(hint.TableCap, 1024), maxCap);
 
     // Level-1 accumulators are replicated only when the table path carries the bulk of the updates: steps whose
@@ -1685,6 +1784,10 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         for (size_t i = 0; i < checks.size(); ++i) {
             args.checks[i] = checks[i];
             algoBytes += (in.Rows + 1) * 4;  // the offsets are read (and checked), not staged
+        }
+        if (many) {
+            algoBytes = 0;
+            for (const Batch* b : many->In) algoBytes += AlgorithmicBytes(plan, *b) + int64_t(checks.size()) * (b->Rows + 1) * 4;
         }
         sink = KeyedSink{};
         sink.use_hot = 1;
@@ -1755,25 +1858,33 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         std::fprintf(stderr, "\n");
     }
     BufferPtr tLo, tHi, tAcc, tSeen, tRep;
+    BufferPtr sliceDescs, blockSlices;  // a launch over slices: its descriptors on the device
+    uint64_t totalCap = 0;
     for (;;) {
-        tLo = Buffer::Alloc(cap * 8);
-        tHi = Buffer::Alloc(twoWords ? cap * 8 : 64);
-        tAcc = Buffer::Alloc(size_t(naggs) * cap * 8);
-        tSeen = Buffer::Alloc(cap * 4);
-        tRep = Buffer::Alloc(hashed ? cap * 8 : 64);
+        totalCap = cap * nslices;  // every slice has a table of its own, one after the other
+        tLo = Buffer::Alloc(totalCap * 8);
+        tHi = Buffer::Alloc(twoWords ? totalCap * 8 : 64);
+        tAcc = Buffer::Alloc(size_t(naggs) * totalCap * 8);
+        tSeen = Buffer::Alloc(totalCap * 4);
+        tRep = Buffer::Alloc(hashed ? totalCap * 8 : 64);
         if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
         for (KeyedSink* k : {&sink, &ssink}) {
             k->table_mask = cap - 1;
+            k->acc_stride = totalCap;
             k->t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
             k->t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
             k->t_acc = static_cast<uint64_t*>(tAcc->Ptr);
             k->t_seen = static_cast<uint32_t*>(tSeen->Ptr);
             k->t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
         }
-        SSA_HIP(LaunchKeyedTableInit(sink, twoWords != 0, hashed, StreamHandle));
+        {
+            KeyedSink all = sink;
+            all.table_mask = totalCap - 1;  // (the capacity, not a mask, when there are several tables)
+            SSA_HIP(LaunchKeyedTableInit(all, twoWords != 0, hashed, StreamHandle));
+        }
         bool timedRun = false;
         int hotMode = 1;
-        if (in.Rows > 0) {
+        if (totalRows > 0) {
             // a scan of many rows runs the kernel built for this step program, when that can be had
             hipFunction_t spec = nullptr;
             LaunchCfg specCfg = scfg;
@@ -1781,7 +1892,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 // register-held groups on or off: as decided, else the way not yet timed
                 if (const char* env = std::getenv("SSA_KEYED_HOT")) hint.HotChoice = std::atoi(env) != 0 ? 1 : 0;
                 hotMode = hint.HotChoice >= 0 ? hint.HotChoice : (hint.MsPerRowOn == 0 ? 1 : 0);
-                timedRun = hint.HotChoice < 0 && in.Rows >= (int64_t(1) << 22);
+                timedRun = hint.HotChoice < 0 && totalRows >= (int64_t(1) << 22) && (!many || maxRows >= (int64_t(1) << 16));
                 if (hint.HotChoice < 0 && !timedRun) hotMode = 1;
                 ssink.use_hot = hotMode;
                 KeyedSink image = ssink;
@@ -1789,14 +1900,20 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 image.t_seen = nullptr;
                 image.t_rep_row = nullptr;
                 image.table_mask = 0;
+                image.acc_stride = 0;
                 std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(specRows) + "\n#define SSA_SPEC_HASHED " +
                                       (hashed ? "1" : "0") + "\n";
                 if (std::getenv("SSA_PHASE_TIMING")) defines += "#define SSA_PHASE_TIMING 1\n";  // diagnostics
                 ScanRowsPerThread = specRows;
-                spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, sargs, &image, sizeof(image), in.Rows, specCfg);
+                spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, sargs, &image, sizeof(image), totalRows, specCfg);
                 ScanRowsPerThread = kRowsPerThread;
             }
             timedRun = timedRun && spec != nullptr;
+            if (many) {
+                ScanArgs& la = spec ? sargs : args;
+                LaunchCfg& lc = spec ? specCfg : cfg;
+                SSA_RETURN_NOT_OK(DescribeSlices(plan, *many, la, int64_t(kBlock) * (spec ? specRows : kRowsPerThread), cap, lc, sliceDescs, blockSlices));
+            }
             ProfileBegin();
             if (spec) {
                 if (timedRun) SSA_HIP(hipEventRecord(EvTuneA, StreamHandle));
@@ -1832,6 +1949,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     }
 
     // groups per tile of table slots, scanned: where each tile's groups go in the output
+    cap = totalCap;  // (from here on the tables of all slices are one table: its slots in order are the slices in order)
     const int64_t ntilesT = int64_t(cap / kTileRows);
     BufferPtr tileCounts = Buffer::Alloc(size_t(ntilesT) * 4 + 64);
     BufferPtr tileOffsets = Buffer::Alloc(size_t(ntilesT + 1 + (ntilesT + 4095) / 4096 + 2) * 8 + 64);
@@ -1842,15 +1960,26 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                            static_cast<int64_t*>(counter->Ptr), StreamHandle));
     int64_t ngroups = 0;
     SSA_HIP(hipMemcpyAsync(&ngroups, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    if (many) {  // where each slice's groups begin: the offsets of the first tile of each table
+        many->GroupStart.assign(nslices + 1, 0);
+        const size_t tilesPerSlice = size_t(ntilesT) / nslices;
+        SSA_HIP(hipMemcpy2DAsync(many->GroupStart.data(), 8, tileOffsets->Ptr, tilesPerSlice * 8, 8, nslices, hipMemcpyDeviceToHost, StreamHandle));
+    }
     SSA_HIP(hipStreamSynchronize(StreamHandle));
+    int64_t maxGroups = ngroups;
+    if (many) {
+        many->GroupStart[nslices] = ngroups;
+        maxGroups = 0;
+        for (size_t i = 0; i < nslices; ++i) maxGroups = std::max(maxGroups, many->GroupStart[i + 1] - many->GroupStart[i]);
+    }
 
     // next call on this step: size both table levels for what was seen
-    hint.TableCap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(ngroups) * 2), 1024), maxCap);  // load 0.25 .. 0.5
+    hint.TableCap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(maxGroups) * 2), 1024), maxCap);  // load 0.25 .. 0.5
     // Groupings of many groups keep a level-1 table too: it fills with the first 256 groups each workgroup meets, and
     // those include the heavy hitters of a skewed key (an empty search phrase, the busiest users), whose rows would
     // otherwise queue on single addresses in HBM (ClickBench SearchPhrase: 1046 ms without level 1, 3.6 ms with it).
-    hint.LdsCap = ngroups <= 8 ? 16 : 256;
-    hint.ManyGroups = ngroups > 128;
+    hint.LdsCap = maxGroups <= 8 ? 16 : 256;
+    hint.ManyGroups = maxGroups > 128;
 
     KeyedFinalizeArgs fa{};
     fa.capacity = cap;

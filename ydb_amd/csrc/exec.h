@@ -54,6 +54,8 @@ struct DictInfo;
 struct DictLowering;
 // Process-wide counters: steps / filters that ran over dictionary codes; whole dictionary columns decoded by a gather.
 extern std::atomic<int64_t> gDictStepsOnCodes, gDictColumnsDecoded;
+// ... sets of slices (of one schema, under one step) that ApplyProgramMany scanned with one launch; sets it ran slice by slice.
+extern std::atomic<int64_t> gManyStepsOneLaunch, gManyStepsPerSlice;
 
 struct Column {
     FieldDesc Field;         // name, type, nullable (validity present), scalar flag + value
@@ -128,6 +130,15 @@ struct BorderValue {
     TScalar Value;  // numbers as the VM payload (floats widened to double), strings as bytes
 };
 
+// Several slices of one schema scanned by one launch (Executor::ApplyProgramMany).
+struct ManySlices {
+    std::vector<const Batch*> In;                  // every slice; In[0] is the batch the plan was made for
+    std::vector<std::vector<OffsetCheck>> Checks;  // per slice, or empty
+    std::vector<int64_t> GroupStart;               // out: the groups of slice i are rows [GroupStart[i], GroupStart[i + 1]) of the result
+    std::vector<SliceDesc> HostDescs;              // what the launch reads, kept until it has been copied
+    std::vector<int32_t> HostMap;
+};
+
 class Executor {
 public:
     explicit Executor(int device);
@@ -143,6 +154,9 @@ public:
 
     // TProgram::ApplyTo: every step in order.
     Status ApplyProgram(const TProgram& program, const BatchPtr& in, BatchPtr& out);
+    // The program applied to each of `in` (slices of a table: program.h:423-433 runs them one by one), one result per
+    // slice.  Slices of one schema (the same columns carry nulls) whose step is an aggregation are scanned by one launch.
+    Status ApplyProgramMany(const TProgram& program, const std::vector<BatchPtr>& in, std::vector<BatchPtr>& out);
     // TProgramStep::BuildFilter for the first step: Arrow-order bitmap (LSB first) of rows*1 bits, on the host.
     Status BuildFilter(const TProgramStep& step, const BatchPtr& in, std::vector<uint8_t>& bits, int64_t& selected);
 
@@ -198,7 +212,10 @@ private:
     Status RunNoKeyAsOneGroup(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out);
     Status RunKeyedUniform(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out, bool& done);
     Status RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
-                        const std::vector<OffsetCheck>& checks, bool* notUniform);
+                        const std::vector<OffsetCheck>& checks, bool* notUniform, ManySlices* many = nullptr);
+    Status DescribeSlices(const StepPlan& plan, ManySlices& many, ScanArgs& args, int64_t tileRows, uint64_t cap, LaunchCfg& cfg,
+                          BufferPtr& descs, BufferPtr& map);
+    Status ApplyStepMany(const TProgramStep& step, const std::vector<BatchPtr>& in, std::vector<BatchPtr>& out);
     Status RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& in, BatchPtr& out);
     Status RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,
                            int64_t& selected);

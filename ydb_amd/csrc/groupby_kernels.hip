@@ -194,6 +194,11 @@ __global__ __launch_bounds__(kBlock) void IotaI32Kernel(int32_t* out, int64_t n,
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) out[i] = int32_t(i) * step;
 }
 
+// out[i] = *addrs[i]: a few words from many places (the first and last offsets of the string columns of many slices)
+__global__ __launch_bounds__(kBlock) void GatherI32AtKernel(const int32_t* const* addrs, int64_t n, int32_t* out) {
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) out[i] = *addrs[i];
+}
+
 struct G128 {
     uint64_t lo, hi;
 };
@@ -283,6 +288,12 @@ hipError_t LaunchGatherFixed(const void* src, const uint8_t* srcValid, int64_t s
         default: return hipErrorInvalidValue;
     }
 #undef SSA_GATHER
+    return hipGetLastError();
+}
+
+hipError_t LaunchGatherI32At(const int32_t* const* addrs, int64_t n, int32_t* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(GatherI32AtKernel, dim3(GridFor(n)), dim3(kBlock), 0, st, addrs, n, out);
     return hipGetLastError();
 }
 

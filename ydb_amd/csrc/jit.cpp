@@ -118,15 +118,20 @@ struct State {
     std::thread Worker;
     bool WorkerStarted = false, Stop = false;
 
-    ~State() {
+    // No more background builds: the queue is dropped, a build in progress is waited for.
+    void StopWorker() {
         {
             std::lock_guard<std::mutex> g(QueueLock);
             Stop = true;
             Queue.clear();
         }
         QueueCv.notify_all();
+        std::lock_guard<std::mutex> j(JoinLock);
         if (Worker.joinable()) Worker.join();
     }
+    std::mutex JoinLock;
+
+    ~State() { StopWorker(); }
 };
 
 State& St() {
@@ -268,8 +273,14 @@ void BuildAndPublish(const Job& job) {
     e.LastUse = Clock::now();
 }
 
+// The compiler's libraries are loaded when they are first needed, so their exit handlers run before the destructor
+// of State: a build still running on the worker thread at that time would work with objects already destroyed.  An
+// exit handler registered after those libraries were loaded runs before theirs, and waits for the worker.
+void StopWorkerAtExit() { St().StopWorker(); }
+
 void WorkerLoop() {
     State& st = St();
+    bool registered = false;
     for (;;) {
         Job job;
         {
@@ -280,6 +291,10 @@ void WorkerLoop() {
             st.Queue.pop_front();
         }
         BuildAndPublish(job);
+        if (!registered) {  // (after the first build: everything the compiler loads is loaded now)
+            std::atexit(StopWorkerAtExit);
+            registered = true;
+        }
     }
 }
 
@@ -328,6 +343,8 @@ void KernelJit::Stats(int64_t& built, double& buildMs, int64_t& launches) const 
 }
 
 void KernelJit::NoteLaunch() { ++St().Launches; }
+
+void KernelJit::Shutdown() { St().StopWorker(); }
 
 bool JitEnabled() {
     const char* mode = std::getenv("SSA_JIT");
@@ -387,9 +404,14 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
             EvictIfNeeded(st);
             if (!buildHere) {
                 std::lock_guard<std::mutex> q(st.QueueLock);
+                if (st.Stop) {  // shut down: no new builds
+                    e.State = Entry::NONE;
+                    return false;
+                }
                 if (!st.WorkerStarted) {
                     st.Worker = std::thread(WorkerLoop);
                     st.WorkerStarted = true;
+                    std::atexit(StopWorkerAtExit);
                 }
                 st.Queue.push_back(std::move(job));
                 st.QueueCv.notify_one();

@@ -41,6 +41,9 @@ public:
     // Process-wide counters: kernels built, host milliseconds spent building them, launches that used one.
     void Stats(int64_t& built, double& buildMs, int64_t& launches) const;
     void NoteLaunch();
+    // Ends background builds (a build in progress is waited for; later requests run the generic kernels).  To be called
+    // before the process exits while a build may be running.
+    void Shutdown();
 
 private:
     KernelJit() = default;

@@ -68,6 +68,8 @@ struct KeyedSink {
     int32_t hot_off[kHotAggs];   // LDS byte offset of its 64-bit operand tile
     int32_t use_hot;             // keep the first groups of a workgroup in registers (else every row goes through the tables)
     int32_t reserved;
+    uint64_t acc_stride;         // slots between the accumulators k and k + 1 of one group in t_acc: the capacity, or the
+                                 // capacities of all slices' tables together (SliceDesc)
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.
@@ -80,6 +82,7 @@ struct KArgs {
 #ifndef __HIPCC_RTC__  // the rest is the host's launch interface
 struct LaunchCfg {
     int grid;
+    int max_grid;         // workgroups the device holds at once for this kernel (the grid of a scan with tiles to spare)
     uint32_t lds_bytes;   // dynamic LDS per workgroup: staged column tiles + R registers + sink area
     hipStream_t stream;
 };
@@ -166,6 +169,8 @@ hipError_t LaunchGatherValidity(const uint8_t* src_valid, int64_t src_valid_off,
                                 uint8_t* dst_valid_bytes, hipStream_t st);
 // out[i] = i * step
 hipError_t LaunchIotaI32(int32_t* out, int64_t n, int32_t step, hipStream_t st);
+// out[i] = *addrs[i] (addrs: device array of device addresses)
+hipError_t LaunchGatherI32At(const int32_t* const* addrs, int64_t n, int32_t* out, hipStream_t st);
 hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, int64_t n, int32_t* out_lens, hipStream_t st);
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);

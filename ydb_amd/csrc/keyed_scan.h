@@ -180,11 +180,11 @@ __device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uin
 // table key is a hash (a string of more than 8 bytes, more than 119 key bits): the hash finds a slot, this decides
 // whether the slot's group is the row's -- equal hashes of different keys end up in different slots.  Such steps take
 // all their keys from input columns.  A string whose offsets do not describe the chars buffer counts as empty.
-__device__ __noinline__ bool SameKeyRows(const ScanArgs& a, const KeyedSink& s, uint64_t r1, uint64_t r2) {
+__device__ __noinline__ bool SameKeyRows(const DevColumn* cols, const KeyedSink& s, uint64_t r1, uint64_t r2) {
     if (r1 == r2) return true;
     for (int k = 0; k < s.nkeys; ++k) {
         const KeySpec& ks = s.keys[k];
-        const DevColumn& col = a.cols[ks.col >= 0 ? ks.col : -2 - ks.reg];
+        const DevColumn& col = cols[ks.col >= 0 ? ks.col : -2 - ks.reg];
         if (ks.col >= 0) {
             const int32_t* offs = static_cast<const int32_t*>(col.values);
             int32_t b1 = offs[r1], n1 = offs[r1 + 1] - b1, b2 = offs[r2], n2 = offs[r2 + 1] - b2;
@@ -420,11 +420,23 @@ __device__ __forceinline__ void ScanKeyedBody() {
     constexpr bool kStatic = false;
 #endif
 #define SSA_ROW(table, expr, i) (kStatic ? uint32_t(expr) : ReadLane32(table, i))
-    Machine<U> m(a);
+    // a launch over several slices: this workgroup's slice, its rows and its part of the level-2 table
+    const SliceDesc* slice = a.slices != nullptr ? a.slices + __builtin_amdgcn_readfirstlane(a.block_slice[blockIdx.x]) : nullptr;
+    Machine<U> m(a, slice);
+    const uint64_t tableOff = slice != nullptr ? Uniform64(slice->table_off) : 0ull;
+    const int64_t firstTile = slice != nullptr ? int64_t(blockIdx.x) - __builtin_amdgcn_readfirstlane(slice->first_block) : int64_t(blockIdx.x);
+    const int64_t tileStride = slice != nullptr ? int64_t(__builtin_amdgcn_readfirstlane(slice->nblocks)) : int64_t(gridDim.x);
     const int naggs = s.naggs;
     const int L = s.lds_cap, R = s.lds_rep;
     const bool twoWords = kHashed || s.two_words != 0;
     constexpr bool hashed = kHashed;
+    uint64_t* const tKeyLo = rs.t_key_lo + tableOff;
+    uint64_t* const tKeyHi = twoWords ? rs.t_key_hi + tableOff : rs.t_key_hi;
+    uint64_t* const tRepRow = hashed ? rs.t_rep_row + tableOff : rs.t_rep_row;
+    uint32_t* const tSeen = rs.t_seen + tableOff;
+    uint64_t* const tAcc = rs.t_acc + tableOff;
+    const uint64_t accStride = rs.acc_stride;
+    const uint64_t tableMask = rs.table_mask;
     // level-1 table in the sink area of LDS:
     //   by hash position: lo[L], hi[L], rep[L], dense[L];  by dense id: acc[naggs][L][R], seen[L];  count;
     //   keys of the register-held groups: hot[kHotGroups][2]
@@ -491,9 +503,9 @@ __device__ __forceinline__ void ScanKeyedBody() {
     uint64_t tlast = __builtin_readcyclecounter();
 #endif
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = firstTile; tile < ntiles; tile += tileStride) {
         SSA_T(7);
-        m.BeginTile(tile * (kBlock * U), (tile + gridDim.x) * (kBlock * U));
+        m.BeginTile(tile * (kBlock * U), (tile + tileStride) * (kBlock * U));
         SSA_T(0);
         m.Run();
         SSA_T(1);
@@ -697,16 +709,16 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 const uint64_t row = uint64_t(m.Row(0)) + uint64_t(pu) * 64u;
                 const uint32_t h = Fold32(klo, khi);
                 const bool byHash = hashed && (khi >> 63) != 0;  // (exact keys keep the top of hi clear)
-                auto sameRows = [&](uint64_t rep) { return SameKeyRows(a, s, row, rep); };
+                auto sameRows = [&](uint64_t rep) { return SameKeyRows(m.cols, s, row, rep); };
                 if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes, byHash, sameRows);
                 if (sl < 0) {
                     const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
                     int64_t g;
                     if (byHash) {
-                        g = TableUpsertVerified(rs.t_key_lo, rs.t_key_hi, rs.t_rep_row, rs.table_mask, start, klo, khi, row, 4096u, sameRows);
+                        g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, start, klo, khi, row, 4096u, sameRows);
                     } else {
-                        g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, start, klo, khi, twoWords, 4096u);
-                        if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(row));
+                        g = TableUpsert(tKeyLo, tKeyHi, tableMask, start, klo, khi, twoWords, 4096u);
+                        if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(tRepRow + g), static_cast<unsigned long long>(row));
                     }
                     if (g < 0) {
                         m.err |= SCAN_TABLE_FULL;
@@ -814,7 +826,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
                     if (slot[u] >= 0) {
                         if (!((lSeen[slot[u]] >> k) & 1u)) atomicOr(lSeen + slot[u], 1u << k);
                     } else {
-                        uint32_t* g = rs.t_seen + (-2 - slot[u]);
+                        uint32_t* g = tSeen + (-2 - slot[u]);
                         if (!((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> k) & 1u)) atomicOr(g, 1u << k);
                     }
                 }
@@ -835,9 +847,9 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 }
             }
             uint64_t* accK = lAcc + size_t(k) * L * R;
-            uint64_t* tabK = rs.t_acc + size_t(k) * (rs.table_mask + 1);
+            uint64_t* tabK = tAcc + size_t(k) * accStride;
             if (kind == AGG_MIN_S || kind == AGG_MAX_S) {
-                const DevColumn& strCol = a.cols[SSA_ROW(tAggStrCol, s.aggs[k].str_col, k)];
+                const DevColumn& strCol = m.cols[SSA_ROW(tAggStrCol, s.aggs[k].str_col, k)];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (!((live >> u) & 1u)) continue;
@@ -895,11 +907,11 @@ __device__ __forceinline__ void ScanKeyedBody() {
         int64_t g;
         if (hashed && (hi >> 63) != 0) {
             const uint64_t row = lRep[i];
-            g = TableUpsertVerified(rs.t_key_lo, rs.t_key_hi, rs.t_rep_row, rs.table_mask, start, lo, hi, row, 4096u,
-                                    [&](uint64_t rep) { return SameKeyRows(a, s, row, rep); });
+            g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, start, lo, hi, row, 4096u,
+                                    [&](uint64_t rep) { return SameKeyRows(m.cols, s, row, rep); });
         } else {
-            g = TableUpsert(rs.t_key_lo, rs.t_key_hi, rs.table_mask, start, lo, hi, twoWords, 4096u);
-            if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(rs.t_rep_row + g), static_cast<unsigned long long>(lRep[i]));
+            g = TableUpsert(tKeyLo, tKeyHi, tableMask, start, lo, hi, twoWords, 4096u);
+            if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(tRepRow + g), static_cast<unsigned long long>(lRep[i]));
         }
         if (g < 0) {
             m.err |= SCAN_TABLE_FULL;
@@ -910,16 +922,16 @@ __device__ __forceinline__ void ScanKeyedBody() {
             const uint64_t* src = lAcc + (size_t(k) * L + d) * R;
             if (kind == AGG_MIN_S || kind == AGG_MAX_S) {
                 for (int r = 0; r < R; ++r) {
-                    if (src[r] != ~0ull) StringBestUpdate(a.cols[s.aggs[k].str_col], kind == AGG_MIN_S, rs.t_acc + size_t(k) * (rs.table_mask + 1) + g, src[r]);
+                    if (src[r] != ~0ull) StringBestUpdate(m.cols[s.aggs[k].str_col], kind == AGG_MIN_S, tAcc + size_t(k) * accStride + g, src[r]);
                 }
                 continue;
             }
             uint64_t v = src[0];
             for (int r = 1; r < R; ++r) v = TableCombine(kind, v, src[r]);
-            if (v != TableIdentity(kind)) AccUpdate(kind, rs.t_acc + size_t(k) * (rs.table_mask + 1) + g, v);
+            if (v != TableIdentity(kind)) AccUpdate(kind, tAcc + size_t(k) * accStride + g, v);
         }
         const uint32_t seen = lSeen[d];
-        if (seen) atomicOr(rs.t_seen + g, seen);
+        if (seen) atomicOr(tSeen + g, seen);
     }
     m.ReportErrors();
 #undef SSA_ROW

@@ -185,6 +185,14 @@ __device__ __forceinline__ uint64_t ReadLane64(uint64_t v, int lane) {
     return (uint64_t(hi) << 32) | lo;
 }
 
+// A value every lane of the wave holds alike, moved to scalar registers (values loaded through a pointer the compiler
+// cannot prove uniform would otherwise occupy vector registers for the whole kernel).
+__device__ __forceinline__ uint64_t Uniform64(uint64_t v) {
+    const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
+    const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
+    return (uint64_t(hi) << 32) | lo;
+}
+
 template <int U>
 struct Machine {
     static constexpr int kTile = kBlock * U;
@@ -224,10 +232,15 @@ struct Machine {
     int ncols;
     int64_t nrows;
     int ncode;
+    const DevColumn* cols;       // the batch's columns: of the launch, or of this workgroup's slice
+    const OffsetCheck* checks;
 
-    __device__ __forceinline__ explicit Machine(const ScanArgs& args) : a(args), err(0) {
+    // `slice`: this workgroup scans one slice of a launch over several (SliceDesc), else nullptr
+    __device__ __forceinline__ explicit Machine(const ScanArgs& args, const SliceDesc* slice = nullptr) : a(args), err(0) {
         const int lane = threadIdx.x & 63;
-        nrows = a.nrows;
+        nrows = slice != nullptr ? int64_t(Uniform64(uint64_t(slice->nrows))) : a.nrows;
+        cols = slice != nullptr ? slice->cols : a.cols;
+        checks = slice != nullptr ? slice->checks : a.checks;
         ncode = a.ncode;
         tCode0 = lane < ncode ? a.code[3 * lane] : 0u;
         tCode1 = lane < ncode ? a.code[3 * lane + 1] : 0u;
@@ -236,12 +249,12 @@ struct Machine {
         tColOff = uint32_t(a.lds_col_off[c]);
         tColType = uint32_t(a.cols[c].type);
         tColW = uint32_t(TypeWidth(a.cols[c].type));
-        tColValBit = uint32_t(a.cols[c].val_bit_off);
-        tColValidBit = uint32_t(a.cols[c].valid_bit_off);
-        tColCharsBytes = uint32_t(a.cols[c].chars_bytes);
-        tColVal = reinterpret_cast<uint64_t>(a.cols[c].values);
-        tColValid = reinterpret_cast<uint64_t>(a.cols[c].validity);
-        tColChars = reinterpret_cast<uint64_t>(a.cols[c].chars);
+        tColValBit = uint32_t(cols[c].val_bit_off);
+        tColValidBit = uint32_t(cols[c].valid_bit_off);
+        tColCharsBytes = uint32_t(cols[c].chars_bytes);
+        tColVal = reinterpret_cast<uint64_t>(cols[c].values);
+        tColValid = reinterpret_cast<uint64_t>(cols[c].validity);
+        tColChars = reinterpret_cast<uint64_t>(cols[c].chars);
         tRegOff = uint32_t(a.lds_reg_offs[lane & (kMaxRegs - 1)]);
         const int k = lane < kMaxConsts ? lane : 0;
         tConstBits = a.consts[k].bits;
@@ -362,7 +375,7 @@ struct Machine {
         // restored in the lanes that are inactive at the reload), load and compare one column at a time afterwards.
         const int64_t ckRow = slice0 + int64_t(U) * lane;
         auto loadOffsets = [&](int i, uint32_t* v) {
-            const int32_t* offs = a.checks[i].offsets + ckRow;
+            const int32_t* offs = checks[i].offsets + ckRow;
             if (full) {
                 if constexpr (U % 4 == 0) {
 #pragma unroll
@@ -380,7 +393,7 @@ struct Machine {
             }
         };
         auto compareOffsets = [&](int i, const uint32_t* v) {
-            const uint32_t first = a.checks[i].first, len = S().checks[i].len;
+            const uint32_t first = checks[i].first, len = S().checks[i].len;
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const uint32_t want = first + len * uint32_t(ckRow + j);

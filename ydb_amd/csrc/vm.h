@@ -327,6 +327,18 @@ struct LookupTable {
     uint64_t n;
 };
 
+// One slice of a scan over several batches of one schema ("slices" of a table: the reference runs the program on
+// each, ydb/core/formats/arrow/program.h:423-433).  A launch covers them all: workgroups [first_block, first_block +
+// nblocks) scan this slice's rows with this slice's column addresses and aggregate into this slice's part of the
+// level-2 table, slots [table_off, table_off + capacity).
+struct SliceDesc {
+    int64_t nrows;
+    uint64_t table_off;
+    int32_t first_block, nblocks;
+    DevColumn cols[kMaxCols];      // types as in ScanArgs::cols; addresses and bit offsets of this slice
+    OffsetCheck checks[kMaxOffsetChecks];
+};
+
 struct ScanArgs {
     int64_t nrows;
     int32_t ncols;
@@ -350,6 +362,9 @@ struct ScanArgs {
     int32_t nchecks;
     OffsetCheck checks[kMaxOffsetChecks];
     LookupTable tables[kMaxLookupTables];
+    // a scan over several slices (else nullptr): the slices, and the slice of every workgroup of the grid
+    const SliceDesc* slices;
+    const int32_t* block_slice;
 };
 
 }  // namespace ssa

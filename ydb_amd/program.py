@@ -178,6 +178,17 @@ class ProgramContainer:
         self._check(rc, err)
         return DeviceBatch(self._lib, out.value)
 
+    def ApplyDeviceMany(self, batches: Sequence[DeviceBatch]) -> List[DeviceBatch]:
+        """The program on each of the batches (slices of a table), one result per slice (program.h:423-433 of the
+        reference runs them one by one); slices of one schema under an aggregation are scanned by one launch."""
+        n = len(batches)
+        ins = (ctypes.c_void_p * max(n, 1))(*[b._h for b in batches])
+        outs = (ctypes.c_void_p * max(n, 1))()
+        err = ctypes.c_void_p()
+        rc = self._lib.ssa_program_apply_many(self._h, ins, n, outs, ctypes.byref(err))
+        self._check(rc, err)
+        return [DeviceBatch(self._lib, outs[i]) for i in range(n)]
+
     def Export(self, batch: DeviceBatch) -> Dict[str, ResultColumn]:
         out_a, out_s, err = ArrowArray(), ArrowSchema(), ctypes.c_void_p()
         rc = self._lib.ssa_batch_export(self._h, batch._h, ctypes.byref(out_a), ctypes.byref(out_s), ctypes.byref(err))

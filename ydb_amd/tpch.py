@@ -153,21 +153,24 @@ class DeviceLineitem:
         if rc != 0:
             raise RuntimeError(f"ssa_gen_lineitem failed: {rc}")
 
-    def batch(self, columns):
-        """Wraps the named logical columns as an HBM-resident record batch (no copy)."""
+    def batch(self, columns, row0: int = 0, rows: int = None):
+        """Wraps the named logical columns as an HBM-resident record batch (no copy); `row0` / `rows`: a slice of them
+        (row0 a multiple of 4 keeps every column 16-byte aligned)."""
         from . import _lib
         from .program import device_batch
         T = {"int32": 4, "double": 11, "int8": 2, "string": 14}
+        n = self.nrows - row0 if rows is None else rows
+        assert 0 <= row0 and row0 + n <= self.nrows
         desc = []
         for name in columns:
             if name == "l_shipdate":
-                desc.append((name, T["int32"], self.t[name].data_ptr(), 0, 0, 0, 0))
+                desc.append((name, T["int32"], self.t[name].data_ptr() + 4 * row0, 0, 0, 0, 0))
             elif name in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"):
-                desc.append((name, T["double"], self.t[name].data_ptr(), 0, 0, 0, 0))
+                desc.append((name, T["double"], self.t[name].data_ptr() + 8 * row0, 0, 0, 0, 0))
             elif name == "l_returnflag":
-                desc.append((name, T["string"], self.t["rf_offsets"].data_ptr(), 0, self.t["rf_chars"].data_ptr(), self.nrows, 0))
+                desc.append((name, T["string"], self.t["rf_offsets"].data_ptr() + 4 * row0, 0, self.t["rf_chars"].data_ptr(), self.nrows, 0))
             elif name == "l_linestatus":
-                desc.append((name, T["string"], self.t["ls_offsets"].data_ptr(), 0, self.t["ls_chars"].data_ptr(), self.nrows, 0))
+                desc.append((name, T["string"], self.t["ls_offsets"].data_ptr() + 4 * row0, 0, self.t["ls_chars"].data_ptr(), self.nrows, 0))
             elif name in ("l_returnflag_dict", "l_linestatus_dict"):
                 # the flag as a dictionary-encoded string column: the 1-byte codes the generator wrote + their letters
                 import torch
@@ -180,15 +183,15 @@ class DeviceLineitem:
                                    torch.arange(len(letters) + 1, dtype=torch.int32, device=dev))
                     torch.cuda.synchronize(dev)
                 chars, offs = self.t[key]
-                desc.append((name[:-5], T["string"], self.t["rf_code" if rf else "ls_code"].data_ptr(), 0, chars.data_ptr(),
+                desc.append((name[:-5], T["string"], self.t["rf_code" if rf else "ls_code"].data_ptr() + row0, 0, chars.data_ptr(),
                              len(letters), 0, T["int8"], offs.data_ptr(), len(letters)))
             elif name == "l_returnflag_code":
-                desc.append((name, T["int8"], self.t["rf_code"].data_ptr(), 0, 0, 0, 0))
+                desc.append((name, T["int8"], self.t["rf_code"].data_ptr() + row0, 0, 0, 0, 0))
             elif name == "l_linestatus_code":
-                desc.append((name, T["int8"], self.t["ls_code"].data_ptr(), 0, 0, 0, 0))
+                desc.append((name, T["int8"], self.t["ls_code"].data_ptr() + row0, 0, 0, 0, 0))
             else:
                 raise KeyError(name)
-        return device_batch(desc, self.nrows, keep=self)
+        return device_batch(desc, n, keep=self)
 
 
 Q6_COLUMNS = ["l_shipdate", "l_discount", "l_quantity", "l_extendedprice"]
