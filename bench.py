@@ -221,8 +221,9 @@ def main():
             prog, cols, bpr, name = tpch_workload(k)
             stream.append((k, prog, li.batch(cols), bpr, name))
     scans = [ShardedScan(prog, resolver, device=local_rank) for _, prog, _, _, _ in stream]
-    # a result of millions of groups stays in HBM on one GPU (its row count is read back)
-    on_device = args.workload in ("cb_userid", "cb_phrase") and world == 1
+    # a result of millions of groups stays in HBM (its row count is read back); with several ranks each keeps the groups
+    # whose key hash it owns
+    on_device = args.workload in ("cb_userid", "cb_phrase")
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -304,9 +305,13 @@ def main():
                                  "roofline": roofline_of("q1_slices", prog, kernel_ms, launches, algo_bytes, pc.SpecializationStats()[2])}
         del res, slices
 
+    result = results[0]
+    groups = result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0)
+    if on_device and world > 1:  # the result is spread over the ranks
+        t = torch.tensor([groups], dtype=torch.int64, device=gather_dev)
+        dist.all_reduce(t)
+        groups = int(t.item())
     if rank == 0:
-        result = results[0]
-        groups = result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0)
         total_rows = rows * world * args.steps * len(stream)
         wl_key, prog, _, bpr, name = stream[0]
         kernel_ms, launches, algo_bytes = profiles[0]

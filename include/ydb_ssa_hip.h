@@ -173,6 +173,31 @@ int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_
  * scanned by one kernel launch with one host synchronisation for all of them; anything else runs slice by slice, with
  * the same results.  On failure no batch is returned. */
 int ssa_program_apply_many(ssa_program_t* program, const ssa_batch_t* const* in, size_t n, ssa_batch_t** out, char** err);
+/*
+ * Result batches between the GPUs of a sharded scan.  The reference sends every shard's partial result to the compute
+ * node that merges them (ydb/core/tx/columnshard/columnshard__scan.cpp:300-340, TEvScanData); with one process per GPU
+ * the partial tables stay in device memory and travel as flat buffers through a collective of the host's choice
+ * (RCCL all_gather / all_to_all):
+ *  - ssa_batch_pack_layout: the description of the batch as a flat buffer -- `header` (host bytes; NULL to ask for the
+ *    sizes only) and the size of its data (string columns: the bytes in use, read from the first and last offset);
+ *  - ssa_batch_pack_data: the column buffers into `device_dst` (device memory of at least data_bytes), one launch;
+ *  - ssa_batch_unpack: a batch whose columns are views of `device_data` as described by `header`; the caller keeps the
+ *    memory alive, and unchanged, while the batch or anything derived from it without a copy is in use;
+ *  - ssa_batch_concat: the rows of `n` batches of one schema (names and types; nulls may be present in some only) as one
+ *    new batch, part after part, one launch for all buffers;
+ *  - ssa_batch_slice: rows [row0, row0 + rows) as a view; ssa_batch_rename: the same columns under other names (the
+ *    merge program reads the partial aggregates under names of its own); ssa_batch_column_name: to be freed with
+ *    ssa_free_string.
+ */
+int ssa_batch_pack_layout(ssa_program_t* program, const ssa_batch_t* batch, uint8_t* header, size_t header_capacity, size_t* header_bytes,
+                          size_t* data_bytes, char** err);
+int ssa_batch_pack_data(ssa_program_t* program, const ssa_batch_t* batch, void* device_dst, size_t capacity, char** err);
+int ssa_batch_unpack(const uint8_t* header, size_t header_bytes, void* device_data, size_t data_bytes, ssa_batch_t** out, char** err);
+int ssa_batch_concat(ssa_program_t* program, const ssa_batch_t* const* parts, size_t n, ssa_batch_t** out, char** err);
+int ssa_batch_slice(const ssa_batch_t* batch, int64_t row0, int64_t rows, ssa_batch_t** out, char** err);
+int ssa_batch_rename(const ssa_batch_t* batch, const char* const* names, size_t n, ssa_batch_t** out, char** err);
+char* ssa_batch_column_name(const ssa_batch_t* batch, size_t i);
+
 /* Process-wide counters: program steps ssa_program_apply_many ran over all their slices with one launch, and steps it
  * ran slice by slice. */
 void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_slice);

@@ -419,6 +419,93 @@ int ssa_program_apply_many(ssa_program_t* program, const ssa_batch_t* const* in,
     return SSA_OK;
 }
 
+int ssa_batch_pack_layout(ssa_program_t* program, const ssa_batch_t* batch, uint8_t* header, size_t header_capacity, size_t* header_bytes,
+                          size_t* data_bytes, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    std::vector<uint8_t> h;
+    uint64_t data = 0;
+    Status st = program->Exec->PackedLayout(*batch->Batch, h, data);
+    if (!st.ok()) return Fail(st, err);
+    if (header_bytes) *header_bytes = h.size();
+    if (data_bytes) *data_bytes = size_t(data);
+    if (header) {
+        if (h.size() > header_capacity) return Fail(Status::Invalid("the header does not fit: " + std::to_string(h.size()) + " bytes"), err);
+        std::memcpy(header, h.data(), h.size());
+    }
+    return SSA_OK;
+}
+
+int ssa_batch_pack_data(ssa_program_t* program, const ssa_batch_t* batch, void* device_dst, size_t capacity, char** err) {
+    if (err) *err = nullptr;
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    Status st = program->Exec->PackData(*batch->Batch, device_dst, capacity);
+    if (!st.ok()) return Fail(st, err);
+    return SSA_OK;
+}
+
+int ssa_batch_unpack(const uint8_t* header, size_t header_bytes, void* device_data, size_t data_bytes, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    BatchPtr b;
+    Status st = UnpackBatch(header, header_bytes, device_data, data_bytes, b);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_batch{b};
+    return SSA_OK;
+}
+
+int ssa_batch_concat(ssa_program_t* program, const ssa_batch_t* const* parts, size_t n, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    if (n == 0 || !parts) return Fail(Status::Invalid("no batches"), err);
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    std::vector<BatchPtr> in;
+    for (size_t i = 0; i < n; ++i) {
+        if (!parts[i]) return Fail(Status::Invalid("null batch"), err);
+        in.push_back(parts[i]->Batch);
+    }
+    BatchPtr res;
+    Status st = program->Exec->ConcatBatches(in, res);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_batch{res};
+    return SSA_OK;
+}
+
+int ssa_batch_slice(const ssa_batch_t* batch, int64_t row0, int64_t rows, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    const Batch& b = *batch->Batch;
+    if (row0 < 0 || rows < 0 || row0 + rows > b.Rows) return Fail(Status::Invalid("rows outside the batch"), err);
+    auto v = std::make_shared<Batch>();
+    v->Rows = rows;
+    for (const Column& c : b.Cols) v->Cols.push_back(ColumnView(c, row0, rows));
+    *out = new ssa_batch{v};
+    return SSA_OK;
+}
+
+int ssa_batch_rename(const ssa_batch_t* batch, const char* const* names, size_t n, ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    if (n != batch->Batch->Cols.size()) return Fail(Status::Invalid("one name per column is needed"), err);
+    auto v = std::make_shared<Batch>(*batch->Batch);
+    for (size_t i = 0; i < n; ++i) v->Cols[i].Field.Name = names[i] ? names[i] : "";
+    *out = new ssa_batch{v};
+    return SSA_OK;
+}
+
+char* ssa_batch_column_name(const ssa_batch_t* batch, size_t i) {
+    if (i >= batch->Batch->Cols.size()) return nullptr;
+    return DupString(batch->Batch->Cols[i].Field.Name);
+}
+
 void ssa_shutdown(void) { ssa::KernelJit::Instance().Shutdown(); }
 
 void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_slice) {

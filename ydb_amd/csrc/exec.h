@@ -130,6 +130,11 @@ struct BorderValue {
     TScalar Value;  // numbers as the VM payload (floats widened to double), strings as bytes
 };
 
+// Rows [start, start + count) of a column as a view of the same buffers.
+Column ColumnView(const Column& col, int64_t start, int64_t count);
+// A batch of views of `data`, a flat buffer filled by Executor::PackData and described by `header` (Executor::PackedLayout).
+Status UnpackBatch(const uint8_t* header, size_t headerBytes, void* data, size_t dataBytes, BatchPtr& out);
+
 // Several slices of one schema scanned by one launch (Executor::ApplyProgramMany).
 struct ManySlices {
     std::vector<const Batch*> In;                  // every slice; In[0] is the batch the plan was made for
@@ -191,6 +196,13 @@ public:
     // `in` itself when it has no dictionary column, else a copy with those columns decoded (a gather through the codes)
     Status DecodedBatch(const BatchPtr& in, BatchPtr& out);
 
+    // -- result batches between GPUs (exchange.cpp) -----------------------------------------------------------
+    // A batch as one flat buffer: the layout's description (host bytes: row count, per column its type, name and the place
+    // of its buffers) and the size of the data; PackData fills the data, UnpackBatch makes a batch of views of it.
+    Status PackedLayout(const Batch& in, std::vector<uint8_t>& header, uint64_t& dataBytes);
+    Status PackData(const Batch& in, void* dst, size_t capacity);
+    Status ConcatBatches(const std::vector<BatchPtr>& parts, BatchPtr& out);
+
     Status Sync();
     hipStream_t Stream() const { return StreamHandle; }
     KernelProfile Profile;
@@ -215,6 +227,8 @@ private:
                         const std::vector<OffsetCheck>& checks, bool* notUniform, ManySlices* many = nullptr);
     Status DescribeSlices(const StepPlan& plan, ManySlices& many, ScanArgs& args, int64_t tileRows, uint64_t cap, LaunchCfg& cfg,
                           BufferPtr& descs, BufferPtr& map);
+    Status RunSegments(const std::vector<CopySegment>& segments);
+    Status StringBounds(const Batch& in, std::vector<int32_t>& bounds);
     Status ApplyStepMany(const TProgramStep& step, const std::vector<BatchPtr>& in, std::vector<BatchPtr>& out);
     Status RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& in, BatchPtr& out);
     Status RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,

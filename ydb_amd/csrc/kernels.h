@@ -191,6 +191,23 @@ hipError_t LaunchWidenCodes(const void* idx, int type, int64_t n, uint64_t entri
 hipError_t LaunchColumnToPayload(const void* values, int type, int64_t valBitOff, const uint8_t* validity, int64_t validBitOff, int64_t n,
                                  uint64_t* payload, uint8_t* valid, hipStream_t st);
 
+// ---- batches between GPUs: pack / concat --------------------------------------------------------------------
+enum CopySegmentKind : int32_t {
+    SEG_BYTES = 0,          // dst[i] = src[i], count bytes
+    SEG_I32_ADD = 1,        // int32 dst[i] = src[i] + arg, count values
+    SEG_BITS_TO_BYTES = 2,  // dst[i] = bit (arg + i) of src, count rows
+    SEG_FILL = 3,           // dst[i] = arg, count bytes
+};
+struct CopySegment {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint64_t count;
+    int32_t kind;
+    int64_t arg;
+};
+// Runs every segment of the device array (one grid row per segment).  maxCount: the largest `count` (sizes the grid).
+hipError_t LaunchCopySegments(const CopySegment* deviceSegments, int nsegments, uint64_t maxCount, hipStream_t st);
+
 // ---- compressed IPC bodies ---------------------------------------------------------------------------------
 // One block of an LZ4 frame (https://github.com/lz4/lz4/blob/dev/doc/lz4_Frame_format.md).
 struct Lz4BlockRef {

@@ -73,23 +73,6 @@ Status Executor::ApplyProgramMany(const TProgram& program, const std::vector<Bat
     return Status::OK();
 }
 
-namespace {
-
-// rows [start, start + count) of a column of the joint result
-Column ViewOf(const Column& col, int64_t start, int64_t count) {
-    Column v = col;
-    v.Length = count;
-    if (col.Field.Type == T_BOOL) v.ValBitOff = int32_t(col.ValBitOff + start);
-    else v.ElemOffset = col.ElemOffset + start;
-    if (col.Validity) {
-        v.ValidBitOff = int32_t(col.ValidBitOff + start);
-        v.NullCount = -1;
-    }
-    return v;
-}
-
-}  // namespace
-
 Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<BatchPtr>& in, std::vector<BatchPtr>& out) {
     const size_t n = in.size();
     const std::vector<FieldDesc> schema = in[0]->Schema();
@@ -274,7 +257,7 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
         }
         auto b = std::make_shared<Batch>();
         b->Rows = count;
-        for (const Column& col : all->Cols) b->Cols.push_back(ViewOf(col, start, count));
+        for (const Column& col : all->Cols) b->Cols.push_back(ColumnView(col, start, count));
         out[i] = b;
     }
     SSA_HIP(hipStreamSynchronize(StreamHandle));

@@ -189,6 +189,49 @@ class ProgramContainer:
         self._check(rc, err)
         return [DeviceBatch(self._lib, outs[i]) for i in range(n)]
 
+    # -- result batches between GPUs (the collective itself is the caller's: torch.distributed over RCCL) -------
+    def PackLayout(self, batch: DeviceBatch) -> Tuple[bytes, int]:
+        """(header, data_bytes): the description of `batch` as one flat buffer and the size of its data."""
+        hb, db, err = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_void_p()
+        rc = self._lib.ssa_batch_pack_layout(self._h, batch._h, None, 0, ctypes.byref(hb), ctypes.byref(db), ctypes.byref(err))
+        self._check(rc, err)
+        buf = (ctypes.c_uint8 * max(hb.value, 1))()
+        rc = self._lib.ssa_batch_pack_layout(self._h, batch._h, buf, hb.value, ctypes.byref(hb), ctypes.byref(db), ctypes.byref(err))
+        self._check(rc, err)
+        return bytes(buf[:hb.value]), db.value
+
+    def PackData(self, batch: DeviceBatch, device_ptr: int, capacity: int) -> None:
+        err = ctypes.c_void_p()
+        self._check(self._lib.ssa_batch_pack_data(self._h, batch._h, device_ptr, capacity, ctypes.byref(err)), err)
+
+    def Unpack(self, header: bytes, device_ptr: int, data_bytes: int, keep=None) -> DeviceBatch:
+        """A batch of views of the device memory at `device_ptr` (kept alive through `keep`)."""
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        hb = (ctypes.c_uint8 * max(len(header), 1)).from_buffer_copy(header or b"\0")
+        self._check(self._lib.ssa_batch_unpack(hb, len(header), device_ptr, data_bytes, ctypes.byref(out), ctypes.byref(err)), err)
+        return DeviceBatch(self._lib, out.value, keep=keep)
+
+    def Concat(self, batches: Sequence[DeviceBatch]) -> DeviceBatch:
+        n = len(batches)
+        ins = (ctypes.c_void_p * max(n, 1))(*[b._h for b in batches])
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.ssa_batch_concat(self._h, ins, n, ctypes.byref(out), ctypes.byref(err)), err)
+        return DeviceBatch(self._lib, out.value)
+
+    def Slice(self, batch: DeviceBatch, row0: int, rows: int) -> DeviceBatch:
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.ssa_batch_slice(batch._h, row0, rows, ctypes.byref(out), ctypes.byref(err)), err)
+        return DeviceBatch(self._lib, out.value, keep=batch)
+
+    def Rename(self, batch: DeviceBatch, names: Sequence[str]) -> DeviceBatch:
+        arr = (ctypes.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.ssa_batch_rename(batch._h, arr, len(names), ctypes.byref(out), ctypes.byref(err)), err)
+        return DeviceBatch(self._lib, out.value, keep=batch)
+
+    def ColumnNames(self, batch: DeviceBatch) -> List[str]:
+        return [_lib.take_string(self._lib, self._lib.ssa_batch_column_name(batch._h, i)) for i in range(batch.num_columns)]
+
     def Export(self, batch: DeviceBatch) -> Dict[str, ResultColumn]:
         out_a, out_s, err = ArrowArray(), ArrowSchema(), ctypes.c_void_p()
         rc = self._lib.ssa_batch_export(self._h, batch._h, ctypes.byref(out_a), ctypes.byref(out_s), ctypes.byref(err))

@@ -14,6 +14,13 @@ program over its own rows; the only exchange is the small table of partial aggre
 High-cardinality groupings instead hash-partition the partial tables (`all_to_all_results`: point-to-point
 sends to the rank that owns each key hash, `partition_of_keys`), so that each rank merges 1/N of the groups
 and the result stays distributed.
+
+On GPUs (`ShardedScan.run`) none of this touches the host: the partial table stays an HBM-resident batch, is laid
+out as one flat device buffer (ssa_batch_pack_*), travels through one `all_gather_into_tensor` -- or, partitioned by
+the XXH64 of its keys with the sharding kernels, one `all_to_all_single` -- over RCCL, and the received parts are
+concatenated (one launch) into the input of the merge program, which runs through the same executor.  The only host
+traffic is the parts' headers (a few hundred bytes per rank: row counts and buffer sizes).  The functions that pack
+results on the host remain for ranks without a GPU (the CPU tests of this path).
 """
 from __future__ import annotations
 
@@ -277,18 +284,123 @@ class ShardedScan:
         """Local scan (HBM-resident `batch`), then -- when torch.distributed is initialised with more than one rank --
         the exchange of the partial tables and the merge program.  exchange = "allgather": every rank ends with the
         whole result; "alltoall": every rank ends with the groups whose key hash it owns (their union is the result);
-        "auto": all-to-all once any rank's partial table exceeds ALL_TO_ALL_GROUPS rows."""
+        "auto": all-to-all once any rank's partial table exceeds ALL_TO_ALL_GROUPS rows.  `gather_device`: where the
+        collective's tensors live -- the GPU (RCCL), or the CPU when the process group is gloo (a rehearsal of several
+        ranks on one GPU): the packed parts then cross the host on their way."""
         import torch.distributed as dist
 
         single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        if single and keep_on_device:
-            return self.local.ApplyDevice(batch)  # the result batch stays in HBM (one rank, nothing to exchange)
-        partial = self.local.Export(self.local.ApplyDevice(batch))
+        partial = self.local.ApplyDevice(batch)
         if single:
-            return partial
+            return partial if keep_on_device else self.local.Export(partial)  # one rank: nothing to exchange
         if self.merge is None:
             raise ValueError("sharded scan without aggregation: results stay on their shards")
-        return self.merge.ApplyProgram(self.exchange(partial, gather_device, exchange))
+        merged = self.merge.ApplyDevice(self.exchange_device(partial, gather_device, exchange))
+        return merged if keep_on_device else self.merge.Export(merged)
+
+    HEADER_CAPACITY = 16384  # bytes of a part's description (a few dozen per column)
+
+    def _merge_names(self, partial) -> List[str]:
+        names = {i: n for i, n in self.resolver}
+        agg_names = {_column_name(a.column, names) for a in last_group_by(self.program).aggregates}
+        return [(_PARTIAL_PREFIX + n) if n in agg_names else n for n in self.local.ColumnNames(partial)]
+
+    def exchange_device(self, partial, device=None, exchange: str = "auto"):
+        """The merge program's input on this rank as an HBM-resident batch: the partial tables of all ranks
+        (all-gather), or the groups of all ranks whose key hash this rank owns (all-to-all)."""
+        import torch
+        import torch.distributed as dist
+
+        pc = self.local
+        world, rank = dist.get_world_size(), dist.get_rank()
+        gpu = torch.device("cuda", torch.cuda.current_device())
+        wire = device if device is not None else gpu  # where the collective's tensors live
+        names = {i: n for i, n in self.resolver}
+        key_names = [_column_name(k, names) for k in last_group_by(self.program).keys]
+        cap = self.HEADER_CAPACITY
+
+        def describe(parts):
+            """One row of int64 per part: header length, data bytes, then the header itself."""
+            t = torch.zeros((len(parts), 2 + cap // 8), dtype=torch.int64)
+            for i, p in enumerate(parts):
+                header, data_bytes = pc.PackLayout(p)
+                if len(header) > cap:
+                    raise ValueError("result batch with too many columns to exchange")
+                t[i, 0], t[i, 1] = len(header), data_bytes
+                t[i, 2:].view(torch.uint8)[:len(header)] = torch.frombuffer(bytearray(header), dtype=torch.uint8)
+            return t
+
+        def parse(row):
+            hl, db = int(row[0]), int(row[1])
+            return row[2:].view(torch.uint8)[:hl].numpy().tobytes(), db
+
+        def rows_of(header: bytes) -> int:
+            return struct.unpack_from("<q", header, 8)[0]
+
+        import os
+        import time
+        timing = os.environ.get("SSA_EXCHANGE_TIMING") and rank == 0
+        marks = [("start", time.perf_counter())]
+
+        def mark(what):
+            if timing:
+                torch.cuda.synchronize()
+                marks.append((what, time.perf_counter()))
+
+        heads = None
+        if exchange in ("auto", "allgather"):
+            # every rank's description of its whole partial table: enough to decide, and the first half of an all-gather
+            mine = describe([partial]).reshape(-1).to(wire)
+            every = torch.empty(world * mine.numel(), dtype=torch.int64, device=wire)
+            dist.all_gather_into_tensor(every, mine)
+            heads = [parse(r) for r in every.cpu().reshape(world, -1)]
+            if exchange == "auto":
+                most = max(rows_of(h) for h, _ in heads)
+                exchange = "alltoall" if (key_names and most > self.ALL_TO_ALL_GROUPS) else "allgather"
+            mark("descriptions")
+
+        if exchange == "allgather":
+            width = max(db for _, db in heads)
+            send = torch.empty(width, dtype=torch.uint8, device=gpu)
+            pc.PackData(partial, send.data_ptr(), width)
+            recv = torch.empty(world * width, dtype=torch.uint8, device=wire)
+            dist.all_gather_into_tensor(recv, send.to(wire))
+            recv = recv.to(gpu)
+            mark("all-gather")
+            parts = [pc.Unpack(h, recv.data_ptr() + r * width, db, keep=recv) for r, (h, db) in enumerate(heads)]
+        else:
+            split, counts = pc.ShardingSplit(partial, key_names, world)
+            mark("partition by key hash")
+            pieces, at = [], 0
+            for r in range(world):
+                pieces.append(pc.Slice(split, at, counts[r]))
+                at += counts[r]
+            mine = describe(pieces).reshape(-1).to(wire)  # part r: what rank r gets from this rank
+            theirs = torch.empty_like(mine)               # part r: what this rank gets from rank r
+            dist.all_to_all_single(theirs, mine)
+            out_heads = [parse(r) for r in mine.cpu().reshape(world, -1)]
+            in_heads = [parse(r) for r in theirs.cpu().reshape(world, -1)]
+            out_sizes = [db for _, db in out_heads]
+            in_sizes = [db for _, db in in_heads]
+            send = torch.empty(sum(out_sizes), dtype=torch.uint8, device=gpu)
+            at = 0
+            for r in range(world):
+                pc.PackData(pieces[r], send.data_ptr() + at, out_sizes[r])
+                at += out_sizes[r]
+            mark("pack")
+            recv = torch.empty(sum(in_sizes), dtype=torch.uint8, device=wire)
+            dist.all_to_all_single(recv, send.to(wire), output_split_sizes=in_sizes, input_split_sizes=out_sizes)
+            recv = recv.to(gpu)
+            mark("all-to-all")
+            parts, at = [], 0
+            for r in range(world):
+                parts.append(pc.Unpack(in_heads[r][0], recv.data_ptr() + at, in_sizes[r], keep=recv))
+                at += in_sizes[r]
+        whole = pc.Concat(parts)
+        mark("concatenate")
+        if timing:
+            print("exchange: " + ", ".join(f"{w} {1e3 * (t - marks[i][1]):.2f} ms" for i, (w, t) in enumerate(marks[1:])), flush=True)
+        return pc.Rename(whole, self._merge_names(whole))
 
     def exchange(self, partial: Dict[str, ResultColumn], device=None, exchange: str = "auto") -> Dict[str, Col]:
         """The merge program's input batch on this rank."""
