@@ -135,3 +135,43 @@ def test_partition_of_keys_is_balanced_and_stable():
     counts = np.bincount(r, minlength=8)
     assert counts.min() > 0.9 * 12_500 and counts.max() < 1.1 * 12_500
     assert (shard.partition_of_keys(h, 8) == r).all()
+
+
+def test_commands_after_the_aggregation_run_on_the_merged_groups():
+    """HAVING count > c, avg = sum / count, projection of the average only: shards run the program up to its last GroupBy
+    (shard.split_at_last_group_by), the merge program reduces their partial tables and then applies what follows the
+    aggregation.  Filtering or projecting per shard would drop groups that pass only when merged, and sums the average
+    needs."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import compare_batches
+    from oracle import ssa_oracle
+    from ydb_amd import shard, tpch
+    from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
+    rows = 12_000
+    prog = (Program(version=5)
+            .group_by([Aggregate(130, AGG.SUM, [tpch.L_QUANTITY]), Aggregate(131, AGG.COUNT, [tpch.L_QUANTITY]), Aggregate(132, AGG.MAX, [tpch.L_SHIPDATE])],
+                      keys=[tpch.L_SHIPDATE])
+            .assign_const(140, "Uint64", 5).assign_func(141, F.CMP_GREATER, [131, 140]).filter(141)
+            .assign_func(142, F.MATH_DIVIDE, [130, 131])
+            .project([tpch.L_SHIPDATE, 142, 132]))
+    cols = ["l_shipdate", "l_quantity"]
+    head, tail = shard.split_at_last_group_by(prog)
+    assert len(head.commands) == 1 and len(tail) == 5
+    full = tpch.lineitem_host(0, rows)
+    exp = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply({c: full[c] for c in cols})
+    assert 0 < len(exp["142"].to_pylist())
+    parts = []
+    for r in range(3):
+        li = tpch.lineitem_host(r * rows // 3, rows // 3)
+        parts.append(ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, head).apply({c: li[c] for c in cols}))
+    # some days have more than five rows only in the whole table: a HAVING applied per shard would have dropped them
+    per_shard_days = set()
+    for r in range(3):
+        li = tpch.lineitem_host(r * rows // 3, rows // 3)
+        per_shard_days |= set(ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply({c: li[c] for c in cols})["l_shipdate"].to_pylist())
+    assert per_shard_days < set(exp["l_shipdate"].to_pylist())
+    mp_, mr = shard.merge_program(prog, tpch.LINEITEM_RESOLVER)
+    merged = ssa_oracle.Oracle(mr, mp_).apply(shard.partial_batch(parts, prog, tpch.LINEITEM_RESOLVER))
+    assert list(merged.keys()) == list(exp.keys())
+    compare_batches(merged, exp, key_names=["l_shipdate"], float_sum_names=["142"])

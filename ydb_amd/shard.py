@@ -30,7 +30,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from .arrow_c import Col, ResultColumn
-from .ssa_pb import AGG, Aggregate, Column, GroupBy, Program, Projection
+from .ssa_pb import AGG, Aggregate, Assign, Column, Filter, Function, GroupBy, Program, Projection
 
 Resolver = Sequence[Tuple[int, str]]
 
@@ -58,8 +58,20 @@ def last_group_by(program: Program) -> Optional[GroupBy]:
     return gb
 
 
+def split_at_last_group_by(program: Program) -> Tuple[Program, List[object]]:
+    """(the program up to and including its last GroupBy, the commands after it).  Shards run the first part; what
+    follows an aggregation (a HAVING filter, avg = sum / count, the final projection) only makes sense on merged
+    groups and runs after the merge."""
+    idx = max((i for i, cmd in enumerate(program.commands) if isinstance(cmd, GroupBy)), default=None)
+    if idx is None:
+        raise ValueError("program has no GroupBy: shards are concatenated, not merged")
+    return Program(commands=list(program.commands[:idx + 1]), version=program.version, kernels=program.kernels), list(program.commands[idx + 1:])
+
+
 def merge_program(program: Program, resolver: Resolver) -> Tuple[Program, List[Tuple[int, str]]]:
-    """Program + resolver that reduce concatenated partial results of `program` to its final result.
+    """Program + resolver that reduce concatenated partial results of `program` -- of its part up to the last GroupBy
+    (split_at_last_group_by) -- to its final result: the merging GroupBy, then the program's own commands after the
+    aggregation.
 
     Partial aggregate columns are fed in under the name "partial:<name>" so that the merged aggregate can
     carry the original name; key columns keep their names."""
@@ -83,11 +95,24 @@ def merge_program(program: Program, resolver: Resolver) -> Tuple[Program, List[T
         out_resolver.append((next_id, name))
         keys.append(next_id)
         next_id += 1
-    merged = Program(version=program.version).group_by(aggs, keys=keys)
-    # a trailing projection of the original program applies to the merged result as well
-    tail = program.commands[-1]
-    if isinstance(tail, Projection):
-        merged.project([_column_name(c, names) for c in tail.columns])
+    merged = Program(version=program.version, kernels=program.kernels).group_by(aggs, keys=keys)
+    # the program's commands after the aggregation apply to the merged groups; table columns (the keys) have other ids
+    # in the merge program's resolver, so every reference goes by name
+    by_name = lambda c: Column(name=_column_name(c, names))  # noqa: E731
+    _, tail = split_at_last_group_by(program)
+    for cmd in tail:
+        if isinstance(cmd, Projection):
+            merged.commands.append(Projection([by_name(c) for c in cmd.columns]))
+        elif isinstance(cmd, Filter):
+            merged.commands.append(Filter(by_name(cmd.predicate)))
+        elif isinstance(cmd, Assign):
+            fn = cmd.function
+            if fn is not None:
+                fn = Function(fn.id, [by_name(a) for a in fn.args], fn.function_type, fn.kernel_idx, fn.yql_op)
+            out = cmd.column if cmd.column is None or isinstance(cmd.column, Column) else Column(id=cmd.column) if isinstance(cmd.column, int) else Column(name=cmd.column)
+            merged.commands.append(Assign(out, fn, cmd.constant, cmd.null, cmd.parameter, cmd.external))
+        else:
+            raise ValueError(f"command {type(cmd).__name__} after the last GroupBy cannot be merged across shards")
     return merged, out_resolver
 
 
@@ -264,11 +289,13 @@ class ShardedScan:
 
         self.program = program
         self.resolver = list(resolver)
+        self.device = device
         self.local = ProgramContainer(device)
         ok, err = self.local.Init(self.resolver, program)
         if not ok:
             raise ValueError(err)
         self.merge = None
+        self._head = None  # the program up to its last GroupBy: what a shard runs when there is a merge to follow
         if last_group_by(program) is not None:
             mp, mr = merge_program(program, resolver)
             self.merge_resolver = mr
@@ -290,20 +317,36 @@ class ShardedScan:
         import torch.distributed as dist
 
         single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        partial = self.local.ApplyDevice(batch)
         if single:
-            return partial if keep_on_device else self.local.Export(partial)  # one rank: nothing to exchange
+            result = self.local.ApplyDevice(batch)
+            return result if keep_on_device else self.local.Export(result)  # one rank: nothing to exchange
         if self.merge is None:
             raise ValueError("sharded scan without aggregation: results stay on their shards")
+        partial = self.head.ApplyDevice(batch)
         merged = self.merge.ApplyDevice(self.exchange_device(partial, gather_device, exchange))
         return merged if keep_on_device else self.merge.Export(merged)
+
+    @property
+    def head(self):
+        """The executor of the program's part up to its last GroupBy (the whole program when nothing follows it)."""
+        if self._head is None:
+            head, tail = split_at_last_group_by(self.program)
+            if not tail:
+                self._head = self.local
+            else:
+                from .program import ProgramContainer
+                self._head = ProgramContainer(self.device)
+                ok, err = self._head.Init(self.resolver, head)
+                if not ok:
+                    raise ValueError(err)
+        return self._head
 
     HEADER_CAPACITY = 16384  # bytes of a part's description (a few dozen per column)
 
     def _merge_names(self, partial) -> List[str]:
         names = {i: n for i, n in self.resolver}
         agg_names = {_column_name(a.column, names) for a in last_group_by(self.program).aggregates}
-        return [(_PARTIAL_PREFIX + n) if n in agg_names else n for n in self.local.ColumnNames(partial)]
+        return [(_PARTIAL_PREFIX + n) if n in agg_names else n for n in self.head.ColumnNames(partial)]
 
     def exchange_device(self, partial, device=None, exchange: str = "auto"):
         """The merge program's input on this rank as an HBM-resident batch: the partial tables of all ranks
@@ -311,7 +354,7 @@ class ShardedScan:
         import torch
         import torch.distributed as dist
 
-        pc = self.local
+        pc = self.head
         world, rank = dist.get_world_size(), dist.get_rank()
         gpu = torch.device("cuda", torch.cuda.current_device())
         wire = device if device is not None else gpu  # where the collective's tensors live
