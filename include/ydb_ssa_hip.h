@@ -289,6 +289,21 @@ int ssa_filter_filtered_count(ssa_program_t* program, const ssa_filter_t* filter
 int ssa_filter_apply(ssa_program_t* program, const ssa_filter_t* filter, const ssa_batch_t* batch, ssa_batch_t** out, char** err);
 void ssa_filter_destroy(ssa_filter_t* filter);
 
+/*
+ * NArrow::NMerger::TMergePartialStream (ydb/core/formats/arrow/reader/merger.h:41-95): AddSource for each of the
+ * `n_sources` batches (every one sorted ascending by `key_columns`; `filters`: NULL, or per source a filter or NULL)
+ * followed by DrainAll (merger.cpp:145-186).  The result is sorted by the key columns -- descending when `reverse`, as
+ * the reference reads its sources from their ends then -- and holds every key once: the row with the greatest
+ * `version_columns` among the rows of that key, and no row at all when that row is denied by its source's filter.
+ * Rows compare as in ydb/core/formats/arrow/switch/compare.h:82-119 (validity is not looked at, strings by memcmp then
+ * length).  Sources without rows and sources whose filter denies everything take no part (merger.h:80-85).  Among rows of
+ * one key and one version -- an order the reference's heap leaves open -- the row of the earlier source is taken.
+ * All columns of the sources are carried (they must agree in names and types).
+ */
+int ssa_merge_sorted(ssa_program_t* program, const ssa_batch_t* const* sources, const ssa_filter_t* const* filters, size_t n_sources,
+                     const char* const* key_columns, size_t n_keys, const char* const* version_columns, size_t n_versions, int reverse,
+                     ssa_batch_t** out, char** err);
+
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 
 /* When enabled, every fused scan kernel launch of this program is bracketed by HIP events on the program's

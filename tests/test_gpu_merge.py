@@ -1,0 +1,157 @@
+"""The PK k-way merge on the GPU (ssa_merge_sorted through MergePartialStream) against the merge oracle and the
+reference's merger tests (ydb/core/formats/arrow/ut/ut_arrow.cpp:655-740), bit-exact; at millions of rows through
+sortedness, uniqueness and counts."""
+import numpy as np
+import pytest
+
+from ydb_amd.arrow_c import Col
+
+pytestmark = pytest.mark.gpu
+
+
+def container():
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import Program
+    pc = ProgramContainer()
+    ok, err = pc.Init([(1, "k")], Program().project([1]))
+    assert ok, err
+    return pc
+
+
+def run(pc, sources, sort, versions=(), reverse=False, filters=None):
+    """(GPU result as name -> list, oracle result)"""
+    from oracle import merge_oracle
+    from ydb_amd.column_filter import ColumnFilter
+    from ydb_amd.merger import MergePartialStream
+    merger = MergePartialStream(pc, sort, reverse=reverse, version_columns=versions)
+    for i, s in enumerate(sources):
+        f = None
+        if filters is not None and filters[i] is not None:
+            f = ColumnFilter.FromValues(pc, list(filters[i]))
+        n = len(next(iter(s.values())))
+        batch = {k: (Col(list(v), type="string") if isinstance(v, list) and (not v or isinstance(v[0], (bytes, str))) else np.asarray(v)) for k, v in s.items()}
+        merger.AddSource(pc.Import(batch) if n else None, f)
+    out = merger.DrainAll()
+    got = None
+    if out is not None:
+        res = pc.Export(out)
+        got = {k: [bytes(x) if isinstance(x, (bytes, bytearray)) else x.item() if hasattr(x, "item") else x for x in c.values] for k, c in res.items()}
+    plain = [{k: (list(v) if isinstance(v, list) else [x.item() for x in np.asarray(v)]) for k, v in s.items()} for s in sources]
+    plain = [{k: [x.encode() if isinstance(x, str) else x for x in v] for k, v in s.items()} for s in plain]
+    exp = merge_oracle.drain_all(plain, list(sort), list(versions), reverse, filters)
+    return got, exp
+
+
+def table1000():
+    i = np.arange(1000)
+    return {"i8": (i // 100).astype(np.int8), "i16": ((i % 100) // 10).astype(np.int16), "i32": (i % 10).astype(np.int32)}
+
+
+def cut(t, start, count):
+    return {k: v[start:start + count] for k, v in t.items()}
+
+
+SLICES = [(0, 100), (100, 200), (200, 400), (500, 50), (600, 1)]
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_merging_sorted_input_stream(reverse):
+    pc = container()
+    t = table1000()
+    got, exp = run(pc, [cut(t, a, n) for a, n in SLICES], ["i8", "i16", "i32"], versions=["i8"], reverse=reverse)
+    assert got == exp
+    value = [a * 100 + b * 10 + c for a, b, c in zip(got["i8"], got["i16"], got["i32"])]
+    assert value == (list(range(600, -1, -1)) if reverse else list(range(601)))
+
+
+def test_merging_sorted_input_stream_replace():
+    pc = container()
+    t = table1000()
+    sources = []
+    for snap, start in enumerate((0, 200, 400, 600)):
+        s = cut(t, start, 400)
+        s["snap"] = np.full(400, snap, np.uint64)
+        sources.append(s)
+    got, exp = run(pc, sources, ["i8", "i16", "i32"], versions=["snap"])
+    assert got == exp
+    assert len(got["snap"]) == 1000 and {v: got["snap"].count(v) for v in range(4)} == {0: 200, 1: 200, 2: 200, 3: 400}
+
+
+def random_sources(rng, nsources, max_rows, key_space, string_key=False, dup_in_source=False):
+    sources = []
+    for s in range(nsources):
+        n = int(rng.integers(0, max_rows + 1))
+        k1 = np.sort(rng.integers(-key_space, key_space, n)).astype(np.int64)
+        k2 = rng.integers(0, 3, n).astype(np.uint16)
+        order = np.lexsort((k2, k1))
+        k1, k2 = k1[order], k2[order]
+        if not dup_in_source and n:
+            keep = np.ones(n, bool)
+            keep[1:] = (k1[1:] != k1[:-1]) | (k2[1:] != k2[:-1])
+            k1, k2 = k1[keep], k2[keep]
+            n = len(k1)
+        src = {"k1": k1, "k2": k2, "ver": rng.permutation(1000 * nsources)[:n].astype(np.uint64) if n else np.zeros(0, np.uint64),
+               "payload": rng.random(n), "src": np.full(n, s, np.int32)}
+        if string_key:
+            words = sorted({"w%03d" % int(x) for x in rng.integers(0, key_space, n)} | {"", "w", "w0000"})
+            idx = np.sort(rng.integers(0, len(words), n))
+            src["k1"] = [words[i] for i in idx]
+            o = sorted(range(n), key=lambda i: (src["k1"][i].encode(), int(k2[i])))
+            if not dup_in_source:
+                seen, o2 = set(), []
+                for i in o:
+                    key = (src["k1"][i], int(k2[i]))
+                    if key not in seen:
+                        seen.add(key)
+                        o2.append(i)
+                o = o2
+            for name in ("k2", "ver", "payload", "src"):
+                src[name] = src[name][o]
+            src["k1"] = [src["k1"][i] for i in o]
+        sources.append(src)
+    return sources
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sources_against_the_oracle(seed):
+    rng = np.random.default_rng(500 + seed)
+    pc = container()
+    nsources = int(rng.integers(1, 8))
+    sources = random_sources(rng, nsources, max_rows=int(rng.choice([5, 300, 5000])), key_space=int(rng.choice([10, 200, 100000])),
+                             string_key=bool(seed % 3 == 2), dup_in_source=bool(seed % 4 == 1))
+    if all(len(s["k2"]) == 0 for s in sources):
+        sources[0] = random_sources(rng, 1, 10, 5)[0]
+    filters = None
+    if seed % 2 == 1:
+        filters = [None if rng.random() < 0.3 else list(rng.random(len(s["k2"])) > rng.choice([0.0, 0.4, 1.0])) for s in sources]
+    for reverse in (False, True):
+        got, exp = run(pc, sources, ["k1", "k2"], versions=["ver"], reverse=reverse, filters=filters)
+        if got is None:
+            assert all(len(s["k2"]) == 0 or (filters and filters[i] is not None and not any(filters[i])) for i, s in enumerate(sources))
+            continue
+        assert got == exp, (seed, reverse)
+
+
+def test_merge_at_scale_is_sorted_unique_and_keeps_the_newest():
+    """16 sources of 500 k rows over a key space of 3 M: every key once, ascending, with the greatest version among the
+    sources that hold it; the payload identifies the row that won."""
+    import torch  # noqa: F401
+    pc = container()
+    from ydb_amd.merger import MergePartialStream
+    rng = np.random.default_rng(99)
+    nsources, rows, space = 16, 500_000, 3_000_000
+    merger = MergePartialStream(pc, ["k"], version_columns=["ver"])
+    best = {}
+    newest = np.full(space, -1, np.int64)
+    for s in range(nsources):
+        k = np.sort(rng.choice(space, rows, replace=False)).astype(np.int64)
+        ver = np.full(rows, (s * 7) % nsources, np.uint64)  # distinct per source
+        newest[k] = np.maximum(newest[k], int(ver[0]))
+        merger.AddSource(pc.Import({"k": k, "ver": ver, "src": np.full(rows, s, np.int32)}))
+    out = pc.Export(merger.DrainAll())
+    k = np.asarray(out["k"].values)
+    assert len(k) == int((newest >= 0).sum())
+    assert (np.diff(k) > 0).all()
+    assert (np.asarray(out["ver"].values).astype(np.int64) == newest[k]).all()
+    assert ((np.asarray(out["src"].values) * 7) % nsources == np.asarray(out["ver"].values)).all()
+    del best

@@ -1,0 +1,72 @@
+"""The merge oracle against the reference's own merger tests (ydb/core/formats/arrow/ut/ut_arrow.cpp:655-740):
+MergingSortedInputStream, MergingSortedInputStreamReversed and MergingSortedInputStreamReplace over MakeTable1000
+(ut_arrow.cpp:413-432), plus by-hand cases of deleted rows."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import merge_oracle  # noqa: E402
+
+
+def table1000():
+    """MakeTable1000: row i = (i8 i / 100, i16 (i % 100) / 10, i32 i % 10), sorted by the three."""
+    return {"i8": [i // 100 for i in range(1000)], "i16": [(i % 100) // 10 for i in range(1000)], "i32": [i % 10 for i in range(1000)]}
+
+
+def cut(t, start, count):
+    return {k: v[start:start + count] for k, v in t.items()}
+
+
+def restore(t, i):
+    return t["i8"][i] * 100 + t["i16"][i] * 10 + t["i32"][i]
+
+
+SLICES = [(0, 100), (100, 200), (200, 400), (500, 50), (600, 1)]
+
+
+def test_merging_sorted_input_stream():
+    t = table1000()
+    got = merge_oracle.drain_all([cut(t, a, n) for a, n in SLICES], ["i8", "i16", "i32"], versions=["i8"])
+    assert len(got["i8"]) == 601  # UNIT_ASSERT_VALUES_EQUAL(sorted->num_rows(), 601)
+    assert [restore(got, i) for i in range(601)] == list(range(601))
+
+
+def test_merging_sorted_input_stream_reversed():
+    t = table1000()
+    got = merge_oracle.drain_all([cut(t, a, n) for a, n in SLICES], ["i8", "i16", "i32"], versions=["i8"], reverse=True)
+    assert len(got["i8"]) == 601
+    assert [restore(got, i) for i in range(601)] == list(range(600, -1, -1))
+
+
+def test_merging_sorted_input_stream_replace():
+    t = table1000()
+    sources = []
+    for snap, start in enumerate((0, 200, 400, 600)):
+        s = cut(t, start, 400)
+        s["snap"] = [snap] * 400  # AddSnapColumn
+        sources.append(s)
+    got = merge_oracle.drain_all(sources, ["i8", "i16", "i32"], versions=["snap"])
+    assert len(got["i8"]) == 1000
+    assert [restore(got, i) for i in range(1000)] == list(range(1000))  # CheckSorted1000, IsSortedAndUnique
+    counts = {v: got["snap"].count(v) for v in range(4)}
+    assert counts == {0: 200, 1: 200, 2: 200, 3: 400}
+
+
+def test_a_deleted_newest_version_hides_its_key():
+    # key 2: the newest version (source 1) is deleted -> the key is gone, the older row of source 0 is skipped with it
+    # key 3: only the older version is deleted -> the newest stays
+    a = {"k": [1, 2, 3], "v": [1, 1, 1], "x": [10, 20, 30]}
+    b = {"k": [2, 3, 4], "v": [2, 2, 2], "x": [21, 31, 41]}
+    got = merge_oracle.drain_all([a, b], ["k"], versions=["v"], filters=[[True, True, False], [False, True, True]])
+    assert got == {"k": [1, 3, 4], "v": [1, 2, 2], "x": [10, 31, 41]}
+    # duplicates inside one source: its iterator shows the heap the first of them (the last when reading from the end),
+    # the others are skipped whatever their version; sources that are deleted as a whole take no part
+    c = {"k": [5, 5, 6], "v": [1, 2, 1], "x": [1, 2, 3]}
+    got = merge_oracle.drain_all([c, a], ["k"], versions=["v"], filters=[None, [False, False, False]])
+    assert got == {"k": [5, 6], "v": [1, 1], "x": [1, 3]}
+    got = merge_oracle.drain_all([c], ["k"], versions=["v"], reverse=True)
+    assert got == {"k": [6, 5], "v": [1, 2], "x": [3, 2]}
+    d = {"k": [5, 7], "v": [3, 0], "x": [9, 8]}
+    got = merge_oracle.drain_all([c, d], ["k"], versions=["v"])
+    assert got == {"k": [5, 6, 7], "v": [3, 1, 0], "x": [9, 3, 8]}

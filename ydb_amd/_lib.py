@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = [
     "ssa_program_step_count", "ssa_program_explain", "ssa_program_apply", "ssa_program_build_filter", "ssa_batch_import",
     "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_program_apply_many", "ssa_apply_many_stats",
     "ssa_batch_pack_layout", "ssa_batch_pack_data", "ssa_batch_unpack", "ssa_batch_concat", "ssa_batch_slice", "ssa_batch_rename",
-    "ssa_batch_column_name", "ssa_batch_export", "ssa_batch_rows",
+    "ssa_batch_column_name", "ssa_merge_sorted", "ssa_batch_export", "ssa_batch_rows",
     "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
     "ssa_gen_lineitem",
     "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
@@ -119,6 +119,8 @@ def load() -> ctypes.CDLL:
     lib.ssa_batch_rename.restype = i32
     lib.ssa_batch_column_name.argtypes = [vp, sz]
     lib.ssa_batch_column_name.restype = vp
+    lib.ssa_merge_sorted.argtypes = [vp, P(vp), P(vp), sz, P(cp), sz, P(cp), sz, i32, P(vp), P(vp)]
+    lib.ssa_merge_sorted.restype = i32
     lib.ssa_apply_many_stats.argtypes = [P(i64), P(i64)]
     lib.ssa_apply_many_stats.restype = None
     lib.ssa_program_apply_device.argtypes = [vp, vp, P(vp), P(vp)]

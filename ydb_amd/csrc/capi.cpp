@@ -506,6 +506,33 @@ char* ssa_batch_column_name(const ssa_batch_t* batch, size_t i) {
     return DupString(batch->Batch->Cols[i].Field.Name);
 }
 
+int ssa_merge_sorted(ssa_program_t* program, const ssa_batch_t* const* sources, const ssa_filter_t* const* filters, size_t n_sources,
+                     const char* const* key_columns, size_t n_keys, const char* const* version_columns, size_t n_versions, int reverse,
+                     ssa_batch_t** out, char** err) {
+    if (err) *err = nullptr;
+    if (!sources || n_sources == 0) return Fail(Status::Invalid("no sources"), err);
+    std::lock_guard<std::mutex> g(program->Lock);
+    {
+        Status est = EnsureExecutor(program);
+        if (!est.ok()) return Fail(est, err);
+    }
+    std::vector<BatchPtr> in;
+    std::vector<FilterPtr> fs;
+    for (size_t i = 0; i < n_sources; ++i) {
+        if (!sources[i]) return Fail(Status::Invalid("null source"), err);
+        in.push_back(sources[i]->Batch);
+        if (filters) fs.push_back(filters[i] ? filters[i]->Filter : nullptr);
+    }
+    std::vector<std::string> keys, versions;
+    for (size_t i = 0; i < n_keys; ++i) keys.emplace_back(key_columns[i] ? key_columns[i] : "");
+    for (size_t i = 0; i < n_versions; ++i) versions.emplace_back(version_columns[i] ? version_columns[i] : "");
+    BatchPtr res;
+    Status st = program->Exec->MergeSorted(in, fs, keys, versions, reverse != 0, res);
+    if (!st.ok()) return Fail(st, err);
+    *out = new ssa_batch{res};
+    return SSA_OK;
+}
+
 void ssa_shutdown(void) { ssa::KernelJit::Instance().Shutdown(); }
 
 void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_slice) {

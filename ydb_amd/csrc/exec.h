@@ -203,6 +203,13 @@ public:
     Status PackData(const Batch& in, void* dst, size_t capacity);
     Status ConcatBatches(const std::vector<BatchPtr>& parts, BatchPtr& out);
 
+    // TMergePartialStream::AddSource + DrainAll (ydb/core/formats/arrow/reader/merger.h:78-95): sources sorted by
+    // `keyNames` (ascending), merged into one batch sorted by them (descending when `reverse`) where every key appears
+    // once, with the row of its greatest `versionNames`; a key whose newest row is denied by its source's filter does not
+    // appear.  filters: empty, or one per source (null = none).
+    Status MergeSorted(const std::vector<BatchPtr>& sources, const std::vector<FilterPtr>& filters, const std::vector<std::string>& keyNames,
+                       const std::vector<std::string>& versionNames, bool reverse, BatchPtr& out);
+
     Status Sync();
     hipStream_t Stream() const { return StreamHandle; }
     KernelProfile Profile;

@@ -246,6 +246,36 @@ struct PredicateKeys {
     int32_t nkeys;
     PredicateKey cols[kMaxShardKeys];
 };
+// ---- k-way merge of sorted sources (merge_kernels.hip) ----------------------------------------------------
+constexpr int32_t PK_DEC128 = 6;  // (a PredicateKind for the merge's comparisons only)
+constexpr int kMaxMergeKeys = 12;  // key columns + version columns
+struct MergeKeyColumn {
+    const void* values;    // fixed-width values, or int32 offsets of a string column
+    const uint8_t* chars;  // string columns only
+    int32_t kind;          // PredicateKind / PK_DEC128
+    int32_t width;
+};
+struct MergeKeys {
+    int32_t nkeys, nversions;  // cols[0 .. nkeys): the sort key; cols[nkeys .. nkeys + nversions): the version, newest first
+    MergeKeyColumn cols[kMaxMergeKeys];
+};
+// One tile of one round's output: the rows of runs in[s, m) and in[m, e) merged, from diagonal d0 on.
+struct MergeTile {
+    uint64_t s, m, e, d0;
+};
+int MergeTileRows();
+// One round: every tile's part of the merge of its two runs (row ids in `in`) into `out`; splits: 2 * ntiles words of scratch.
+hipError_t LaunchMergeRound(const MergeKeys& keys, const uint64_t* in, uint64_t* out, const MergeTile* deviceTiles, int64_t ntiles, uint64_t* splits,
+                            hipStream_t st);
+// bits: bit i set when sorted[i] is the first row of its key and keep[sorted[i]] != 0 (keep may be nullptr: all kept)
+hipError_t LaunchMergeWinners(const MergeKeys& keys, const uint64_t* sorted, int64_t n, const uint8_t* keep, uint64_t* bits, hipStream_t st);
+// bit r: row r is the first of a run of equal keys inside its source (the last when `reverse`); boundary[r] = 1 where a source begins
+hipError_t LaunchMergeCandidates(const MergeKeys& keys, int64_t n, const uint8_t* boundary, bool reverse, uint64_t* bits, hipStream_t st);
+// out[j] = number of ids (ascending, n of them) below bounds[j]
+hipError_t LaunchCountBelow(const uint64_t* ids, int64_t n, const uint64_t* bounds, int nbounds, uint64_t* out, hipStream_t st);
+hipError_t LaunchIotaU64(uint64_t* out, int64_t n, hipStream_t st);
+hipError_t LaunchReverseU64(const uint64_t* in, int64_t n, uint64_t* out, hipStream_t st);
+
 hipError_t LaunchExpandRuns(const uint32_t* starts, int64_t nruns, int firstValue, int64_t nbits, uint64_t* bits, hipStream_t st);
 hipError_t LaunchTransitionCount(const uint64_t* bits, int64_t nbits, uint32_t* counts, hipStream_t st);
 hipError_t LaunchTransitionScatter(const uint64_t* bits, int64_t nbits, const int64_t* offsets, uint32_t* starts, hipStream_t st);
