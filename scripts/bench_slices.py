@@ -1,3 +1,5 @@
+"""Q1 (utf8 flags, 1-byte codes) and Q6 over 64 slices of 2^20 rows of one resident table: ssa_program_apply_many against
+one ssa_program_apply_device per slice.  Run from the repository root: PYTHONPATH=. python scripts/bench_slices.py"""
 import sys, time
 import numpy as np
 import torch

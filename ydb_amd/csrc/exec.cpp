@@ -1902,7 +1902,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 image.table_mask = 0;
                 image.acc_stride = 0;
                 std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(specRows) + "\n#define SSA_SPEC_HASHED " +
-                                      (hashed ? "1" : "0") + "\n";
+                                      (hashed ? "1" : "0") + "\n#define SSA_SPEC_SLICES " + (many ? "1" : "0") + "\n";
                 if (std::getenv("SSA_PHASE_TIMING")) defines += "#define SSA_PHASE_TIMING 1\n";  // diagnostics
                 ScanRowsPerThread = specRows;
                 spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, sargs, &image, sizeof(image), totalRows, specCfg);

@@ -420,8 +420,13 @@ __device__ __forceinline__ void ScanKeyedBody() {
     constexpr bool kStatic = false;
 #endif
 #define SSA_ROW(table, expr, i) (kStatic ? uint32_t(expr) : ReadLane32(table, i))
-    // a launch over several slices: this workgroup's slice, its rows and its part of the level-2 table
+    // a launch over several slices: this workgroup's slice, its rows and its part of the level-2 table.  (A kernel built
+    // for a step program is built for one kind of launch: in the one for single batches none of this is left.)
+#if defined(SSA_SPEC) && !SSA_SPEC_SLICES
+    const SliceDesc* slice = nullptr;
+#else
     const SliceDesc* slice = a.slices != nullptr ? a.slices + __builtin_amdgcn_readfirstlane(a.block_slice[blockIdx.x]) : nullptr;
+#endif
     Machine<U> m(a, slice);
     const uint64_t tableOff = slice != nullptr ? Uniform64(slice->table_off) : 0ull;
     const int64_t firstTile = slice != nullptr ? int64_t(blockIdx.x) - __builtin_amdgcn_readfirstlane(slice->first_block) : int64_t(blockIdx.x);

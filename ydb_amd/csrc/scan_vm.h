@@ -234,6 +234,12 @@ struct Machine {
     int ncode;
     const DevColumn* cols;       // the batch's columns: of the launch, or of this workgroup's slice
     const OffsetCheck* checks;
+#ifdef SSA_SPEC
+    // the offset checks' addresses in scalar registers (read once: a load through `checks` per tile would sit in front
+    // of the tile's offset loads)
+    uint64_t ckOffsets[kMaxOffsetChecks];
+    uint32_t ckFirst[kMaxOffsetChecks];
+#endif
 
     // `slice`: this workgroup scans one slice of a launch over several (SliceDesc), else nullptr
     __device__ __forceinline__ explicit Machine(const ScanArgs& args, const SliceDesc* slice = nullptr) : a(args), err(0) {
@@ -241,6 +247,14 @@ struct Machine {
         nrows = slice != nullptr ? int64_t(Uniform64(uint64_t(slice->nrows))) : a.nrows;
         cols = slice != nullptr ? slice->cols : a.cols;
         checks = slice != nullptr ? slice->checks : a.checks;
+#ifdef SSA_SPEC
+#pragma unroll
+        for (int i = 0; i < kMaxOffsetChecks; ++i) {
+            const bool used = i < reinterpret_cast<const ScanArgs*>(kSpecImage)->nchecks;
+            ckOffsets[i] = used ? Uniform64(reinterpret_cast<uint64_t>(checks[i].offsets)) : 0ull;
+            ckFirst[i] = used ? uint32_t(__builtin_amdgcn_readfirstlane(int(checks[i].first))) : 0u;
+        }
+#endif
         ncode = a.ncode;
         tCode0 = lane < ncode ? a.code[3 * lane] : 0u;
         tCode1 = lane < ncode ? a.code[3 * lane + 1] : 0u;
@@ -374,13 +388,22 @@ struct Machine {
         // with the copies above; the generic kernels, which have no registers to spare (a spilled lane table is not
         // restored in the lanes that are inactive at the reload), load and compare one column at a time afterwards.
         const int64_t ckRow = slice0 + int64_t(U) * lane;
+        // (the address comes out of a register or through a pointer of unknown provenance: without the address space
+        // spelled out these would be FLAT loads, which count against the LDS counter as well and stall the tile's LDS work)
+        typedef const __attribute__((address_space(1))) int32_t* GlobalI32;
+        typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) U32x4* GlobalU4;
         auto loadOffsets = [&](int i, uint32_t* v) {
-            const int32_t* offs = checks[i].offsets + ckRow;
+#ifdef SSA_SPEC
+            GlobalI32 offs = (GlobalI32)(ckOffsets[i]) + ckRow;
+#else
+            GlobalI32 offs = (GlobalI32)(reinterpret_cast<uint64_t>(checks[i].offsets)) + ckRow;
+#endif
             if (full) {
                 if constexpr (U % 4 == 0) {
 #pragma unroll
                     for (int j = 0; j < U; j += 4) {
-                        const uint4 q = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(offs + j, 16));
+                        const U32x4 q = *(GlobalU4)(offs + j);
                         v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
                     }
                 } else {
@@ -393,7 +416,11 @@ struct Machine {
             }
         };
         auto compareOffsets = [&](int i, const uint32_t* v) {
+#ifdef SSA_SPEC
+            const uint32_t first = ckFirst[i], len = S().checks[i].len;
+#else
             const uint32_t first = checks[i].first, len = S().checks[i].len;
+#endif
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const uint32_t want = first + len * uint32_t(ckRow + j);
