@@ -61,6 +61,40 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
         uint32_t ip = 0;
         const uint64_t blockStart = op;
         while (ip < n) {
+            // The common sequence -- at most five literals, a match of at most 18 bytes -- lies inside the eight bytes
+            // that start at its token: one LDS round trip brings token, literals and offset, a second the match's source.
+            // (The staged block is followed by 32 readable bytes.)  Everything else, and the end of a block, takes the
+            // general code below.
+            {
+                uint64_t w = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w |= uint64_t(q[ip + k]) << (8 * k);
+                const uint32_t tk = uint32_t(w) & 0xFFu, fl = tk >> 4, fm = (tk & 15u) + 4u;
+                if (fl <= 5u && (tk & 15u) != 15u && ip + 3u + fl <= n) {
+                    const uint32_t off = uint32_t(w >> (8u * (1u + fl))) & 0xFFFFu;
+                    const uint64_t mp = op + fl;  // where the match lands
+                    const uint64_t reach = t.linked ? mp : mp - blockStart;
+                    if (off == 0 || off > reach || mp + fm > t.dst_bytes) {
+                        bad = true;
+                        break;
+                    }
+                    if (lane < fl) {
+                        const uint8_t x = uint8_t(w >> (8u * (1u + lane)));
+                        ring[(op + lane) & (kRing - 1)] = x;
+                        dst[op + lane] = x;
+                    }
+                    if (lane < fm) {
+                        uint32_t r = lane;
+                        if (off < fm) r = lane - off * uint32_t(__fdividef(float(lane) + 0.5f, float(off)));  // lane % off (lane < 19)
+                        const uint8_t x = ring[(mp - off + r) & (kRing - 1)];
+                        ring[(mp + lane) & (kRing - 1)] = x;
+                        dst[mp + lane] = x;
+                    }
+                    ip += 3u + fl;
+                    op = mp + fm;
+                    continue;
+                }
+            }
             const uint32_t token = q[ip++];
             uint32_t lit = token >> 4;
             if (lit == 15) {
