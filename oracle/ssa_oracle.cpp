@@ -1385,6 +1385,15 @@ static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
                 for (int64_t r = 0; r < n; ++r) out->u[r] = LikeRegexMatch(args[0]->s[r], a.pattern);
                 return out;
             }
+            // The reference matches ignore_case patterns with RE2, which folds Unicode: a pattern byte >= 0x80 starts a
+            // character with its own case orbit, and 'k' / 's' also match U+212A KELVIN SIGN / U+017F LONG S
+            // (arrow/compute/kernels/scalar_string.cc, MatchSubstring with ignore_case -> RE2::Options::set_case_sensitive(false)).
+            // Folding ASCII letters only is the same thing for every other pattern; those are declined.
+            if (a.ignoreCase) {
+                for (unsigned char ch : pat) {
+                    if (ch >= 0x80 || ch == 'k' || ch == 'K' || ch == 's' || ch == 'S') throw Error("Unsupported: case-insensitive match whose pattern needs Unicode case folding");
+                }
+            }
             return StringMatch(kind, a.ignoreCase, args[0], pat, true, BOOL);
         }
         case OP_CAST: {

@@ -691,3 +691,21 @@ def test_string_min_max_some(n, jit, monkeypatch):
             p.group_by(aggs, keys=keys)
             got, exp = both(res, p, batch)
             compare_batches(got, exp, key_names=names)
+
+
+def test_ignore_case_patterns_that_need_unicode_folding_are_declined():
+    """The reference matches ignore_case patterns with RE2, which folds Unicode ('k' also matches U+212A, 's' U+017F, 'é'
+    matches 'É'); the device folds ASCII letters only, so such patterns are refused (the caller's CPU path takes them),
+    while patterns of other ASCII characters still match, also in data that holds non-ASCII text."""
+    from ydb_amd.ssa_pb import F
+    values = ["Kelvin K", "mass", "MASS", "lonſ", "École", "école", "abc", "ABC déjà"]
+    for fid in (F.STR_MATCH_IGNORE_CASE, F.STR_STARTS_WITH_IGNORE_CASE, F.STR_ENDS_WITH_IGNORE_CASE):
+        for pattern in ("k", "S", "mass", "é", "déj"):
+            prog = (Program().assign_const(Column(name="pat"), "Bytes", pattern.encode())
+                    .assign_func(Column(name="res"), fid, [1, "pat"]).project(["res"]))
+            g, o = both_fail([(1, "x")], prog, {"x": Col(values, type="string")})
+            assert "UNSUPPORTED" in g and "Unsupported" in o, (pattern, g, o)
+        prog = (Program().assign_const(Column(name="pat"), "Bytes", b"AB")
+                .assign_func(Column(name="res"), fid, [1, "pat"]).project(["res"]))
+        got, exp = both([(1, "x")], prog, {"x": Col(values, type="string")})
+        compare_batches(got, exp)

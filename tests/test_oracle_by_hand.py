@@ -61,3 +61,23 @@ def test_unsafe_float_to_integer_casts_follow_the_x86_conversions():
         p = Program().assign_func(100, fid, [1]).project([100])
         out = ssa_oracle.Oracle([(1, "f")], p).apply({"f": vals})
         assert out["100"].to_pylist() == expect, (fid, out["100"].to_pylist())
+
+
+def test_ignore_case_patterns_that_need_unicode_folding_are_declined_by_the_oracle():
+    """RE2 (the reference's ignore_case matcher) folds Unicode; the restatement folds ASCII letters only and says so for
+    the patterns where that differs: bytes >= 0x80 and the letters k / s (U+212A, U+017F)."""
+    import pytest
+    from oracle import ssa_oracle
+    from ydb_amd.arrow_c import Col
+    from ydb_amd.ssa_pb import Column, F, Program
+    values = ["Kelvin", "mass", "École", "abc"]
+    for pattern, ok in (("ab", True), ("k", False), ("S", False), ("é", False), ("C", True)):
+        prog = (Program().assign_const(Column(name="pat"), "Bytes", pattern.encode())
+                .assign_func(Column(name="res"), F.STR_MATCH_IGNORE_CASE, [1, "pat"]).project(["res"]))
+        orc = ssa_oracle.Oracle([(1, "x")], prog)
+        if ok:
+            res = orc.apply({"x": Col(values, type="string")})["res"].to_pylist()
+            assert [bool(v) for v in res] == [pattern.lower() in v.lower() for v in values]
+        else:
+            with pytest.raises(ssa_oracle.OracleError, match="Unsupported"):
+                orc.apply({"x": Col(values, type="string")})

@@ -1905,7 +1905,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                                       (hashed ? "1" : "0") + "\n#define SSA_SPEC_SLICES " + (many ? "1" : "0") + "\n";
                 if (std::getenv("SSA_PHASE_TIMING")) defines += "#define SSA_PHASE_TIMING 1\n";  // diagnostics
                 ScanRowsPerThread = specRows;
-                spec = SpecializedKernel("keyed_scan.h", "ssa_spec_keyed", defines, sargs, &image, sizeof(image), totalRows, specCfg);
+                spec = SpecializedKernel("keyed_scan.h", hotMode ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines, sargs, &image, sizeof(image), totalRows, specCfg);
                 ScanRowsPerThread = kRowsPerThread;
             }
             timedRun = timedRun && spec != nullptr;

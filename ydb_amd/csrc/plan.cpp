@@ -605,14 +605,17 @@ struct Compiler {
             case EOperation::MatchSubstring:
                 if (!a.HasMatchOptions) return Status::Invalid("MatchSubstringOptions required");
                 if (!IsStringLike(args[0]->Type)) return Status::Invalid(NoKernel(fn, args[0]->Type, T_NONE));
+                if (a.IgnoreCase && NeedsUnicodeFold(a.Pattern)) return Status::Unsupported(kUnicodeFold);
                 return StrMatchNode(STR_CONTAINS, a.IgnoreCase, args[0], a.Pattern, true, T_BOOL, out);
             case EOperation::StartsWith:
                 if (!a.HasMatchOptions) return Status::Invalid("MatchSubstringOptions required");
                 if (!IsStringLike(args[0]->Type)) return Status::Invalid(NoKernel(fn, args[0]->Type, T_NONE));
+                if (a.IgnoreCase && NeedsUnicodeFold(a.Pattern)) return Status::Unsupported(kUnicodeFold);
                 return StrMatchNode(STR_STARTS, a.IgnoreCase, args[0], a.Pattern, true, T_BOOL, out);
             case EOperation::EndsWith:
                 if (!a.HasMatchOptions) return Status::Invalid("MatchSubstringOptions required");
                 if (!IsStringLike(args[0]->Type)) return Status::Invalid(NoKernel(fn, args[0]->Type, T_NONE));
+                if (a.IgnoreCase && NeedsUnicodeFold(a.Pattern)) return Status::Unsupported(kUnicodeFold);
                 return StrMatchNode(STR_ENDS, a.IgnoreCase, args[0], a.Pattern, true, T_BOOL, out);
             case EOperation::MatchLike: {
                 if (!a.HasMatchOptions) return Status::Invalid("MatchSubstringOptions required");
@@ -625,11 +628,23 @@ struct Compiler {
                     if (a.IgnoreCase) return Status::Unsupported("case-insensitive general LIKE pattern");
                     return StrMatchNode(STR_LIKE, false, args[0], a.Pattern, true, T_BOOL, out);
                 }
+                if (a.IgnoreCase && NeedsUnicodeFold(lit)) return Status::Unsupported(kUnicodeFold);
                 return StrMatchNode(kind, a.IgnoreCase, args[0], lit, true, T_BOOL, out);
             }
             default:
                 return Status::Unsupported("operation is not available on the GPU path");
         }
+    }
+
+    // The reference matches ignore_case patterns with RE2, which folds Unicode: a pattern byte >= 0x80 starts a character
+    // with a case orbit of its own, and 'k' / 's' also match U+212A KELVIN SIGN / U+017F LONG S.  The device folds ASCII
+    // letters only -- the same thing for every other pattern -- so those patterns go back to the CPU.
+    static constexpr const char* kUnicodeFold = "case-insensitive match whose pattern needs Unicode case folding";
+    static bool NeedsUnicodeFold(const std::string& pattern) {
+        for (unsigned char ch : pattern) {
+            if (ch >= 0x80 || ch == 'k' || ch == 'K' || ch == 's' || ch == 'S') return true;
+        }
+        return false;
     }
 
     static ExprPtr DecimalPart(const ExprPtr& col, int part) {
