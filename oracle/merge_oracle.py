@@ -95,3 +95,49 @@ def drain_all(sources: Sequence[Dict[str, list]], sort: Sequence[str], versions:
                 heapq.heappop(items)
             first = False
     return out
+
+
+def drain_current_to(sources: Sequence[Dict[str, list]], sort: Sequence[str], read_to: Sequence, include_finish: bool, versions: Sequence[str] = (),
+                     filters: Optional[Sequence[Optional[Sequence[bool]]]] = None):
+    """TMergePartialStream::DrainCurrentTo (merger.cpp:39-70) in forward order: a control point with the key `read_to` is
+    put into the heap, where it sorts in front of the rows of its own key (batch_iterator.cpp:33-42); positions are
+    drained until it is reached, and the position of its key as well when `include_finish` (merger.cpp:47-59).
+    Returns (drained rows, what is left of every source, what is left of every filter)."""
+    names = list(sources[0].keys()) if sources else []
+    out: Dict[str, list] = {n: [] for n in names}
+    border = tuple(read_to)
+    heap = []
+    for i, s in enumerate(sources):
+        keep = filters[i] if filters else None
+        if len(s[sort[0]]) == 0:
+            continue
+        heap.append(_Iterator(i, s, keep, sort, versions, False))
+    wrap = functools.cmp_to_key(_order)
+    items = [wrap(it) for it in heap]
+    heapq.heapify(items)
+    reached = False
+    while items and not reached:
+        top = items[0].obj
+        if not top.key() < border:  # the control point is on top: it precedes rows of its own key and all greater ones
+            reached = True
+            if not include_finish or top.key() > border:
+                break
+        if not top.deleted():
+            for n in names:
+                out[n].append(top.source[n][top.pos])
+        start = top.key()
+        first = True
+        while items and (first or items[0].obj.key() == start):
+            cur = items[0].obj
+            if cur.next():
+                heapq.heapreplace(items, wrap(cur))
+            else:
+                heapq.heappop(items)
+            first = False
+    left_pos = {it.obj.index: it.obj.pos for it in items}
+    rest, rest_filters = [], []
+    for i, s in enumerate(sources):
+        p = left_pos.get(i, len(s[sort[0]]))
+        rest.append({n: v[p:] for n, v in s.items()})
+        rest_filters.append(None if not filters or filters[i] is None else list(filters[i][p:]))
+    return out, rest, rest_filters

@@ -155,3 +155,36 @@ def test_merge_at_scale_is_sorted_unique_and_keeps_the_newest():
     assert (np.asarray(out["ver"].values).astype(np.int64) == newest[k]).all()
     assert ((np.asarray(out["src"].values) * 7) % nsources == np.asarray(out["ver"].values)).all()
     del best
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_drain_current_to_against_the_oracle(seed):
+    """DrainCurrentTo in steps over random borders, then DrainAll: every step equals the oracle's control-point drain, and
+    the steps together are the whole merge."""
+    from oracle import merge_oracle
+    from ydb_amd.column_filter import ColumnFilter
+    from ydb_amd.merger import MergePartialStream
+    rng = np.random.default_rng(900 + seed)
+    pc = container()
+    sources = random_sources(rng, int(rng.integers(2, 6)), max_rows=2000, key_space=300)
+    sources = [s for s in sources if len(s["k2"])]
+    filters = [None if rng.random() < 0.5 else list(rng.random(len(s["k2"])) > 0.3) for s in sources] if seed % 2 else None
+    merger = MergePartialStream(pc, ["k1", "k2"], version_columns=["ver"])
+    for i, s in enumerate(sources):
+        f = ColumnFilter.FromValues(pc, filters[i]) if filters and filters[i] is not None else None
+        merger.AddSource(pc.Import({k: np.asarray(v) for k, v in s.items()}), f)
+    plain = [{k: [x.item() for x in np.asarray(v)] for k, v in s.items()} for s in sources]
+    pf = filters
+    for border in sorted(int(x) for x in rng.integers(-300, 300, 3)):
+        include = bool(rng.random() < 0.5)
+        exp, plain, pf = merge_oracle.drain_current_to(plain, ["k1", "k2"], [border, 1], include, ["ver"], pf)
+        out = merger.DrainCurrentTo({"k1": np.array([border], np.int64), "k2": np.array([1], np.uint16)}, include)
+        got = {k: [] for k in exp} if out is None else {k: [x.item() for x in c.values] for k, c in pc.Export(out).items()}
+        assert got == exp, (seed, border, include)
+    exp = merge_oracle.drain_all(plain, ["k1", "k2"], ["ver"], False, pf) if any(len(s["k2"]) for s in plain) else None
+    out = merger.DrainAll()
+    if exp is None or out is None:
+        assert out is None or out.rows == 0
+        assert exp is None or not exp["k1"]
+    else:
+        assert {k: [x.item() for x in c.values] for k, c in pc.Export(out).items()} == exp

@@ -70,3 +70,24 @@ def test_a_deleted_newest_version_hides_its_key():
     d = {"k": [5, 7], "v": [3, 0], "x": [9, 8]}
     got = merge_oracle.drain_all([c, d], ["k"], versions=["v"])
     assert got == {"k": [5, 6, 7], "v": [3, 1, 0], "x": [9, 3, 8]}
+
+
+def test_drain_current_to_stops_at_the_control_point():
+    a = {"k": [1, 3, 5, 7], "v": [1, 1, 1, 1]}
+    b = {"k": [2, 3, 6, 7], "v": [2, 2, 2, 2]}
+    got, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [5], include_finish=False, versions=["v"])
+    assert got == {"k": [1, 2, 3], "v": [1, 2, 2]}
+    assert rest == [{"k": [5, 7], "v": [1, 1]}, {"k": [6, 7], "v": [2, 2]}]
+    got, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [5], include_finish=True, versions=["v"])
+    assert got == {"k": [1, 2, 3, 5], "v": [1, 2, 2, 1]}
+    assert rest == [{"k": [7], "v": [1]}, {"k": [6, 7], "v": [2, 2]}]
+    # a border between keys, and one beyond every key
+    got, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [4], include_finish=True, versions=["v"])
+    assert got["k"] == [1, 2, 3] and rest[0]["k"] == [5, 7]
+    got, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [100], include_finish=False, versions=["v"])
+    assert got["k"] == [1, 2, 3, 5, 6, 7] and all(len(r["k"]) == 0 for r in rest)
+    # draining in two steps is draining in one
+    first, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [3], include_finish=True, versions=["v"])
+    second = merge_oracle.drain_all(rest, ["k"], ["v"])
+    whole = merge_oracle.drain_all([a, b], ["k"], ["v"])
+    assert {n: first[n] + second[n] for n in whole} == whole

@@ -37,6 +37,32 @@ class MergePartialStream:
     def IsEmpty(self) -> bool:
         return not self._sources
 
+    def DrainCurrentTo(self, read_to, include_finish: bool) -> Optional[DeviceBatch]:
+        """merger.cpp:39-70 (PutControlPoint + DrainToControlPoint): the merged rows whose key is below the border
+        `read_to` (a one-row batch of the sort columns) -- and equal to it when `include_finish`: the control point sorts
+        in front of the rows of its key (batch_iterator.cpp:33-42) and DrainToControlPoint drains that key only with
+        includeFinish.  The other rows stay in the stream for the next drain.  Every source is sorted, so the rows that
+        leave are a prefix of it: one predicate filter per source finds its length, the prefix goes through the merge,
+        the rest is kept as a view.  Forward order only."""
+        if self._reverse:
+            raise NotImplementedError("DrainCurrentTo over sources read from their ends")
+        from .column_filter import ColumnFilter
+        LESS, LESS_OR_EQUAL = 1, 2
+        head = MergePartialStream(self._pc, self._sort, False, self._versions)
+        rest_sources, rest_filters = [], []
+        for batch, flt in zip(self._sources, self._filters):
+            cut = ColumnFilter.MakePredicateFilter(self._pc, batch, read_to, LESS_OR_EQUAL if include_finish else LESS)
+            k = cut.GetFilteredCount()
+            k = batch.rows if k is None else k
+            bits = flt.BuildSimpleFilter() if flt is not None else None
+            if k > 0:
+                head.AddSource(self._pc.Slice(batch, 0, k), ColumnFilter.FromValues(self._pc, list(bits[:k])) if bits is not None else None)
+            if k < batch.rows:
+                rest_sources.append(self._pc.Slice(batch, k, batch.rows - k))
+                rest_filters.append(ColumnFilter.FromValues(self._pc, list(bits[k:])) if bits is not None else None)
+        self._sources, self._filters = rest_sources, rest_filters
+        return head.DrainAll()
+
     def DrainAll(self) -> Optional[DeviceBatch]:
         """merger.cpp:145-150.  None when there is no source to drain."""
         if not self._sources:
