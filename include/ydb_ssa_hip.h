@@ -201,6 +201,9 @@ char* ssa_batch_column_name(const ssa_batch_t* batch, size_t i);
 /* Process-wide counters: program steps ssa_program_apply_many ran over all their slices with one launch, and steps it
  * ran slice by slice. */
 void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_slice);
+/* Process-wide counter: GROUP BY scans that applied the rows missing the workgroups' own tables region by region of the
+ * table in HBM (groupings of a million groups and more take this way; SSA_KEYED_PARTITION=0 / 1 forbids / forces it). */
+void ssa_keyed_stats(int64_t* scans_applied_by_region);
 /* Download a batch into Arrow C Data structures. */
 int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, struct ArrowArray* out,
                      struct ArrowSchema* out_schema, char** err);

@@ -1632,6 +1632,8 @@ static int64_t AlgorithmicBytes(const StepPlan& plan, const Batch& in) {
 
 // `many`: the scan covers several slices of one schema in one launch (`in` is the first of them, the plan and the LDS
 // layout are made for it); the result holds the groups of all slices, slice after slice.
+std::atomic<int64_t> gKeyedStepsDeferred{0};
+
 Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
                               const std::vector<OffsetCheck>& checks, bool* notUniform, ManySlices* many) {
     *notUniform = false;
@@ -1859,6 +1861,36 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     }
     BufferPtr tLo, tHi, tAcc, tSeen, tRep;
     BufferPtr sliceDescs, blockSlices;  // a launch over slices: its descriptors on the device
+    // Groupings whose table is far larger than the caches: the scan leaves the rows that miss level 1 as records, which
+    // are then sorted by table region and applied region by region (DeferredArgs).  SSA_KEYED_PARTITION: 0 never, 1 always.
+    bool deferWanted = false;
+    int nvals = 0;
+    bool needMask = false;
+    {
+        const char* env = std::getenv("SSA_KEYED_PARTITION");
+        const int mode = env ? std::atoi(env) : -1;
+        bool can = !many && JitEnabled() && in.Rows > 0 && in.Rows < (int64_t(1) << 31) && naggs <= 31;
+        for (const AggSpec& a : phys) {
+            if (a.kind == AGG_MIN_S || a.kind == AGG_MAX_S) can = false;  // (their accumulators are rows compared by their strings)
+            if (a.kind != AGG_COUNT) ++nvals;
+            if (a.check_valid || a.kind == AGG_MIN_F || a.kind == AGG_MAX_F) needMask = true;
+        }
+        // (the records and their sorted copy: at most 32 GB of HBM)
+        const double recordBytes = 2.0 * double(in.Rows) * (8 + (twoWords ? 8 : 0) + 8 * nvals + (needMask ? 4 : 0) + (hashed ? 4 : 0));
+        can = can && recordBytes <= 32e9;
+        deferWanted = can && mode != 0 && (mode == 1 || (hint.Groups >= (int64_t(1) << 20) && in.Rows >= (int64_t(1) << 22)));
+        // (probing inside LDS is cheap: the table may be up to three quarters full, and everything that walks over it is
+        // the faster for it)
+        if (deferWanted && hint.Groups > 0) cap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(hint.Groups) + uint64_t(hint.Groups) / 3), 1024), maxCap);
+    }
+    BufferPtr recLo, recHi, recVal, recMask;
+    // slots of a region: what one workgroup holds in 48 KB of LDS (SSA_KEYED_REGION: experiments and tests)
+    int regionSlots = 4096;
+    while (regionSlots > 256 && size_t(regionSlots) * (8 + (twoWords ? 8 : 0) + (hashed ? 8 : 0) + 8 * size_t(naggs) + 4) > 48 * 1024) regionSlots >>= 1;
+    if (const char* env = std::getenv("SSA_KEYED_REGION")) {
+        const int r = std::atoi(env);
+        if (r >= 64 && r <= regionSlots && (r & (r - 1)) == 0) regionSlots = r;
+    }
     uint64_t totalCap = 0;
     for (;;) {
         totalCap = cap * nslices;  // every slice has a table of its own, one after the other
@@ -1870,6 +1902,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
         for (KeyedSink* k : {&sink, &ssink}) {
             k->table_mask = cap - 1;
+            k->region_mask = cap - 1;
             k->acc_stride = totalCap;
             k->t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
             k->t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
@@ -1883,6 +1916,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             SSA_HIP(LaunchKeyedTableInit(all, twoWords != 0, hashed, StreamHandle));
         }
         bool timedRun = false;
+        bool deferNow = false;
         int hotMode = 1;
         if (totalRows > 0) {
             // a scan of many rows runs the kernel built for this step program, when that can be had
@@ -1900,13 +1934,43 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 image.t_seen = nullptr;
                 image.t_rep_row = nullptr;
                 image.table_mask = 0;
+                image.region_mask = 0;
                 image.acc_stride = 0;
+                image.rec_lo = image.rec_hi = image.rec_val = nullptr;
+                image.rec_mask = nullptr;
                 std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(specRows) + "\n#define SSA_SPEC_HASHED " +
                                       (hashed ? "1" : "0") + "\n#define SSA_SPEC_SLICES " + (many ? "1" : "0") + "\n";
                 if (std::getenv("SSA_PHASE_TIMING")) defines += "#define SSA_PHASE_TIMING 1\n";  // diagnostics
                 ScanRowsPerThread = specRows;
-                spec = SpecializedKernel("keyed_scan.h", hotMode ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines, sargs, &image, sizeof(image), totalRows, specCfg);
+                // (more than 2^16 regions would take a third round of the sort: such tables are updated row by row)
+                if (deferWanted && cap / std::min<uint64_t>(cap, uint64_t(regionSlots)) <= 65536) {
+                    image.defer = 1;
+                    spec = SpecializedKernel("keyed_scan.h", hotMode ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines + "#define SSA_SPEC_DEFER 1\n",
+                                             sargs, &image, sizeof(image), totalRows, specCfg);
+                    deferNow = spec != nullptr;  // (still being built: this scan updates the table row by row)
+                }
+                if (!deferNow) {
+                    image.defer = 0;
+                    specCfg = scfg;
+                    spec = SpecializedKernel("keyed_scan.h", hotMode ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines, sargs, &image, sizeof(image), totalRows, specCfg);
+                }
                 ScanRowsPerThread = kRowsPerThread;
+            }
+            ssink.defer = deferNow ? 1 : 0;
+            ssink.region_mask = deferNow ? std::min<uint64_t>(cap, uint64_t(regionSlots)) - 1 : cap - 1;
+            if (deferNow) {
+                const size_t n = size_t(in.Rows);
+                if (!recLo) {
+                    recLo = Buffer::Alloc(n * 8);
+                    recHi = Buffer::Alloc(twoWords ? n * 8 : 64);
+                    recVal = Buffer::Alloc(size_t(nvals) * n * 8 + 64);
+                    recMask = Buffer::Alloc(needMask ? n * 4 : 64);
+                    if (!recLo || !recHi || !recVal || !recMask) return Status::Hip("out of device memory");
+                }
+                ssink.rec_lo = static_cast<uint64_t*>(recLo->Ptr);
+                ssink.rec_hi = static_cast<uint64_t*>(recHi->Ptr);
+                ssink.rec_val = static_cast<uint64_t*>(recVal->Ptr);
+                ssink.rec_mask = needMask ? static_cast<uint32_t*>(recMask->Ptr) : nullptr;
             }
             timedRun = timedRun && spec != nullptr;
             if (many) {
@@ -1942,6 +2006,11 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 (hotMode ? hint.MsPerRowOn : hint.MsPerRowOff) = double(ms) / double(in.Rows);
                 if (hint.MsPerRowOn > 0 && hint.MsPerRowOff > 0) hint.HotChoice = hint.MsPerRowOn <= hint.MsPerRowOff ? 1 : 0;
             }
+        }
+        if (!tableFull && deferNow) {
+            SSA_RETURN_NOT_OK(ApplyDeferredRecords(ssink, sargs, in.Rows, nvals, needMask, regionSlots, cap));
+            gKeyedStepsDeferred.fetch_add(1, std::memory_order_relaxed);
+            SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull, nullptr));
         }
         if (!tableFull) break;
         if (cap >= maxCap) return Status::Invalid("internal: group-by table overflow");
@@ -1980,6 +2049,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     // otherwise queue on single addresses in HBM (ClickBench SearchPhrase: 1046 ms without level 1, 3.6 ms with it).
     hint.LdsCap = maxGroups <= 8 ? 16 : 256;
     hint.ManyGroups = maxGroups > 128;
+    hint.Groups = maxGroups;
 
     KeyedFinalizeArgs fa{};
     fa.capacity = cap;

@@ -56,6 +56,7 @@ struct DictLowering;
 extern std::atomic<int64_t> gDictStepsOnCodes, gDictColumnsDecoded;
 // ... sets of slices (of one schema, under one step) that ApplyProgramMany scanned with one launch; sets it ran slice by slice.
 extern std::atomic<int64_t> gManyStepsOneLaunch, gManyStepsPerSlice;
+extern std::atomic<int64_t> gKeyedStepsDeferred;  // keyed scans whose level-2 updates were applied region by region
 
 struct Column {
     FieldDesc Field;         // name, type, nullable (validity present), scalar flag + value
@@ -232,6 +233,8 @@ private:
     Status RunKeyedUniform(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out, bool& done);
     Status RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
                         const std::vector<OffsetCheck>& checks, bool* notUniform, ManySlices* many = nullptr);
+    Status ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& args, int64_t rows, int nvals, bool needMask, int regionSlots,
+                                uint64_t cap);
     Status DescribeSlices(const StepPlan& plan, ManySlices& many, ScanArgs& args, int64_t tileRows, uint64_t cap, LaunchCfg& cfg,
                           BufferPtr& descs, BufferPtr& map);
     Status RunSegments(const std::vector<CopySegment>& segments);
@@ -270,6 +273,7 @@ private:
     struct KeyedHint {
         int LdsCap = 16;
         bool ManyGroups = false;
+        int64_t Groups = 0;      // groups of the step's last scan
         uint64_t TableCap = 4096;
         // The register-held groups pay when a few groups take most rows (TPC-H Q1: 2.7x) and cost registers and per-row
         // work when they do not (a selective filter in front of thirty groups: 0.6x).  A kernel built for the step is

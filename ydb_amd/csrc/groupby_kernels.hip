@@ -32,6 +32,320 @@ __global__ __launch_bounds__(kBlock) void KeyedTableInitKernel(const KeyedTableI
     }
 }
 
+// ---- deferred level-2 updates ------------------------------------------------------------------------
+// Digit of a record in one round of the sort: bits of the number of the region its probe sequence starts in.
+__device__ __forceinline__ uint32_t DigitOf(const RadixArgs& a, uint64_t lo, uint64_t hi) {
+    const uint32_t h = Fold32(lo, hi);
+    const uint64_t start = (uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24) & a.table_mask;
+    return uint32_t(start >> a.region_shift >> a.digit_shift) & uint32_t(a.ndigits - 1);
+}
+
+constexpr int kRadixPerThread = 16;
+constexpr int kRadixTile = kBlock * kRadixPerThread;
+
+// The records a workgroup takes: chunk `blockIdx.x % chunks` of segment `blockIdx.x / chunks`, whole tiles.
+__device__ __forceinline__ void RadixChunk(const RadixArgs& a, uint32_t& begin, uint32_t& end) {
+    const int seg = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+    const uint32_t s0 = a.seg_start[seg], s1 = a.seg_start[seg + 1];
+    uint32_t per = (s1 - s0 + uint32_t(a.chunks) - 1) / uint32_t(a.chunks);
+    per = (per + kRadixTile - 1) / kRadixTile * kRadixTile;
+    const uint64_t b = uint64_t(s0) + uint64_t(chunk) * per;
+    begin = b < s1 ? uint32_t(b) : s1;
+    end = b + per < s1 ? uint32_t(b + per) : s1;
+}
+
+__global__ __launch_bounds__(kBlock) void RadixCountKernel(const RadixArgs) {
+    const RadixArgs& a = KernArgsAs<RadixArgs>();
+    __shared__ uint32_t lHist[256];
+    lHist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t begin, end;
+    RadixChunk(a, begin, end);
+    const bool two = a.two_words != 0;
+    for (uint32_t r0 = begin; r0 < end; r0 += kRadixTile) {
+        // (loads without conditions, so that all of them are in flight together: a row past the end reads the last one)
+        uint64_t lo[kRadixPerThread], hi[kRadixPerThread];
+#pragma unroll
+        for (int u = 0; u < kRadixPerThread; ++u) {
+            const uint32_t r = r0 + u * kBlock + threadIdx.x;
+            lo[u] = a.src.lo[r < end ? r : end - 1];
+            hi[u] = 0;
+        }
+        if (two) {
+#pragma unroll
+            for (int u = 0; u < kRadixPerThread; ++u) {
+                const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                hi[u] = a.src.hi[r < end ? r : end - 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRadixPerThread; ++u) {
+            if (r0 + u * kBlock + threadIdx.x >= end) lo[u] = kEmpty;
+        }
+#pragma unroll
+        for (int u = 0; u < kRadixPerThread; ++u) {
+            if (lo[u] != kEmpty) atomicAdd(lHist + DigitOf(a, lo[u], hi[u]), 1u);
+        }
+    }
+    __syncthreads();
+    if (int(threadIdx.x) < a.ndigits) a.counts[size_t(blockIdx.x) * a.ndigits + threadIdx.x] = lHist[threadIdx.x];
+}
+
+// counts[seg][c][d] -> records of (seg, d) in the chunks before c; out_start[seg * ndigits + d + 1] <- records of
+// (seg, d), scanned by the next kernel.  A workgroup takes 64 digits of one segment; its waves share the chunks.
+constexpr int kOffsetWaves = 16;
+__global__ __launch_bounds__(64 * kOffsetWaves) void RadixColumnScanKernel(const RadixArgs) {
+    const RadixArgs& a = KernArgsAs<RadixArgs>();
+    __shared__ uint32_t lSum[kOffsetWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = a.ndigits / 64;
+    const int seg = blockIdx.x / groups, d = (blockIdx.x % groups) * 64 + lane;
+    uint32_t* col = a.counts + size_t(seg) * a.chunks * a.ndigits + d;
+    const int per = (a.chunks + kOffsetWaves - 1) / kOffsetWaves;
+    const int c0 = wave * per, c1 = (c0 + per < a.chunks) ? c0 + per : a.chunks;
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) sum += col[size_t(c) * a.ndigits];
+    lSum[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+    for (int q = 0; q < kOffsetWaves; ++q) {
+        if (q < wave) run += lSum[q][lane];
+        total += lSum[q][lane];
+    }
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+        const uint32_t n = col[size_t(c) * a.ndigits];
+        col[size_t(c) * a.ndigits] = run;
+        run += n;
+    }
+    if (wave == 0) a.out_start[size_t(seg) * a.ndigits + d + 1] = total;
+}
+
+// out_start[1 ..]: counts -> positions (inclusive scan in place; out_start[0] = first record of the source).  One workgroup.
+__global__ __launch_bounds__(1024) void RadixStartScanKernel(const RadixArgs) {
+    const RadixArgs& a = KernArgsAs<RadixArgs>();
+    __shared__ uint32_t lPart[1024];
+    const int n = a.nseg * a.ndigits;
+    const int per = (n + 1023) / 1024;
+    const int i0 = int(threadIdx.x) * per;
+    uint32_t sum = 0;
+    for (int i = i0; i < i0 + per && i < n; ++i) sum += a.out_start[i + 1];
+    lPart[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = int(threadIdx.x) >= off ? lPart[threadIdx.x - off] : 0u;
+        __syncthreads();
+        lPart[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = lPart[threadIdx.x] - sum;
+    for (int i = i0; i < i0 + per && i < n; ++i) {
+        run += a.out_start[i + 1];
+        a.out_start[i + 1] = run;
+    }
+    if (threadIdx.x == 0) a.out_start[0] = 0;
+}
+
+// The records to their places.  A tile of the chunk is first ordered by digit inside LDS (indices only), then written
+// out in that order: neighbouring lanes then write neighbouring records of one (segment, digit), whole lines at a time.
+__global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
+    const RadixArgs& a = KernArgsAs<RadixArgs>();
+    __shared__ uint32_t lCursor[256], lCount[256], lBase[256 + 1];
+    __shared__ uint32_t lWave[kBlock / 64];
+    __shared__ uint64_t lSortedLo[kRadixTile];
+    __shared__ uint16_t lOrder[kRadixTile];
+    __shared__ uint8_t lDigit[kRadixTile];
+    const int seg = blockIdx.x / a.chunks;
+    const bool more = a.two_words != 0 || a.dst.mask != nullptr || a.dst.row != nullptr || a.nvals > 0;  // more than the lo word to move
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lCount[threadIdx.x] = 0;
+    if (int(threadIdx.x) < a.ndigits) {
+        lCursor[threadIdx.x] = a.out_start[size_t(seg) * a.ndigits + threadIdx.x] + a.counts[size_t(blockIdx.x) * a.ndigits + threadIdx.x];
+    }
+    __syncthreads();
+    uint32_t begin, end;
+    RadixChunk(a, begin, end);
+    const bool two = a.two_words != 0;
+    for (uint32_t r0 = begin; r0 < end; r0 += kRadixTile) {
+        // (loads without conditions, so that all of them are in flight together: a row past the end reads the last one)
+        uint64_t lo[kRadixPerThread], hi[kRadixPerThread];
+#pragma unroll
+        for (int u = 0; u < kRadixPerThread; ++u) {
+            const uint32_t r = r0 + u * kBlock + threadIdx.x;
+            lo[u] = a.src.lo[r < end ? r : end - 1];
+            hi[u] = 0;
+        }
+        if (two) {
+#pragma unroll
+            for (int u = 0; u < kRadixPerThread; ++u) {
+                const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                hi[u] = a.src.hi[r < end ? r : end - 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRadixPerThread; ++u) {
+            if (r0 + u * kBlock + threadIdx.x >= end) lo[u] = kEmpty;
+        }
+        uint32_t digit[kRadixPerThread], rank[kRadixPerThread];
+#pragma unroll
+        for (int u = 0; u < kRadixPerThread; ++u) {
+            digit[u] = lo[u] != kEmpty ? DigitOf(a, lo[u], hi[u]) : 0xFFFFFFFFu;
+            rank[u] = lo[u] != kEmpty ? atomicAdd(lCount + digit[u], 1u) : 0u;
+        }
+        __syncthreads();
+        // first position of each digit inside the ordered tile: exclusive scan of lCount (256 entries, one wave's worth each)
+        {
+            const uint32_t c = lCount[threadIdx.x];
+            uint32_t inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) lWave[wave] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int w = 0; w < wave; ++w) before += lWave[w];
+            lBase[threadIdx.x] = before + inc - c;
+            if (threadIdx.x == kBlock - 1) lBase[256] = before + inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kRadixPerThread; ++u) {
+            if (digit[u] == 0xFFFFFFFFu) continue;
+            const uint32_t at = lBase[digit[u]] + rank[u];
+            lSortedLo[at] = lo[u];
+            lOrder[at] = uint16_t(u * kBlock + threadIdx.x);
+            lDigit[at] = uint8_t(digit[u]);
+        }
+        __syncthreads();
+        const uint32_t n = lBase[256];
+        for (uint32_t p = threadIdx.x; p < n; p += kBlock) {
+            const uint32_t d = lDigit[p];
+            const uint32_t at = lCursor[d] + (p - lBase[d]);
+            a.dst.lo[at] = lSortedLo[p];
+            if (!more) continue;
+            const uint32_t r = r0 + lOrder[p];
+            if (two) a.dst.hi[at] = a.src.hi[r];
+            if (a.dst.mask != nullptr) a.dst.mask[at] = a.src.mask[r];
+            if (a.dst.row != nullptr) a.dst.row[at] = a.src.row != nullptr ? a.src.row[r] : r;
+            for (int v = 0; v < a.nvals; ++v) a.dst.val[size_t(v) * size_t(a.stride) + at] = a.src.val[size_t(v) * size_t(a.stride) + r];
+        }
+        __syncthreads();
+        lCursor[threadIdx.x] += lCount[threadIdx.x];
+        lCount[threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+
+// One region of the table brought up to date by one workgroup: the region's slots are read into LDS, the region's
+// records are applied there, the slots are written back.  No other workgroup touches the region meanwhile.
+__global__ __launch_bounds__(kBlock) void RegionApplyKernel(const RegionApplyArgs) {
+    const RegionApplyArgs& a = KernArgsAs<RegionApplyArgs>();
+    const KeyedSink& s = a.s;
+    extern __shared__ uint64_t lRegion[];
+    const int R = a.region_slots;
+    const bool two = s.two_words != 0, hashed = s.hashed != 0;
+    uint64_t* lLo = lRegion;
+    uint64_t* lHi = lLo + R;
+    uint64_t* lRep = lHi + (two ? R : 0);
+    uint64_t* lAcc = lRep + (hashed ? R : 0);
+    uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(s.naggs) * R);
+    __shared__ uint32_t lStop;
+    uint32_t err = 0;
+    for (int region = blockIdx.x; region < a.nregions; region += gridDim.x) {
+        const uint32_t first = a.region_start[region], last = a.region_start[region + 1];
+        if (first == last) continue;  // (the same for the whole workgroup)
+        // a region that ran full somewhere: the host repeats the step with a larger table, the rest is wasted work
+        if (threadIdx.x == 0) lStop = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SCAN_TABLE_FULL;
+        __syncthreads();
+        if (lStop != 0) break;
+        const uint64_t slot0 = uint64_t(region) * R;
+        // (R is a multiple of the workgroup size; four loads of an array in flight per thread)
+        auto load = [&](uint64_t* dst, const uint64_t* src) {
+            for (int i0 = threadIdx.x; i0 < R; i0 += 4 * kBlock) {
+                uint64_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = src[i0 + j * kBlock < R ? i0 + j * kBlock : i0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (i0 + j * kBlock < R) dst[i0 + j * kBlock] = w[j];
+                }
+            }
+        };
+        load(lLo, s.t_key_lo + slot0);
+        if (two) load(lHi, s.t_key_hi + slot0);
+        if (hashed) load(lRep, s.t_rep_row + slot0);
+        for (int k = 0; k < s.naggs; ++k) load(lAcc + size_t(k) * R, s.t_acc + size_t(k) * s.acc_stride + slot0);
+        for (int i = threadIdx.x; i < R; i += kBlock) lSeen[i] = s.t_seen[slot0 + i];
+        __syncthreads();
+        for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += 4 * kBlock) {
+          uint64_t los[4], his[4];
+          uint32_t masks[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+              const uint32_t i = i0 + j * kBlock < last ? i0 + j * kBlock : i0;
+              los[j] = a.rec.lo[i];
+              his[j] = 0;
+              masks[j] = ~0u;
+          }
+          if (two) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) his[j] = a.rec.hi[i0 + j * kBlock < last ? i0 + j * kBlock : i0];
+          }
+          if (a.rec.mask != nullptr) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) masks[j] = a.rec.mask[i0 + j * kBlock < last ? i0 + j * kBlock : i0];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t i = i0 + j * kBlock;
+            if (i >= last || err != 0) continue;
+            const uint64_t lo = los[j], hi = his[j];
+            const uint32_t mask = masks[j];
+            const uint32_t h = Fold32(lo, hi);
+            const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
+            int64_t g;
+            if (hashed && (hi >> 63) != 0) {
+                const uint64_t row = a.rec.row[i];
+                g = TableUpsertVerified(lLo, lHi, lRep, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, row, uint32_t(R),
+                                        [&](uint64_t rep) { return SameKeyRows(a.cols, s, row, rep); });
+            } else {
+                g = TableUpsert(lLo, lHi, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, two, uint32_t(R));
+                if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(lRep + g), static_cast<unsigned long long>(a.rec.row[i]));
+            }
+            if (g < 0) {
+                err |= SCAN_TABLE_FULL;
+                atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
+                continue;
+            }
+            uint32_t seen = 0;
+            int v = 0;
+            for (int k = 0; k < s.naggs; ++k) {
+                const int kind = s.aggs[k].kind;
+                const int slotV = v;
+                if (kind != AGG_COUNT) ++v;
+                if (!((mask >> k) & 1u)) continue;
+                if (s.aggs[k].check_valid) seen |= 1u << k;
+                AccUpdate(kind, lAcc + size_t(k) * R + g, kind == AGG_COUNT ? 1ull : a.rec.val[size_t(slotV) * size_t(a.stride) + i]);
+            }
+            if (seen != 0 && (lSeen[g] & seen) != seen) atomicOr(lSeen + g, seen);
+          }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < R; i += kBlock) {
+            s.t_key_lo[slot0 + i] = lLo[i];
+            if (two) s.t_key_hi[slot0 + i] = lHi[i];
+            if (hashed) s.t_rep_row[slot0 + i] = lRep[i];
+            s.t_seen[slot0 + i] = lSeen[i];
+            for (int k = 0; k < s.naggs; ++k) s.t_acc[size_t(k) * s.acc_stride + slot0 + i] = lAcc[size_t(k) * R + i];
+        }
+        __syncthreads();
+    }
+    if (err != 0) atomicOr(a.status, err);
+}
+
 // ---- table -> output columns -------------------------------------------------------------------------
 // The groups leave the table in slot order: occupied slots are counted per tile of kTileRows slots, the counts are
 // scanned, and the emit pass places every group at tile offset + rank inside the tile.  (One shared output counter
@@ -170,14 +484,25 @@ __global__ __launch_bounds__(kBlock) void GatherStringLensKernel(const int32_t* 
     }
 }
 
+// Eight lanes share a string and move it in 8-byte words (a thread per string, byte by byte, took 1.65 ms for the 5.3 M
+// phrases of ClickBench's GROUP BY SearchPhrase).
 __global__ __launch_bounds__(kBlock) void GatherStringBytesKernel(const int32_t* offsets, const uint8_t* chars,
                                                                 const uint64_t* rows, int64_t n, const int32_t* newOffsets,
                                                                 uint8_t* outChars) {
-    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) {
+    const int part = threadIdx.x & 7;
+    for (int64_t i = (int64_t(blockIdx.x) * kBlock + threadIdx.x) >> 3; i < n; i += (int64_t(gridDim.x) * kBlock) >> 3) {
         const uint64_t r = rows[i];
         if (r == ~0ull) continue;
         const int32_t b = offsets[r], len = offsets[r + 1] - b, o = newOffsets[i];
-        for (int32_t j = 0; j < len; ++j) outChars[o + j] = chars[b + j];
+        for (int32_t j = part * 8; j < len; j += 64) {
+            if (j + 8 <= len) {
+                uint64_t w;
+                __builtin_memcpy(&w, chars + b + j, 8);
+                __builtin_memcpy(outChars + o + j, &w, 8);
+            } else {
+                for (int32_t t = j; t < len; ++t) outChars[o + t] = chars[b + t];
+            }
+        }
     }
 }
 
@@ -253,6 +578,32 @@ hipError_t LaunchKeyedTableInit(const KeyedSink& sink, bool twoWords, bool hashe
     return hipGetLastError();
 }
 
+hipError_t LaunchRadixCount(const RadixArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(RadixCountKernel, dim3(uint32_t(a.nseg * a.chunks)), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t LaunchRadixOffsets(const RadixArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(RadixColumnScanKernel, dim3(uint32_t(a.nseg * (a.ndigits / 64))), dim3(64 * kOffsetWaves), 0, st, a);
+    hipLaunchKernelGGL(RadixStartScanKernel, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t LaunchRadixScatter(const RadixArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(RadixScatterKernel, dim3(uint32_t(a.nseg * a.chunks)), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+size_t RegionApplyLdsBytes(const KeyedSink& s, int regionSlots) {
+    return size_t(regionSlots) * (8 + (s.two_words ? 8 : 0) + (s.hashed ? 8 : 0) + 8 * size_t(s.naggs) + 4);
+}
+
+hipError_t LaunchRegionApply(const RegionApplyArgs& a, hipStream_t st) {
+    const int grid = a.nregions < kMaxGrid * 16 ? a.nregions : kMaxGrid * 16;
+    hipLaunchKernelGGL(RegionApplyKernel, dim3(uint32_t(grid)), dim3(kBlock), RegionApplyLdsBytes(a.s, a.region_slots), st, a);
+    return hipGetLastError();
+}
+
 hipError_t LaunchKeyedTileCount(const uint64_t* tKeyLo, uint64_t capacity, uint32_t* tileCounts, hipStream_t st) {
     const uint64_t ntiles = capacity / kTileRows;
     hipLaunchKernelGGL(KeyedTileCountKernel, dim3(uint32_t(ntiles < uint64_t(kMaxGrid) ? ntiles : uint64_t(kMaxGrid))), dim3(kBlock), 0, st,
@@ -319,7 +670,7 @@ hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, 
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* newOffsets, uint8_t* outChars, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(GatherStringBytesKernel, dim3(GridFor(n)), dim3(kBlock), 0, st, offsets, chars, rows, n, newOffsets, outChars);
+    hipLaunchKernelGGL(GatherStringBytesKernel, dim3(GridFor(n * 8)), dim3(kBlock), 0, st, offsets, chars, rows, n, newOffsets, outChars);
     return hipGetLastError();
 }
 

@@ -59,6 +59,10 @@ struct KeyedSink {
     int32_t lds_cap;         // level-1 (LDS) table slots, power of two, 0 = none
     int32_t lds_rep;         // accumulator replicas per level-1 slot, power of two
     uint64_t table_mask;     // level-2 capacity - 1
+    // Level 2 is one array per field, on purpose.  With the fields of a group next to each other (one 64-byte line per
+    // row instead of two) ClickBench's GROUP BY UserID ran 1.8 times slower: the key words are read with loads, which the
+    // XCD's L2 serves, the accumulators are updated by atomics, which run at the memory side and drop their line from L2
+    // -- on a shared line the two keep evicting each other.
     uint64_t* t_key_lo;      // [cap] ~0 = free
     uint64_t* t_key_hi;      // [cap] ~0 = not yet published
     uint64_t* t_acc;         // [naggs][cap]
@@ -67,9 +71,16 @@ struct KeyedSink {
     int32_t hot_kind[kHotAggs];  // register path of accumulator k (HotKind)
     int32_t hot_off[kHotAggs];   // LDS byte offset of its 64-bit operand tile
     int32_t use_hot;             // keep the first groups of a workgroup in registers (else every row goes through the tables)
-    int32_t reserved;
+    int32_t defer;               // rows that miss level 1 are written out as records (rec_*) instead of updating level 2
+    uint64_t region_mask;        // a probe sequence stays among the slots that share its start's bits above this mask
+                                 // (table_mask: the whole table)
     uint64_t acc_stride;         // slots between the accumulators k and k + 1 of one group in t_acc: the capacity, or the
                                  // capacities of all slices' tables together (SliceDesc)
+    // Deferred level-2 updates (defer != 0), one record per input row, at the row's index:
+    uint64_t* rec_lo;            // [nrows] key lo word; ~0: the row left no record
+    uint64_t* rec_hi;            // [nrows] key hi word (two-word keys)
+    uint64_t* rec_val;           // [nvals][nrows] operand of every accumulator that is no counter, in accumulator order
+    uint32_t* rec_mask;          // [nrows] bit k: the row updates accumulator k (nullptr: every record updates all of them)
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.
@@ -155,6 +166,50 @@ uint64_t KeyedTableIdentity(int aggKind);  // initial value of a level-2 accumul
 hipError_t ConfigureKeyedKernels(int maxLdsBytes);
 // Free keys, identity accumulators, clear flags: every array of the level-2 table `sink` points at, in one launch.
 hipError_t LaunchKeyedTableInit(const KeyedSink& sink, bool two_words, bool hashed, hipStream_t st);
+// Deferred level-2 updates of a keyed scan (KeyedSink.defer).  The table is cut into regions of `region_slots` slots
+// (probe sequences wrap inside their region); the records the scan left are sorted by region with one or two rounds of
+// a counting sort on the region number, and every region is then brought up to date by one workgroup, in LDS.
+struct RecordSet {
+    uint64_t* lo;
+    uint64_t* hi;             // two-word keys
+    uint64_t* val;            // [nvals][stride]
+    uint32_t* mask;           // nullptr: every record updates all accumulators
+    uint32_t* row;            // the record's row (nullptr where it is not carried: in the scan's output the record's index)
+};
+// One round of the sort: the records of each segment of `src` (seg_start) to `dst`, ordered by digit inside the segment.
+struct RadixArgs {
+    RecordSet src, dst;
+    int64_t stride;               // elements between two operand arrays of a record set (the batch's row count)
+    int32_t nvals;
+    int32_t two_words;
+    int32_t skip_free;            // src.lo may hold ~0: no record at that index
+    uint64_t table_mask;
+    int32_t region_shift;         // region of a slot = slot >> region_shift
+    int32_t digit_shift;          // digit = (region >> digit_shift) & (ndigits - 1)
+    int32_t ndigits;              // 64 .. 256, a power of two
+    int32_t nseg;
+    int32_t chunks;               // workgroups per segment
+    const uint32_t* seg_start;    // [nseg + 1]
+    uint32_t* counts;             // [nseg][chunks][ndigits] records per chunk and digit; then those of the earlier chunks
+    uint32_t* out_start;          // [nseg * ndigits + 1] first record of each (segment, digit) in dst
+};
+hipError_t LaunchRadixCount(const RadixArgs& a, hipStream_t st);
+hipError_t LaunchRadixOffsets(const RadixArgs& a, hipStream_t st);
+hipError_t LaunchRadixScatter(const RadixArgs& a, hipStream_t st);
+struct RegionApplyArgs {
+    KeyedSink s;                  // the scan's sink: table, accumulators, keys
+    const DevColumn* cols;        // the batch's columns on the device (hashed keys: rows are compared by their key values)
+    RecordSet rec;                // the records in region order
+    int64_t stride;
+    int32_t nvals;
+    int32_t region_slots;
+    int32_t nregions;
+    const uint32_t* region_start; // [nregions + 1]
+    uint32_t* status;
+};
+// LDS bytes the apply pass needs for regions of `region_slots` slots.
+size_t RegionApplyLdsBytes(const KeyedSink& s, int region_slots);
+hipError_t LaunchRegionApply(const RegionApplyArgs& a, hipStream_t st);
 // tile_counts[t] = occupied slots among slots [t * kTileRows, (t + 1) * kTileRows); capacity is a multiple of kTileRows
 hipError_t LaunchKeyedTileCount(const uint64_t* t_key_lo, uint64_t capacity, uint32_t* tile_counts, hipStream_t st);
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st);

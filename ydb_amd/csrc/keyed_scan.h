@@ -150,8 +150,10 @@ __device__ __forceinline__ uint64_t TableCombine(int kind, uint64_t a, uint64_t 
 // lane that finds its own lo with hi not yet published looks at the same slot again on the next trip
 // of the loop: the lanes of a wave take every trip together, so the owner's store has been issued by
 // then, and owners in other waves make progress on their own.  Returns -1 after `maxProbes` slots.
-__device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uint64_t mask, uint64_t start, uint64_t lo,
-                                               uint64_t hi, bool twoWords, uint32_t maxProbes) {
+// The probe sequence stays inside the region of its first slot: the slots that agree with it above `regionMask`
+// (the table's mask: the whole table is one region).
+__device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uint64_t mask, uint64_t regionMask, uint64_t start,
+                                               uint64_t lo, uint64_t hi, bool twoWords, uint32_t maxProbes) {
     uint64_t s = start & mask;
     uint32_t probes = 0;
     while (probes < maxProbes) {
@@ -170,7 +172,7 @@ __device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uin
             if (ch == hi) return int64_t(s);
             if (ch == kUnpublished) continue;
         }
-        s = (s + 1) & mask;
+        s = (s & ~regionMask) | ((s + 1) & regionMask);
         ++probes;
     }
     return -1;
@@ -222,8 +224,8 @@ __device__ __noinline__ bool SameKeyRows(const DevColumn* cols, const KeyedSink&
 // take two slots.  The owner of a slot stores its row as the representative before it publishes hi; a reader that
 // still sees no representative looks again on its next trip.  Keeps the smallest row of the group as representative.
 template <class Same>
-__device__ __forceinline__ int64_t TableUpsertVerified(uint64_t* tLo, uint64_t* tHi, uint64_t* tRep, uint64_t mask, uint64_t start,
-                                                       uint64_t lo, uint64_t hi, uint64_t row, uint32_t maxProbes, Same same) {
+__device__ __forceinline__ int64_t TableUpsertVerified(uint64_t* tLo, uint64_t* tHi, uint64_t* tRep, uint64_t mask, uint64_t regionMask,
+                                                       uint64_t start, uint64_t lo, uint64_t hi, uint64_t row, uint32_t maxProbes, Same same) {
     uint64_t s = start & mask;
     uint32_t probes = 0;
     while (probes < maxProbes) {
@@ -249,7 +251,7 @@ __device__ __forceinline__ int64_t TableUpsertVerified(uint64_t* tLo, uint64_t* 
                 }
             }
         }
-        s = (s + 1) & mask;
+        s = (s & ~regionMask) | ((s + 1) & regionMask);
         ++probes;
     }
     return -1;
@@ -427,6 +429,15 @@ __device__ __forceinline__ void ScanKeyedBody() {
 #else
     const SliceDesc* slice = a.slices != nullptr ? a.slices + __builtin_amdgcn_readfirstlane(a.block_slice[blockIdx.x]) : nullptr;
 #endif
+    // Deferred level-2 updates: a row that finds no place in level 1 leaves a record (key, operands) at its row index
+    // instead of touching the table in HBM; the host then sorts the records by table region and applies them region by
+    // region.  Only in kernels built for a step program that asked for it.
+#if defined(SSA_SPEC) && defined(SSA_SPEC_DEFER)
+    constexpr bool kDefer = SSA_SPEC_DEFER != 0;
+#else
+    constexpr bool kDefer = false;
+#endif
+    constexpr int64_t kDeferredSlot = INT64_MIN;
     Machine<U> m(a, slice);
     const uint64_t tableOff = slice != nullptr ? Uniform64(slice->table_off) : 0ull;
     const int64_t firstTile = slice != nullptr ? int64_t(blockIdx.x) - __builtin_amdgcn_readfirstlane(slice->first_block) : int64_t(blockIdx.x);
@@ -442,6 +453,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
     uint64_t* const tAcc = rs.t_acc + tableOff;
     const uint64_t accStride = rs.acc_stride;
     const uint64_t tableMask = rs.table_mask;
+    const uint64_t regionMask = rs.region_mask;
     // level-1 table in the sink area of LDS:
     //   by hash position: lo[L], hi[L], rep[L], dense[L];  by dense id: acc[naggs][L][R], seen[L];  count;
     //   keys of the register-held groups: hot[kHotGroups][2]
@@ -514,7 +526,15 @@ __device__ __forceinline__ void ScanKeyedBody() {
         SSA_T(0);
         m.Run();
         SSA_T(1);
-        if (m.P == 0) continue;
+        if (m.P == 0) {
+            if (kDefer) {  // no row of the tile leaves a record
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (m.Row(u) < m.nrows) rs.rec_lo[uint64_t(m.Row(u))] = kEmpty;
+                }
+            }
+            continue;
+        }
 
         // Keys of the lane's rows.  Batches whose keys all have a fixed width of at most 119 bits pack them at
         // wave-uniform positions.  Otherwise every row first tries the same exact packing at its own positions, a
@@ -716,13 +736,16 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 const bool byHash = hashed && (khi >> 63) != 0;  // (exact keys keep the top of hi clear)
                 auto sameRows = [&](uint64_t rep) { return SameKeyRows(m.cols, s, row, rep); };
                 if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes, byHash, sameRows);
-                if (sl < 0) {
+                if (kDefer && sl < 0) {
+                    if (twoWords) rs.rec_hi[row] = khi;  // (the lo word: at the end of the tile, for every row)
+                    sl = kDeferredSlot;
+                } else if (sl < 0) {
                     const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
                     int64_t g;
                     if (byHash) {
-                        g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, start, klo, khi, row, 4096u, sameRows);
+                        g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, regionMask, start, klo, khi, row, 4096u, sameRows);
                     } else {
-                        g = TableUpsert(tKeyLo, tKeyHi, tableMask, start, klo, khi, twoWords, 4096u);
+                        g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, start, klo, khi, twoWords, 4096u);
                         if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(tRepRow + g), static_cast<unsigned long long>(row));
                     }
                     if (g < 0) {
@@ -804,9 +827,15 @@ __device__ __forceinline__ void ScanKeyedBody() {
         // Table path: everything else, and the rows of groups that are not register-held.
         const bool tablesIdle = hotDone == ((1u << naggs) - 1u) && !__any((m.P & ~hotRows) != 0);
         const int tableAggs = (tablesIdle || (m.S().debug_flags & (2 | 16))) ? 0 : naggs;
+        uint32_t recMask[U];  // deferred rows: the accumulators the row updates
+#pragma unroll
+        for (int u = 0; u < U; ++u) recMask[u] = 0;
+        int valSlot = 0;  // operands of the accumulators before k that records carry
         SSA_UNROLL_STATIC
         for (int k = 0; k < naggs; ++k) {
             if (k >= tableAggs) break;
+            const int recSlot = valSlot;
+            if (kDefer && int32_t(SSA_ROW(tAggKind, s.aggs[k].kind, k)) != AGG_COUNT) ++valSlot;
             uint32_t live = m.P & (((hotDone >> k) & 1u) ? ~hotRows : ~0u);
             if (!__any(live != 0)) continue;
             AggSpec spec;
@@ -830,12 +859,15 @@ __device__ __forceinline__ void ScanKeyedBody() {
                     if (!((live >> u) & 1u)) continue;
                     if (slot[u] >= 0) {
                         if (!((lSeen[slot[u]] >> k) & 1u)) atomicOr(lSeen + slot[u], 1u << k);
+                    } else if (kDefer && slot[u] == kDeferredSlot) {
+                        // (the record's mask says so)
                     } else {
                         uint32_t* g = tSeen + (-2 - slot[u]);
                         if (!((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> k) & 1u)) atomicOr(g, 1u << k);
                     }
                 }
             }
+            const uint32_t counted = live;  // the rows the group has seen an argument of, NaNs included
             if (kind == AGG_COUNT) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) x.v[u] = 1;
@@ -864,12 +896,28 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (kDefer && slot[u] == kDeferredSlot) {
+                    // (a NaN the MIN / MAX passes over still marks the accumulator as seen: the record carries the identity)
+                    if (!((counted >> u) & 1u)) continue;
+                    recMask[u] |= 1u << k;
+                    if (kind != AGG_COUNT) {
+                        rs.rec_val[uint64_t(recSlot) * uint64_t(m.nrows) + uint64_t(m.Row(u))] = ((live >> u) & 1u) ? x.v[u] : TableIdentity(kind);
+                    }
+                    continue;
+                }
                 if (!((live >> u) & 1u)) continue;
                 if (slot[u] >= 0) {
                     AccUpdate(kind, accK + slot[u] * R + rep, x.v[u]);
                 } else {
                     AccUpdate(kind, tabK + (-2 - slot[u]), x.v[u]);
                 }
+            }
+        }
+        if (kDefer) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (m.Row(u) < m.nrows) rs.rec_lo[uint64_t(m.Row(u))] = slot[u] == kDeferredSlot ? kb.lo[u] : kEmpty;
+                if (rs.rec_mask != nullptr && slot[u] == kDeferredSlot) rs.rec_mask[uint64_t(m.Row(u))] = recMask[u];
             }
         }
         SSA_T(5);
@@ -912,10 +960,10 @@ __device__ __forceinline__ void ScanKeyedBody() {
         int64_t g;
         if (hashed && (hi >> 63) != 0) {
             const uint64_t row = lRep[i];
-            g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, start, lo, hi, row, 4096u,
+            g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, regionMask, start, lo, hi, row, 4096u,
                                     [&](uint64_t rep) { return SameKeyRows(m.cols, s, row, rep); });
         } else {
-            g = TableUpsert(tKeyLo, tKeyHi, tableMask, start, lo, hi, twoWords, 4096u);
+            g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, start, lo, hi, twoWords, 4096u);
             if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(tRepRow + g), static_cast<unsigned long long>(lRep[i]));
         }
         if (g < 0) {
