@@ -1745,6 +1745,11 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     KeyedHint& hint = KeyedHints[HintOverride ? HintOverride : &step];
     const uint64_t maxCap = std::max<uint64_t>(1024, NextPow2(uint64_t(maxRows) * 2 + 2));
     uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(hint.TableCap, 1024), maxCap);
+    // A step's first scan knows nothing about its groups: a table of a slot per 32 rows (4 M slots at most) costs
+    // microseconds to set up, and when it is too small the scan gives up early (KeyedSink.abort_check) and is repeated
+    // with 16 times the slots -- two attempts for a hundred million rows of distinct keys instead of five whole scans.
+    if (hint.Groups == 0 && !many) cap = std::min<uint64_t>(std::max<uint64_t>(cap, std::min<uint64_t>(NextPow2(uint64_t(maxRows) / 32 + 1), uint64_t(1) << 22)), maxCap);
+    const int abortCheck = (hint.Groups == 0 || hint.ManyGroups) ? 1 : 0;
 
     // Level-1 accumulators are replicated only when the table path carries the bulk of the updates: steps whose
     // aggregates all run on the register path touch LDS accumulators just for their fifth and later groups.
@@ -1864,6 +1869,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     // Groupings whose table is far larger than the caches: the scan leaves the rows that miss level 1 as records, which
     // are then sorted by table region and applied region by region (DeferredArgs).  SSA_KEYED_PARTITION: 0 never, 1 always.
     bool deferWanted = false;
+    bool deferTimed = false;  // this scan is one of the two that decide hint.DeferChoice
     int nvals = 0;
     bool needMask = false;
     {
@@ -1879,6 +1885,16 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         const double recordBytes = 2.0 * double(in.Rows) * (8 + (twoWords ? 8 : 0) + 8 * nvals + (needMask ? 4 : 0) + (hashed ? 4 : 0));
         can = can && recordBytes <= 32e9;
         deferWanted = can && mode != 0 && (mode == 1 || (hint.Groups >= (int64_t(1) << 20) && in.Rows >= (int64_t(1) << 22)));
+        if (deferWanted && mode != 1) {
+            // (register-held groups are no use among a million groups: not worth two timed scans of their own)
+            if (hint.HotChoice < 0) hint.HotChoice = 0;
+            if (hint.DeferChoice == 0) {
+                deferWanted = false;
+            } else if (hint.DeferChoice < 0) {
+                deferTimed = true;
+                deferWanted = hint.MsDeferOn == 0;  // the sorted way first, then the direct one
+            }
+        }
         // (probing inside LDS is cheap: the table may be up to three quarters full, and everything that walks over it is
         // the faster for it)
         if (deferWanted && hint.Groups > 0) cap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(hint.Groups) + uint64_t(hint.Groups) / 3), 1024), maxCap);
@@ -1903,6 +1919,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         for (KeyedSink* k : {&sink, &ssink}) {
             k->table_mask = cap - 1;
             k->region_mask = cap - 1;
+            k->abort_check = abortCheck;
             k->acc_stride = totalCap;
             k->t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
             k->t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
@@ -1917,6 +1934,8 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
         bool timedRun = false;
         bool deferNow = false;
+        bool specUsed = false;
+        std::chrono::steady_clock::time_point deferT0;
         int hotMode = 1;
         if (totalRows > 0) {
             // a scan of many rows runs the kernel built for this step program, when that can be had
@@ -1935,6 +1954,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 image.t_rep_row = nullptr;
                 image.table_mask = 0;
                 image.region_mask = 0;
+                image.abort_check = 0;
                 image.acc_stride = 0;
                 image.rec_lo = image.rec_hi = image.rec_val = nullptr;
                 image.rec_mask = nullptr;
@@ -1973,12 +1993,17 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 ssink.rec_mask = needMask ? static_cast<uint32_t*>(recMask->Ptr) : nullptr;
             }
             timedRun = timedRun && spec != nullptr;
+            specUsed = spec != nullptr;
             if (many) {
                 ScanArgs& la = spec ? sargs : args;
                 LaunchCfg& lc = spec ? specCfg : cfg;
                 SSA_RETURN_NOT_OK(DescribeSlices(plan, *many, la, int64_t(kBlock) * (spec ? specRows : kRowsPerThread), cap, lc, sliceDescs, blockSlices));
             }
             ProfileBegin();
+            if (deferTimed) {
+                SSA_HIP(hipStreamSynchronize(StreamHandle));
+                deferT0 = std::chrono::steady_clock::now();
+            }
             if (spec) {
                 if (timedRun) SSA_HIP(hipEventRecord(EvTuneA, StreamHandle));
                 SSA_HIP(LaunchSpecialized(spec, sargs, &ssink, sizeof(ssink), specCfg));
@@ -2011,6 +2036,13 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             SSA_RETURN_NOT_OK(ApplyDeferredRecords(ssink, sargs, in.Rows, nvals, needMask, regionSlots, cap));
             gKeyedStepsDeferred.fetch_add(1, std::memory_order_relaxed);
             SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull, nullptr));
+        }
+        if (!tableFull && deferTimed && specUsed && deferNow == deferWanted) {
+            // (both status checks above end with the stream synchronised: scan, sort and region pass are done)
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - deferT0).count();
+            (deferNow ? hint.MsDeferOn : hint.MsDeferOff) = ms;
+            if (hint.MsDeferOn > 0 && hint.MsDeferOff > 0) hint.DeferChoice = hint.MsDeferOn <= hint.MsDeferOff ? 1 : 0;
+            if (std::getenv("SSA_DEBUG_PLAN")) std::fprintf(stderr, "keyed: by region %.3f ms, row by row %.3f ms -> %d\n", hint.MsDeferOn, hint.MsDeferOff, hint.DeferChoice);
         }
         if (!tableFull) break;
         if (cap >= maxCap) return Status::Invalid("internal: group-by table overflow");

@@ -281,6 +281,12 @@ private:
         int HotChoice = -1;      // -1 undecided, 0 off, 1 on
         bool UniformKeysFailed = false;  // a batch of this step had string keys of differing lengths: no further attempts
         double MsPerRowOn = 0, MsPerRowOff = 0;
+        // Groupings of a million groups and more: records sorted by table region and applied inside LDS, or every row
+        // updating the table in HBM itself.  The sorted way wins where the key is in the record (fixed-width keys:
+        // ClickBench UserID 1.6x), the direct way where every update compares key bytes in memory anyway (long string
+        // keys).  Both ways are timed once on the step's large scans, scan to finished table.
+        int DeferChoice = -1;    // -1 undecided, 0 row by row, 1 by region
+        double MsDeferOn = 0, MsDeferOff = 0;
     };
     std::map<const TProgramStep*, KeyedHint> KeyedHints;
 };

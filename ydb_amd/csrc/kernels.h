@@ -81,6 +81,12 @@ struct KeyedSink {
     uint64_t* rec_hi;            // [nrows] key hi word (two-word keys)
     uint64_t* rec_val;           // [nvals][nrows] operand of every accumulator that is no counter, in accumulator order
     uint32_t* rec_mask;          // [nrows] bit k: the row updates accumulator k (nullptr: every record updates all of them)
+    // A scan whose number of groups is not known yet (or is large) may find level 2 too small: with this set, the first
+    // lane that finds no slot raises SCAN_TABLE_FULL in the status word at once, probe loops and the tile loop look at
+    // the word and give up, and the host repeats the step with a larger table after microseconds instead of a whole scan.
+    // (Launch state like the addresses above: zero in the image a kernel is built for.)
+    int32_t abort_check;
+    int32_t pad_;
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.

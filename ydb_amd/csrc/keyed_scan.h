@@ -152,11 +152,16 @@ __device__ __forceinline__ uint64_t TableCombine(int kind, uint64_t a, uint64_t 
 // then, and owners in other waves make progress on their own.  Returns -1 after `maxProbes` slots.
 // The probe sequence stays inside the region of its first slot: the slots that agree with it above `regionMask`
 // (the table's mask: the whole table is one region).
+// `abortWord`: a status word other lanes raise SCAN_TABLE_FULL in (nullptr: none); looked at every 64 slots.
 __device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uint64_t mask, uint64_t regionMask, uint64_t start,
-                                               uint64_t lo, uint64_t hi, bool twoWords, uint32_t maxProbes) {
+                                               uint64_t lo, uint64_t hi, bool twoWords, uint32_t maxProbes, const uint32_t* abortWord = nullptr) {
     uint64_t s = start & mask;
     uint32_t probes = 0;
     while (probes < maxProbes) {
+        if (abortWord != nullptr && (probes & 63u) == 63u &&
+            (__hip_atomic_load(abortWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SCAN_TABLE_FULL)) {
+            return -1;
+        }
         uint64_t cur = __hip_atomic_load(tLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == kEmpty) {
             cur = atomicCAS(reinterpret_cast<unsigned long long*>(tLo + s), static_cast<unsigned long long>(kEmpty),
@@ -225,10 +230,15 @@ __device__ __noinline__ bool SameKeyRows(const DevColumn* cols, const KeyedSink&
 // still sees no representative looks again on its next trip.  Keeps the smallest row of the group as representative.
 template <class Same>
 __device__ __forceinline__ int64_t TableUpsertVerified(uint64_t* tLo, uint64_t* tHi, uint64_t* tRep, uint64_t mask, uint64_t regionMask,
-                                                       uint64_t start, uint64_t lo, uint64_t hi, uint64_t row, uint32_t maxProbes, Same same) {
+                                                       uint64_t start, uint64_t lo, uint64_t hi, uint64_t row, uint32_t maxProbes, Same same,
+                                                       const uint32_t* abortWord = nullptr) {
     uint64_t s = start & mask;
     uint32_t probes = 0;
     while (probes < maxProbes) {
+        if (abortWord != nullptr && (probes & 63u) == 63u &&
+            (__hip_atomic_load(abortWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SCAN_TABLE_FULL)) {
+            return -1;
+        }
         uint64_t cur = __hip_atomic_load(tLo + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == kEmpty) {
             cur = atomicCAS(reinterpret_cast<unsigned long long*>(tLo + s), static_cast<unsigned long long>(kEmpty),
@@ -520,12 +530,16 @@ __device__ __forceinline__ void ScanKeyedBody() {
     uint64_t tlast = __builtin_readcyclecounter();
 #endif
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
+    const uint32_t* const abortWord = rs.abort_check != 0 ? a.status : nullptr;  // (wave-uniform)
     for (int64_t tile = firstTile; tile < ntiles; tile += tileStride) {
         SSA_T(7);
+        // (the load is issued ahead of the tile's own and has arrived when they have)
+        const uint32_t stopNow = abortWord != nullptr ? __hip_atomic_load(abortWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         m.BeginTile(tile * (kBlock * U), (tile + tileStride) * (kBlock * U));
         SSA_T(0);
         m.Run();
         SSA_T(1);
+        if (__builtin_amdgcn_readfirstlane(stopNow) & SCAN_TABLE_FULL) break;  // the step is being repeated with a larger table
         if (m.P == 0) {
             if (kDefer) {  // no row of the tile leaves a record
 #pragma unroll
@@ -743,12 +757,13 @@ __device__ __forceinline__ void ScanKeyedBody() {
                     const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
                     int64_t g;
                     if (byHash) {
-                        g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, regionMask, start, klo, khi, row, 4096u, sameRows);
+                        g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, regionMask, start, klo, khi, row, 4096u, sameRows, abortWord);
                     } else {
-                        g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, start, klo, khi, twoWords, 4096u);
+                        g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, start, klo, khi, twoWords, 4096u, abortWord);
                         if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(tRepRow + g), static_cast<unsigned long long>(row));
                     }
                     if (g < 0) {
+                        if (abortWord != nullptr && !(m.err & SCAN_TABLE_FULL)) atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
                         m.err |= SCAN_TABLE_FULL;
                         m.P &= ~(1u << pu);
                     } else {
@@ -961,12 +976,13 @@ __device__ __forceinline__ void ScanKeyedBody() {
         if (hashed && (hi >> 63) != 0) {
             const uint64_t row = lRep[i];
             g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, regionMask, start, lo, hi, row, 4096u,
-                                    [&](uint64_t rep) { return SameKeyRows(m.cols, s, row, rep); });
+                                    [&](uint64_t rep) { return SameKeyRows(m.cols, s, row, rep); }, abortWord);
         } else {
-            g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, start, lo, hi, twoWords, 4096u);
+            g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, start, lo, hi, twoWords, 4096u, abortWord);
             if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(tRepRow + g), static_cast<unsigned long long>(lRep[i]));
         }
         if (g < 0) {
+            if (abortWord != nullptr && !(m.err & SCAN_TABLE_FULL)) atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
             m.err |= SCAN_TABLE_FULL;
             continue;
         }
