@@ -237,8 +237,9 @@ def main():
         # The executor builds the step program's kernel at the first large scan and settles how it runs it
         # (register-held groups on or off) on the second: with fewer than two warm-up steps asked for, those passes run
         # here, untimed, like the generation of the table.
-        # Groupings of a million groups take a third such pass (records sorted by table region, or row-by-row updates).
-        for _ in range(max(0, (3 if on_device else 2) - warmup) + warmup):
+        # Groupings of a million groups take a third such pass (records sorted by table region, or row-by-row updates),
+        # and so do groupings behind a filter (the rows that passed taken one by one).
+        for _ in range(max(0, (3 if clickbench_run else 2) - warmup) + warmup):
             for i, s in enumerate(scans_):
                 results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device)
         for s in scans_:

@@ -540,6 +540,10 @@ void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_
     if (steps_slice_by_slice) *steps_slice_by_slice = ssa::gManyStepsPerSlice.load();
 }
 
+void ssa_keyed_compact_stats(int64_t* scans_with_compacted_tiles) {
+    if (scans_with_compacted_tiles) *scans_with_compacted_tiles = ssa::gKeyedStepsCompacted.load();
+}
+
 void ssa_keyed_stats(int64_t* scans_applied_by_region) {
     if (scans_applied_by_region) *scans_applied_by_region = ssa::gKeyedStepsDeferred.load();
 }

@@ -1633,6 +1633,7 @@ static int64_t AlgorithmicBytes(const StepPlan& plan, const Batch& in) {
 // `many`: the scan covers several slices of one schema in one launch (`in` is the first of them, the plan and the LDS
 // layout are made for it); the result holds the groups of all slices, slice after slice.
 std::atomic<int64_t> gKeyedStepsDeferred{0};
+std::atomic<int64_t> gKeyedStepsCompacted{0};
 
 Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
                               const std::vector<OffsetCheck>& checks, bool* notUniform, ManySlices* many) {
@@ -1831,6 +1832,42 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             sink.hot_kind[k] = a.kind == AGG_SUM_F ? HOT_SUM_F64 : HOT_SUM_I64;
             sink.hot_off[k] = off;
         }
+        // The tiles a compacting kernel would have to compact: every operand of the sink a staged column without a
+        // validity bitmap (or a constant, or none), eight distinct tiles at most.  compact_n stays 0 otherwise.
+        sink.compact_n = 0;
+        if (plan.HasFilter && !hashed && !many) {
+            bool can = true;
+            auto add = [&](uint32_t fk, uint32_t payload) {
+                int w = 0;
+                switch (fk) {
+                    case FK_NONE: case FK_CONST: return;
+                    case FK_LDS_64: w = 8; break;
+                    case FK_LDS_I32: case FK_LDS_U32: case FK_LDS_F32: w = 4; break;
+                    case FK_LDS_I16: case FK_LDS_U16: w = 2; break;
+                    case FK_LDS_I8: case FK_LDS_U8: w = 1; break;
+                    default: can = false; return;  // registers, unstaged columns, anything with a validity bitmap
+                }
+                const uint32_t off = payload & 0xFFFFFFu;
+                for (int i = 0; i < sink.compact_n; ++i) {
+                    if (sink.compact_off[i] == off) return;
+                }
+                if (sink.compact_n == kMaxCompact) {
+                    can = false;
+                    return;
+                }
+                sink.compact_off[sink.compact_n] = off;
+                sink.compact_w[sink.compact_n++] = w;
+            };
+            for (int k = 0; k < naggs && can; ++k) {
+                const AggSpec& a = sink.aggs[k];
+                if (a.kind == AGG_MIN_S || a.kind == AGG_MAX_S) can = false;
+                if (a.reg != -1) add(a.fetch_kind, a.fetch_payload);
+            }
+            for (int k = 0; k < nkeys && can; ++k) {
+                if (sink.keys[k].col >= 0) can = false; else add(sink.keys[k].fetch_kind, sink.keys[k].fetch_payload);
+            }
+            if (!can) sink.compact_n = 0;
+        }
 
         return Status::OK();
     };
@@ -1907,6 +1944,33 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         const int r = std::atoi(env);
         if (r >= 64 && r <= regionSlots && (r & (r - 1)) == 0) regionSlots = r;
     }
+    const int specCompactTiles = ssink.compact_n;  // (the generic kernel never takes that way)
+    sink.compact_n = 0;
+    // The way the kernel built for the step runs this scan: as decided, else the way not yet timed, in the order 1, 0, 2.
+    int hotMode = 1;
+    bool timedWanted = false;
+    if (JitEnabled() && totalRows > 0) {
+        const bool canCompact = specCompactTiles > 0 && !deferWanted;
+        if (const char* env = std::getenv("SSA_KEYED_HOT")) hint.HotChoice = std::max(0, std::min(2, std::atoi(env)));
+        if (hint.HotChoice == 2 && !canCompact) hint.HotChoice = 0;
+        hotMode = hint.HotChoice >= 0 ? hint.HotChoice : (hint.MsPerRow[1] == 0 ? 1 : (hint.MsPerRow[0] == 0 ? 0 : 2));
+        timedWanted = hint.HotChoice < 0 && totalRows >= (int64_t(1) << 22) && (!many || maxRows >= (int64_t(1) << 16));
+        if (hint.HotChoice < 0 && !timedWanted) hotMode = 1;
+        if (hotMode == 2 && !canCompact) hotMode = 0;
+        // Row by row behind the filter, the per-tile work is what is left to shrink: such a kernel takes 16 rows per thread
+        // when the rows are narrow enough.
+        if (hotMode == 2 && specRows < 16 && WideRowsPerThread(plan, in) >= 16 && !std::getenv("SSA_KEYED_U")) {
+            ScanArgs wargs;
+            LaunchCfg wcfg;
+            KeyedSink wsink{};
+            if (describe(16, wargs, wcfg, wsink).ok() && wsink.compact_n > 0) {
+                sargs = wargs;
+                scfg = wcfg;
+                ssink = wsink;
+                specRows = 16;
+            }
+        }
+    }
     uint64_t totalCap = 0;
     for (;;) {
         totalCap = cap * nslices;  // every slice has a table of its own, one after the other
@@ -1932,22 +1996,17 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             all.table_mask = totalCap - 1;  // (the capacity, not a mask, when there are several tables)
             SSA_HIP(LaunchKeyedTableInit(all, twoWords != 0, hashed, StreamHandle));
         }
-        bool timedRun = false;
+        bool timedRun = timedWanted;
         bool deferNow = false;
         bool specUsed = false;
         std::chrono::steady_clock::time_point deferT0;
-        int hotMode = 1;
         if (totalRows > 0) {
             // a scan of many rows runs the kernel built for this step program, when that can be had
             hipFunction_t spec = nullptr;
             LaunchCfg specCfg = scfg;
             if (JitEnabled()) {
-                // register-held groups on or off: as decided, else the way not yet timed
-                if (const char* env = std::getenv("SSA_KEYED_HOT")) hint.HotChoice = std::atoi(env) != 0 ? 1 : 0;
-                hotMode = hint.HotChoice >= 0 ? hint.HotChoice : (hint.MsPerRowOn == 0 ? 1 : 0);
-                timedRun = hint.HotChoice < 0 && totalRows >= (int64_t(1) << 22) && (!many || maxRows >= (int64_t(1) << 16));
-                if (hint.HotChoice < 0 && !timedRun) hotMode = 1;
-                ssink.use_hot = hotMode;
+                ssink.use_hot = hotMode == 1 ? 1 : 0;
+                if (hotMode != 2) ssink.compact_n = 0;
                 KeyedSink image = ssink;
                 image.t_key_lo = image.t_key_hi = image.t_acc = nullptr;
                 image.t_seen = nullptr;
@@ -1965,14 +2024,16 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 // (more than 2^16 regions would take a third round of the sort: such tables are updated row by row)
                 if (deferWanted && cap / std::min<uint64_t>(cap, uint64_t(regionSlots)) <= 65536) {
                     image.defer = 1;
-                    spec = SpecializedKernel("keyed_scan.h", hotMode ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines + "#define SSA_SPEC_DEFER 1\n",
+                    spec = SpecializedKernel("keyed_scan.h", hotMode == 1 ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines + "#define SSA_SPEC_DEFER 1\n",
                                              sargs, &image, sizeof(image), totalRows, specCfg);
                     deferNow = spec != nullptr;  // (still being built: this scan updates the table row by row)
                 }
                 if (!deferNow) {
                     image.defer = 0;
                     specCfg = scfg;
-                    spec = SpecializedKernel("keyed_scan.h", hotMode ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines, sargs, &image, sizeof(image), totalRows, specCfg);
+                    if (hotMode == 2) defines += "#define SSA_SPEC_COMPACT 1\n";
+                    spec = SpecializedKernel("keyed_scan.h", hotMode == 1 ? "ssa_spec_keyed" : (hotMode == 2 ? "ssa_spec_keyed_compact" : "ssa_spec_keyed_plain"),
+                                             defines, sargs, &image, sizeof(image), totalRows, specCfg);
                 }
                 ScanRowsPerThread = kRowsPerThread;
             }
@@ -2007,6 +2068,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             if (spec) {
                 if (timedRun) SSA_HIP(hipEventRecord(EvTuneA, StreamHandle));
                 SSA_HIP(LaunchSpecialized(spec, sargs, &ssink, sizeof(ssink), specCfg));
+                if (ssink.compact_n > 0) gKeyedStepsCompacted.fetch_add(1, std::memory_order_relaxed);
                 if (timedRun) SSA_HIP(hipEventRecord(EvTuneB, StreamHandle));
             } else {
                 SSA_RETURN_NOT_OK(GenericKernelCan(args));
@@ -2028,8 +2090,16 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         if (timedRun && !tableFull) {  // (the stream has been synchronised by the status check)
             float ms = 0;
             if (hipEventElapsedTime(&ms, EvTuneA, EvTuneB) == hipSuccess && ms > 0) {
-                (hotMode ? hint.MsPerRowOn : hint.MsPerRowOff) = double(ms) / double(in.Rows);
-                if (hint.MsPerRowOn > 0 && hint.MsPerRowOff > 0) hint.HotChoice = hint.MsPerRowOn <= hint.MsPerRowOff ? 1 : 0;
+                hint.MsPerRow[hotMode] = double(ms) / double(in.Rows);
+                const bool third = specCompactTiles > 0 && !deferWanted;  // a compacting way exists
+                if (hint.MsPerRow[1] > 0 && hint.MsPerRow[0] > 0 && (!third || hint.MsPerRow[2] > 0)) {
+                    hint.HotChoice = hint.MsPerRow[1] <= hint.MsPerRow[0] ? 1 : 0;
+                    if (third && hint.MsPerRow[2] < hint.MsPerRow[hint.HotChoice]) hint.HotChoice = 2;
+                    if (std::getenv("SSA_DEBUG_PLAN")) {
+                        std::fprintf(stderr, "keyed: ns per row plain %.4f, register-held groups %.4f, compacted tiles %.4f -> %d\n", 1e6 * hint.MsPerRow[0],
+                                     1e6 * hint.MsPerRow[1], 1e6 * hint.MsPerRow[2], hint.HotChoice);
+                    }
+                }
             }
         }
         if (!tableFull && deferNow) {

@@ -49,6 +49,7 @@ struct ProjectSink {
 constexpr int kHotAggs = 6;
 enum HotKind : int32_t { HOT_NONE = 0, HOT_SUM_F64 = 1, HOT_SUM_I64 = 2, HOT_ROWS = 3 };
 
+constexpr int kMaxCompact = 8;
 struct KeyedSink {
     int32_t naggs;           // distinct accumulators (identical aggregates of the step share one)
     int32_t nkeys;
@@ -86,7 +87,13 @@ struct KeyedSink {
     // the word and give up, and the host repeats the step with a larger table after microseconds instead of a whole scan.
     // (Launch state like the addresses above: zero in the image a kernel is built for.)
     int32_t abort_check;
-    int32_t pad_;
+    // Behind a selective filter (kernels built with SSA_SPEC_COMPACT) the sink takes the rows that passed one per lane
+    // and trip and reads their keys and arguments from the staged tiles at the row's index.  A step qualifies when all of
+    // those are staged columns without a validity bitmap (or constants): compact_n > 0, with the tiles (LDS offset, bytes
+    // per value) listed for reference.
+    int32_t compact_n;
+    uint32_t compact_off[kMaxCompact];
+    int32_t compact_w[kMaxCompact];
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.

@@ -447,6 +447,11 @@ __device__ __forceinline__ void ScanKeyedBody() {
 #else
     constexpr bool kDefer = false;
 #endif
+#if defined(SSA_SPEC) && defined(SSA_SPEC_COMPACT)
+    constexpr bool kCompact = SSA_SPEC_COMPACT != 0;
+#else
+    constexpr bool kCompact = false;
+#endif
     constexpr int64_t kDeferredSlot = INT64_MIN;
     Machine<U> m(a, slice);
     const uint64_t tableOff = slice != nullptr ? Uniform64(slice->table_off) : 0ull;
@@ -531,6 +536,8 @@ __device__ __forceinline__ void ScanKeyedBody() {
 #endif
     const int64_t ntiles = (m.nrows + kBlock * U - 1) / (kBlock * U);
     const uint32_t* const abortWord = rs.abort_check != 0 ? a.status : nullptr;  // (wave-uniform)
+    uint32_t l1Tried = 0, l1Found = 0;  // rows of this wave looked up in level 1 / found there, since the last verdict
+    bool l1Bypass = false;
     for (int64_t tile = firstTile; tile < ntiles; tile += tileStride) {
         SSA_T(7);
         // (the load is issued ahead of the tile's own and has arrived when they have)
@@ -540,6 +547,122 @@ __device__ __forceinline__ void ScanKeyedBody() {
         m.Run();
         SSA_T(1);
         if (__builtin_amdgcn_readfirstlane(stopNow) & SCAN_TABLE_FULL) break;  // the step is being repeated with a larger table
+        if constexpr (kCompact) {
+            // Behind a selective filter most lanes have no row that passed and the rest one or two: the sink below would
+            // still build the keys of all U rows of every lane.  This one takes the rows one per lane and trip, and
+            // reads what it needs of a row -- key columns, arguments -- from the staged tiles at the row's index.  Only
+            // steps whose keys pack exactly and whose operands are staged columns without validity bitmaps (or
+            // constants) are built this way (KeyedSink.compact_n); the semantics are those of the sink below.
+            auto fetchAt = [&](uint32_t fk, uint32_t payload, int idx) -> uint64_t {
+                const unsigned char* base = gLds + (payload & 0xFFFFFFu);
+                switch (fk & 0x7Fu) {
+                    case FK_LDS_64: return reinterpret_cast<const uint64_t*>(base)[idx];
+                    case FK_LDS_I32: return uint64_t(int64_t(reinterpret_cast<const int32_t*>(base)[idx]));
+                    case FK_LDS_U32: return reinterpret_cast<const uint32_t*>(base)[idx];
+                    case FK_LDS_I16: return uint64_t(int64_t(reinterpret_cast<const int16_t*>(base)[idx]));
+                    case FK_LDS_U16: return reinterpret_cast<const uint16_t*>(base)[idx];
+                    case FK_LDS_I8: return uint64_t(int64_t(reinterpret_cast<const int8_t*>(base)[idx]));
+                    case FK_LDS_U8: return reinterpret_cast<const uint8_t*>(base)[idx];
+                    case FK_LDS_F32: return F64ToBits(double(reinterpret_cast<const float*>(base)[idx]));
+                    case FK_CONST: return m.ConstBits(int(payload & 0xFFFFFFu));
+                    default: return 0;
+                }
+            };
+            // The rows that passed are dealt out evenly: they are numbered lane after lane (a lane's rows in order), and
+            // lane l takes the rows l, l + 64, ...  It finds the lane that owns a row by a binary search over the running
+            // counts (six shuffles) -- thirty rows of a thousand are one trip of the loop instead of three.
+            const uint32_t mine = uint32_t(__popc(m.P));
+            uint32_t upTo = mine;  // rows that passed in this lane and the lanes before it
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = uint32_t(__shfl_up(int(upTo), off, 64));
+                if (lane >= off) upTo += o;
+            }
+            const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(upTo), 63));
+            for (uint32_t first = 0; first < total; first += 64) {
+                const uint32_t want = first + uint32_t(lane);
+                const bool has = want < total;
+                int owner = 0;  // the first lane whose running count exceeds `want`
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    if (uint32_t(__shfl(int(upTo), owner + step - 1, 64)) <= want) owner += step;
+                }
+                owner = owner < 64 ? owner : 63;
+                uint32_t ownerRows = uint32_t(__shfl(int(m.P), owner, 64));
+                uint32_t skip = want - uint32_t(__shfl(int(upTo - mine), owner, 64));  // the owner's rows before this one
+                if (has) {
+                while (skip-- != 0) ownerRows &= ownerRows - 1u;
+                const int pu = __ffs(int(ownerRows)) - 1;
+                const int idx = m.waveBase + pu * 64 + owner;
+                uint64_t klo = 0, khi = 0;
+                int pos = 0;
+#pragma unroll
+                for (int k = 0; k < kMaxKeys; ++k) {
+                    if (k >= nkeys) break;
+                    const KeySpec& ks = s.keys[k];
+                    const int nbits = 8 * TypeWidth(ks.type);
+                    const uint64_t bits = PayloadToStored(fetchAt(ks.fetch_kind, ks.fetch_payload, idx), ks.type) & WidthMask(nbits);
+                    if (pos < 64) {
+                        klo |= bits << pos;
+                        if (pos > 0 && pos + nbits > 64) khi |= bits >> (64 - pos);
+                    } else {
+                        khi |= bits << (pos - 64);
+                    }
+                    pos += nbits + (ks.nullable ? 1 : 0);  // (the null flag of a key that is never null stays 0)
+                }
+                {
+                    const uint64_t l = klo, h = khi;
+                    klo = l & 0x7FFFFFFFFFFFFFFFull;
+                    khi = (h << 1) | (l >> 63);
+                }
+                const uint32_t h32 = Fold32(klo, khi);
+                int64_t sl = -1;
+                if (L > 0) {
+                    sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h32, klo, khi, twoWords,
+                                        uint64_t(m.Row(0) + (owner - lane) + int64_t(pu) * 64), ldsProbes, false, [](uint64_t) { return true; });
+                }
+                bool placed = true;
+                if (sl < 0) {
+                    const int64_t g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, uint64_t(h32) * 0x9E3779B97F4A7C15ull >> 24, klo, khi, twoWords, 4096u, abortWord);
+                    if (g < 0) {
+                        if (abortWord != nullptr && !(m.err & SCAN_TABLE_FULL)) atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
+                        m.err |= SCAN_TABLE_FULL;
+                        placed = false;
+                    }
+                    sl = -2 - g;
+                }
+#pragma unroll
+                for (int k = 0; k < kMaxAggs; ++k) {
+                    if (k >= naggs || !placed) break;
+                    const AggSpec& spec = s.aggs[k];
+                    const int kind = spec.kind;
+                    uint64_t x = kind == AGG_COUNT ? 1ull : fetchAt(spec.fetch_kind, spec.fetch_payload, idx);
+                    if (spec.check_valid) {  // (the argument has no nulls: every row marks the accumulator as seen)
+                        if (sl >= 0) {
+                            if (!((lSeen[sl] >> k) & 1u)) atomicOr(lSeen + sl, 1u << k);
+                        } else {
+                            uint32_t* g = tSeen + (-2 - sl);
+                            if (!((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> k) & 1u)) atomicOr(g, 1u << k);
+                        }
+                    }
+                    if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
+                        const double d = BitsToF64(x);
+                        if (d != d) {  // fmin / fmax semantics: a NaN never replaces a number
+                            if (spec.flags & AGG_NAN_UNSUPPORTED) m.err |= SCAN_NAN_ORDER;
+                            continue;
+                        }
+                        x = OrderedFromF64(x);
+                    }
+                    if (sl >= 0) {  // (two calls: each knows its address space)
+                        AccUpdate(kind, lAcc + size_t(k) * L * R + sl * R + rep, x);
+                    } else {
+                        AccUpdate(kind, tAcc + size_t(k) * accStride + (-2 - sl), x);
+                    }
+                }
+                }
+            }
+            continue;
+        }
         if (m.P == 0) {
             if (kDefer) {  // no row of the tile leaves a record
 #pragma unroll
@@ -733,6 +856,33 @@ __device__ __forceinline__ void ScanKeyedBody() {
         // Rows of other groups (and of the first groups until their keys are known) go through the tables.  Every trip
         // of the loop takes each lane's next pending row, whichever of its U rows that is: behind a selective filter
         // most lanes have none and the rest one, so the wave makes one or two trips instead of U.
+        if (kDefer && l1Bypass) {
+            // Level 1 holds few of this wave's rows any more (see below).  What it does hold are the heavy hitters that
+            // came early, and those sit in the slot their hash points at: that one slot is read, nothing is claimed,
+            // and every other row leaves a record.  (A key that is in the table elsewhere leaves records too: level 1
+            // and the records meet in level 2.)
+            uint64_t seenLo[U], seenHi[U];
+            uint32_t seenId[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t at = L > 0 ? Fold32(kb.lo[u], kb.hi[u]) & uint32_t(L - 1) : 0u;
+                seenLo[u] = L > 0 ? lLo[at] : kEmpty;
+                seenHi[u] = (L > 0 && twoWords) ? lHi[at] : 0ull;
+                seenId[u] = L > 0 ? lDense[at] : kNoDense;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!((pending >> u) & 1u)) continue;
+                const bool byHash = hashed && (kb.hi[u] >> 63) != 0;  // (such a row would have to be compared with the group's)
+                if (seenLo[u] == kb.lo[u] && (!twoWords || seenHi[u] == kb.hi[u]) && seenId[u] != kNoDense && !byHash) {
+                    slot[u] = int64_t(seenId[u]);
+                    continue;
+                }
+                if (twoWords) rs.rec_hi[uint64_t(m.Row(u))] = kb.hi[u];
+                slot[u] = kDeferredSlot;
+            }
+            pending = 0;
+        }
         while (__any(pending != 0)) {
             const bool has = pending != 0;
             const int pu = has ? __ffs(int(pending)) - 1 : 0;
@@ -773,6 +923,18 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) slot[u] = (has && pu == u) ? sl : slot[u];
+            if (kDefer) {
+                l1Tried += uint32_t(__popcll(__ballot(has)));
+                l1Found += uint32_t(__popcll(__ballot(has && sl >= 0)));
+            }
+        }
+        // Level 1 keeps the first groups a workgroup meets.  Among millions of groups it is soon full of keys that
+        // never come again, and every row pays eight probes to learn that: once the table is full, a wave that finds
+        // fewer than one row in eight there stops claiming slots and reads one slot per row instead (ClickBench
+        // UserID; SearchPhrase, where the empty phrase is most rows, goes on as before).
+        if (kDefer && !l1Bypass && l1Tried >= 2048u) {
+            if (L == 0 || (l1Found * 8u < l1Tried && __hip_atomic_load(lCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= uint32_t(L))) l1Bypass = true;
+            l1Tried = l1Found = 0;
         }
 
         SSA_T(3);
@@ -1014,6 +1176,10 @@ extern "C" __global__ __launch_bounds__(ssa::kBlock) void ssa_spec_keyed(const s
 // The same kernel under the name the variant without register-held groups is launched by (a step's first large scans
 // time both variants: in a kernel trace the two then show as two kernels, not as one with a bimodal duration).
 extern "C" __global__ __launch_bounds__(ssa::kBlock) void ssa_spec_keyed_plain(const ssa::KArgs<ssa::KeyedSink>) {
+    ssa::ScanKeyedBody<SSA_SPEC_U, SSA_SPEC_HASHED != 0>();
+}
+// ... and the variant that compacts every tile to the rows that passed the filter (built with SSA_SPEC_COMPACT).
+extern "C" __global__ __launch_bounds__(ssa::kBlock) void ssa_spec_keyed_compact(const ssa::KArgs<ssa::KeyedSink>) {
     ssa::ScanKeyedBody<SSA_SPEC_U, SSA_SPEC_HASHED != 0>();
 }
 namespace ssa {
