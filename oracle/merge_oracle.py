@@ -98,29 +98,31 @@ def drain_all(sources: Sequence[Dict[str, list]], sort: Sequence[str], versions:
 
 
 def drain_current_to(sources: Sequence[Dict[str, list]], sort: Sequence[str], read_to: Sequence, include_finish: bool, versions: Sequence[str] = (),
-                     filters: Optional[Sequence[Optional[Sequence[bool]]]] = None):
-    """TMergePartialStream::DrainCurrentTo (merger.cpp:39-70) in forward order: a control point with the key `read_to` is
-    put into the heap, where it sorts in front of the rows of its own key (batch_iterator.cpp:33-42); positions are
-    drained until it is reached, and the position of its key as well when `include_finish` (merger.cpp:47-59).
+                     filters: Optional[Sequence[Optional[Sequence[bool]]]] = None, reverse: bool = False):
+    """TMergePartialStream::DrainCurrentTo (merger.cpp:39-70): a control point with the key `read_to` is put into the
+    heap, where it sorts in front of the rows of its own key (batch_iterator.cpp:33-42); positions are drained until it
+    is reached, and the position of its key as well when `include_finish` (merger.cpp:47-59).  With `reverse` the
+    sources are read from their ends and "in front of" means a greater key (batch_iterator.h:18-24).
     Returns (drained rows, what is left of every source, what is left of every filter)."""
     names = list(sources[0].keys()) if sources else []
     out: Dict[str, list] = {n: [] for n in names}
     border = tuple(read_to)
+    before = (lambda k: k > border) if reverse else (lambda k: k < border)
     heap = []
     for i, s in enumerate(sources):
         keep = filters[i] if filters else None
         if len(s[sort[0]]) == 0:
             continue
-        heap.append(_Iterator(i, s, keep, sort, versions, False))
+        heap.append(_Iterator(i, s, keep, sort, versions, reverse))
     wrap = functools.cmp_to_key(_order)
     items = [wrap(it) for it in heap]
     heapq.heapify(items)
     reached = False
     while items and not reached:
         top = items[0].obj
-        if not top.key() < border:  # the control point is on top: it precedes rows of its own key and all greater ones
+        if not before(top.key()):  # the control point is on top: it precedes rows of its own key and all that follow
             reached = True
-            if not include_finish or top.key() > border:
+            if not include_finish or top.key() != border:
                 break
         if not top.deleted():
             for n in names:
@@ -137,7 +139,33 @@ def drain_current_to(sources: Sequence[Dict[str, list]], sort: Sequence[str], re
     left_pos = {it.obj.index: it.obj.pos for it in items}
     rest, rest_filters = [], []
     for i, s in enumerate(sources):
-        p = left_pos.get(i, len(s[sort[0]]))
-        rest.append({n: v[p:] for n, v in s.items()})
-        rest_filters.append(None if not filters or filters[i] is None else list(filters[i][p:]))
+        n = len(s[sort[0]])
+        if reverse:  # rows 0 .. pos are left
+            lo, hi = 0, left_pos.get(i, -1) + 1
+        else:
+            lo, hi = left_pos.get(i, n), n
+        rest.append({c: v[lo:hi] for c, v in s.items()})
+        rest_filters.append(None if not filters or filters[i] is None else list(filters[i][lo:hi]))
     return out, rest, rest_filters
+
+
+def skip_to_lower_bound(sources: Sequence[Dict[str, list]], sort: Sequence[str], pos: Sequence, include: bool,
+                        filters: Optional[Sequence[Optional[Sequence[bool]]]] = None, reverse: bool = False):
+    """TMergePartialStream::SkipToLowerBound (merger.cpp:209-236): while the heap's top is before `pos` -- or at it and
+    not `include` -- its source is moved to its first row not before `pos` (SkipToLower) and, at `pos` without `include`,
+    one row further; a source that ends on the way leaves the heap.  Restated source by source: the rows it drops are
+    those before `pos` and, without `include`, those equal to it.  Returns (what is left of every source, of every filter)."""
+    border = tuple(pos)
+    rest, rest_filters = [], []
+    for i, s in enumerate(sources):
+        n = len(s[sort[0]])
+        keys = [tuple(s[c][r] for c in sort) for r in range(n)]
+        if reverse:
+            gone = sum(1 for k in keys if k > border or (k == border and not include))
+            lo, hi = 0, n - gone
+        else:
+            gone = sum(1 for k in keys if k < border or (k == border and not include))
+            lo, hi = gone, n
+        rest.append({c: v[lo:hi] for c, v in s.items()})
+        rest_filters.append(None if not filters or filters[i] is None else list(filters[i][lo:hi]))
+    return rest, rest_filters

@@ -188,3 +188,67 @@ def test_drain_current_to_against_the_oracle(seed):
         assert exp is None or not exp["k1"]
     else:
         assert {k: [x.item() for x in c.values] for k, c in pc.Export(out).items()} == exp
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_drains_from_the_ends_skips_and_parts(seed):
+    """The stream read from the ends of its sources (reverse): DrainCurrentTo in steps over falling borders, a
+    SkipToLowerBound in between, then the rest; and DrainAllParts in forward order.  Every step equals the oracle's."""
+    from oracle import merge_oracle
+    from ydb_amd.column_filter import ColumnFilter
+    from ydb_amd.merger import MergePartialStream
+    rng = np.random.default_rng(950 + seed)
+    pc = container()
+    sources = [s for s in random_sources(rng, int(rng.integers(2, 6)), max_rows=1500, key_space=300) if len(s["k2"])]
+    filters = [None if rng.random() < 0.5 else list(rng.random(len(s["k2"])) > 0.3) for s in sources] if seed % 2 else None
+
+    def stream(reverse):
+        m = MergePartialStream(pc, ["k1", "k2"], reverse=reverse, version_columns=["ver"])
+        for i, s in enumerate(sources):
+            f = ColumnFilter.FromValues(pc, filters[i]) if filters and filters[i] is not None else None
+            m.AddSource(pc.Import({k: np.asarray(v) for k, v in s.items()}), f)
+        return m
+
+    def rows_of(out, like):
+        return {k: [] for k in like} if out is None else {k: [x.item() for x in c.values] for k, c in pc.Export(out).items()}
+
+    def border_of(b):
+        return {"k1": np.array([b], np.int64), "k2": np.array([1], np.uint16)}
+
+    plain0 = [{k: [x.item() for x in np.asarray(v)] for k, v in s.items()} for s in sources]
+    # reverse: two drains, a skip, the rest
+    merger, plain, pf = stream(True), plain0, filters
+    borders = sorted((int(x) for x in rng.integers(-300, 300, 3)), reverse=True)
+    for step, border in enumerate(borders):
+        include = bool(rng.random() < 0.5)
+        if step == 1:
+            plain, pf = merge_oracle.skip_to_lower_bound(plain, ["k1", "k2"], [border, 1], include, pf, reverse=True)
+            merger.SkipToLowerBound(border_of(border), include)
+            continue
+        exp, plain, pf = merge_oracle.drain_current_to(plain, ["k1", "k2"], [border, 1], include, ["ver"], pf, reverse=True)
+        assert rows_of(merger.DrainCurrentTo(border_of(border), include), exp) == exp, (seed, border, include)
+    live = [(s, f) for s, f in zip(plain, pf or [None] * len(plain)) if len(s["k2"])]
+    exp = merge_oracle.drain_all([s for s, _ in live], ["k1", "k2"], ["ver"], True, [f for _, f in live]) if live else None
+    out = merger.DrainAll()
+    if exp is None:
+        assert out is None or out.rows == 0
+    else:
+        assert rows_of(out, exp) == exp
+    # forward: a skip, then DrainAllParts
+    merger, plain, pf = stream(False), plain0, filters
+    lo = int(rng.integers(-300, 0))
+    plain, pf = merge_oracle.skip_to_lower_bound(plain, ["k1", "k2"], [lo, 1], False, pf)
+    merger.SkipToLowerBound(border_of(lo), False)
+    positions = [(b, bool(rng.random() < 0.5)) for b in sorted(int(x) for x in rng.integers(lo, 300, 3))]
+    want = []
+    for b, include in positions:
+        exp, plain, pf = merge_oracle.drain_current_to(plain, ["k1", "k2"], [b, 1], include, ["ver"], pf)
+        if exp["k1"]:
+            want.append(exp)
+    live = [(s, f) for s, f in zip(plain, pf or [None] * len(plain)) if len(s["k2"])]
+    if live:
+        exp = merge_oracle.drain_all([s for s, _ in live], ["k1", "k2"], ["ver"], False, [f for _, f in live])
+        if exp["k1"]:
+            want.append(exp)
+    got = [rows_of(p, None) for p in merger.DrainAllParts([(border_of(b), inc) for b, inc in positions])]
+    assert got == want

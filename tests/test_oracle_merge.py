@@ -91,3 +91,35 @@ def test_drain_current_to_stops_at_the_control_point():
     second = merge_oracle.drain_all(rest, ["k"], ["v"])
     whole = merge_oracle.drain_all([a, b], ["k"], ["v"])
     assert {n: first[n] + second[n] for n in whole} == whole
+
+
+def test_drain_current_to_from_the_ends():
+    """Sources read from their ends: the rows above the border leave, greatest first (batch_iterator.h:18-24)."""
+    a = {"k": [1, 3, 5, 7], "v": [1, 1, 1, 1]}
+    b = {"k": [2, 3, 6, 7], "v": [2, 2, 2, 2]}
+    got, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [3], include_finish=False, versions=["v"], reverse=True)
+    assert got == {"k": [7, 6, 5], "v": [2, 2, 1]}
+    assert rest == [{"k": [1, 3], "v": [1, 1]}, {"k": [2, 3], "v": [2, 2]}]
+    got, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [3], include_finish=True, versions=["v"], reverse=True)
+    assert got == {"k": [7, 6, 5, 3], "v": [2, 2, 1, 2]}
+    assert rest == [{"k": [1], "v": [1]}, {"k": [2], "v": [2]}]
+    first, rest, _ = merge_oracle.drain_current_to([a, b], ["k"], [4], include_finish=True, versions=["v"], reverse=True)
+    second = merge_oracle.drain_all(rest, ["k"], ["v"], True)
+    whole = merge_oracle.drain_all([a, b], ["k"], ["v"], True)
+    assert {n: first[n] + second[n] for n in whole} == whole
+
+
+def test_skip_to_lower_bound():
+    a = {"k": [1, 3, 3, 7], "v": [1, 2, 1, 1]}
+    b = {"k": [2, 4], "v": [2, 2]}
+    rest, _ = merge_oracle.skip_to_lower_bound([a, b], ["k"], [3], include=True)
+    assert rest == [{"k": [3, 3, 7], "v": [2, 1, 1]}, {"k": [4], "v": [2]}]
+    rest, _ = merge_oracle.skip_to_lower_bound([a, b], ["k"], [3], include=False)
+    assert rest == [{"k": [7], "v": [1]}, {"k": [4], "v": [2]}]
+    rest, flt = merge_oracle.skip_to_lower_bound([a, b], ["k"], [3], include=True, filters=[[True, False, True, True], None], reverse=True)
+    assert rest == [{"k": [1, 3, 3], "v": [1, 2, 1]}, {"k": [2], "v": [2]}] and flt == [[True, False, True], None]
+    rest, _ = merge_oracle.skip_to_lower_bound([a, b], ["k"], [100], include=True)
+    assert all(len(r["k"]) == 0 for r in rest)
+    # what a skip leaves is what a drain to the same border leaves
+    _, left, _ = merge_oracle.drain_current_to([a, b], ["k"], [3], include_finish=False, versions=["v"])
+    assert left == merge_oracle.skip_to_lower_bound([a, b], ["k"], [3], include=True)[0]

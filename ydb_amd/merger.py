@@ -37,31 +37,71 @@ class MergePartialStream:
     def IsEmpty(self) -> bool:
         return not self._sources
 
-    def DrainCurrentTo(self, read_to, include_finish: bool) -> Optional[DeviceBatch]:
-        """merger.cpp:39-70 (PutControlPoint + DrainToControlPoint): the merged rows whose key is below the border
-        `read_to` (a one-row batch of the sort columns) -- and equal to it when `include_finish`: the control point sorts
-        in front of the rows of its key (batch_iterator.cpp:33-42) and DrainToControlPoint drains that key only with
-        includeFinish.  The other rows stay in the stream for the next drain.  Every source is sorted, so the rows that
-        leave are a prefix of it: one predicate filter per source finds its length, the prefix goes through the merge,
-        the rest is kept as a view.  Forward order only."""
-        if self._reverse:
-            raise NotImplementedError("DrainCurrentTo over sources read from their ends")
+    def _split(self, border, compare: int):
+        """Per source: the number of rows at the reading end for which `row <compare> border` holds (every source is
+        sorted, so they are a prefix of it, or in reverse order a suffix), found by one predicate filter."""
         from .column_filter import ColumnFilter
-        LESS, LESS_OR_EQUAL = 1, 2
-        head = MergePartialStream(self._pc, self._sort, False, self._versions)
+        counts = []
+        for batch in self._sources:
+            k = ColumnFilter.MakePredicateFilter(self._pc, batch, border, compare).GetFilteredCount()
+            counts.append(batch.rows if k is None else k)
+        return counts
+
+    def _cut(self, counts, keep_head: bool):
+        """Takes `counts[i]` rows off the reading end of every source.  Returns a stream of the rows taken when
+        `keep_head`; the rows left stay in this one (sources with no rows left are dropped, as the heap drops them)."""
+        from .column_filter import ColumnFilter
+        head = MergePartialStream(self._pc, self._sort, self._reverse, self._versions) if keep_head else None
         rest_sources, rest_filters = [], []
-        for batch, flt in zip(self._sources, self._filters):
-            cut = ColumnFilter.MakePredicateFilter(self._pc, batch, read_to, LESS_OR_EQUAL if include_finish else LESS)
-            k = cut.GetFilteredCount()
-            k = batch.rows if k is None else k
+        for batch, flt, k in zip(self._sources, self._filters, counts):
             bits = flt.BuildSimpleFilter() if flt is not None else None
-            if k > 0:
-                head.AddSource(self._pc.Slice(batch, 0, k), ColumnFilter.FromValues(self._pc, list(bits[:k])) if bits is not None else None)
-            if k < batch.rows:
-                rest_sources.append(self._pc.Slice(batch, k, batch.rows - k))
-                rest_filters.append(ColumnFilter.FromValues(self._pc, list(bits[k:])) if bits is not None else None)
+            n = batch.rows
+            taken, left = ((n - k, n), (0, n - k)) if self._reverse else ((0, k), (k, n))
+            if head is not None and k > 0:
+                head.AddSource(self._pc.Slice(batch, taken[0], k),
+                               ColumnFilter.FromValues(self._pc, list(bits[taken[0]:taken[1]])) if bits is not None else None)
+            if k < n:
+                rest_sources.append(self._pc.Slice(batch, left[0], n - k))
+                rest_filters.append(ColumnFilter.FromValues(self._pc, list(bits[left[0]:left[1]])) if bits is not None else None)
         self._sources, self._filters = rest_sources, rest_filters
-        return head.DrainAll()
+        return head
+
+    def DrainCurrentTo(self, read_to, include_finish: bool) -> Optional[DeviceBatch]:
+        """merger.cpp:39-70 (PutControlPoint + DrainToControlPoint): the merged rows whose key comes before the border
+        `read_to` (a one-row batch of the sort columns) -- and those equal to it when `include_finish`: the control point
+        sorts in front of the rows of its key (batch_iterator.cpp:33-42) and DrainToControlPoint drains that key only
+        with includeFinish.  "Before" is below in forward order and above when the sources are read from their ends
+        (batch_iterator.h:18-24).  The other rows stay in the stream for the next drain.  One predicate filter per
+        source finds how many rows leave, those go through the merge, the rest is kept as a view."""
+        LESS, LESS_OR_EQUAL, GREATER, GREATER_OR_EQUAL = 1, 2, 3, 4
+        if self._reverse:
+            compare = GREATER_OR_EQUAL if include_finish else GREATER
+        else:
+            compare = LESS_OR_EQUAL if include_finish else LESS
+        return self._cut(self._split(read_to, compare), True).DrainAll()
+
+    def SkipToLowerBound(self, pos, include: bool) -> None:
+        """merger.cpp:209-236: every source is moved forward to its first row that is not before `pos` -- and past the
+        rows equal to it unless `include`; nothing is produced."""
+        LESS, LESS_OR_EQUAL, GREATER, GREATER_OR_EQUAL = 1, 2, 3, 4
+        if self._reverse:
+            compare = GREATER if include else GREATER_OR_EQUAL
+        else:
+            compare = LESS if include else LESS_OR_EQUAL
+        self._cut(self._split(pos, compare), False)
+
+    def DrainAllParts(self, positions) -> List[DeviceBatch]:
+        """merger.cpp:188-207: `positions` is a sequence of (border, include) in stream order; one drain per border and
+        one for what is left, parts without rows left out."""
+        parts = []
+        for border, include in positions:
+            part = self.DrainCurrentTo(border, include)
+            if part is not None and part.rows:
+                parts.append(part)
+        part = self.DrainAll()
+        if part is not None and part.rows:
+            parts.append(part)
+        return parts
 
     def DrainAll(self) -> Optional[DeviceBatch]:
         """merger.cpp:145-150.  None when there is no source to drain."""
