@@ -187,3 +187,14 @@ def test_two_ranks_on_one_gpu_end_with_the_whole_tables_result(tmp_path):
                             assert abs(g - e) <= 1e-11 * max(1.0, abs(e)), (name, exchange, key, col, g, e)
                         else:
                             assert g == e, (name, exchange, key, col, g, e)
+
+
+def test_one_rank_over_rccl_runs_the_device_exchange():
+    """The collectives of the exchange on device buffers over the `nccl` backend (RCCL), which a box with one GPU can run
+    with one rank only: all three exchange settings end with the plain scan's result."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    done = subprocess.run([sys.executable, os.path.join(here, "helpers", "rccl_one_rank.py"), "600000"], env=env, capture_output=True,
+                          text=True, timeout=420)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    assert "exchanges equal the plain scan" in done.stdout

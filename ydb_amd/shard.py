@@ -390,6 +390,12 @@ class ShardedScan:
                 torch.cuda.synchronize()
                 marks.append((what, time.perf_counter()))
 
+        def settle():
+            # A collective on device tensors is queued on the process group's stream, which torch's current stream then
+            # waits for -- the executor's own stream does not: what it reads next must have arrived.
+            if wire.type == "cuda":
+                torch.cuda.current_stream(wire).synchronize()
+
         heads = None
         if exchange in ("auto", "allgather"):
             # every rank's description of its whole partial table: enough to decide, and the first half of an all-gather
@@ -408,6 +414,7 @@ class ShardedScan:
             pc.PackData(partial, send.data_ptr(), width)
             recv = torch.empty(world * width, dtype=torch.uint8, device=wire)
             dist.all_gather_into_tensor(recv, send.to(wire))
+            settle()
             recv = recv.to(gpu)
             mark("all-gather")
             parts = [pc.Unpack(h, recv.data_ptr() + r * width, db, keep=recv) for r, (h, db) in enumerate(heads)]
@@ -433,6 +440,7 @@ class ShardedScan:
             mark("pack")
             recv = torch.empty(sum(in_sizes), dtype=torch.uint8, device=wire)
             dist.all_to_all_single(recv, send.to(wire), output_split_sizes=in_sizes, input_split_sizes=out_sizes)
+            settle()
             recv = recv.to(gpu)
             mark("all-to-all")
             parts, at = [], 0
