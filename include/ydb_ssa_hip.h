@@ -122,8 +122,10 @@ int ssa_batch_import(ssa_program_t* program, const struct ArrowArray* in, const 
  * compressed and its buffers are decoded on the GPU into the columns of a resident batch.  `schema` (a struct
  * ArrowSchema, may be NULL for a whole stream) is the schema of the chunk; a stream's own schema must agree with it in
  * column count and types.  Body compression: none and LZ4_FRAME (the reference's default, serializer/native.h:54-57);
- * a ZSTD body, dictionary-encoded and nested columns are SSA_UNSUPPORTED (the shim keeps the CPU deserializer for
- * those).  Damaged metadata, buffers that do not decode to their announced length and string offsets that run past
+ * dictionary-encoded STRING / BINARY columns (a DictionaryBatch message per dictionary: what the dictionary transformer
+ * stores, ydb/core/formats/arrow/transformer/dictionary.cpp:5-7) become dictionary columns that stay encoded (index_type
+ * of ssa_device_column below); a ZSTD body, delta dictionaries, dictionaries of other value types or with null entries
+ * and nested columns are SSA_UNSUPPORTED (the shim keeps the CPU deserializer for those).  Damaged metadata, buffers that do not decode to their announced length and string offsets that run past
  * the data are SSA_INVALID (the reference returns SerializationError).  ssa_batches_from_blobs decodes `nblobs` blobs
  * of one schema with one kernel launch for all their buffers (one wavefront per compressed buffer) and fills out[0 ..
  * nblobs) -- the portions of a scan; on failure no batch is returned.

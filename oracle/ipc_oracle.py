@@ -86,6 +86,16 @@ _NP = {"bool": np.uint8, "int8": np.int8, "int16": np.int16, "int32": np.int32, 
        "uint32": np.uint32, "uint64": np.uint64, "float": np.float32, "double": np.float64, "timestamp": np.int64, "duration": np.int64}
 
 
+def _field_dictionary(fb: _Fb, f: int):
+    """(dictionary id, code type) of a dictionary-encoded field (Schema.fbs: Field.dictionary = DictionaryEncoding {id,
+    indexType, isOrdered, dictionaryKind}; an absent indexType is int32), else None."""
+    enc = fb.table(f, 4)
+    if not enc:
+        return None
+    it = fb.table(enc, 1)
+    return fb.scalar(enc, 0, "q"), (_INT[(fb.scalar(it, 0, "i"), fb.scalar(it, 1, "B"))] if it else "int32")
+
+
 def _field_type(fb: _Fb, f: int) -> str:
     tt = fb.scalar(f, 2, "B")
     t = fb.table(f, 3)
@@ -101,6 +111,28 @@ def read_blob(blob: bytes, schema: Optional[List[Tuple[str, str]]] = None) -> Di
     RecordBatch message."""
     pos = 0
     fields = list(schema) if schema else None
+    encodings = [None] * len(fields) if fields else []
+    dictionaries: Dict[int, dict] = {}
+
+    def buffers_of(fb, body, record_batch):
+        """A reader of the buffers a RecordBatch table lists, one after the other, decoded."""
+        bufs, _ = fb.vector(record_batch, 2)
+        comp = fb.table(record_batch, 3)
+        codec = fb.scalar(comp, 0, "b") if comp else -1
+        if codec == 1:
+            raise ValueError("Unsupported: ZSTD")
+        state = {"i": 0}
+
+        def take():
+            off, ln = struct.unpack_from("<qq", fb.b, bufs + 16 * state["i"])
+            state["i"] += 1
+            raw = blob[body + off: body + off + ln]
+            if codec == -1 or ln == 0:
+                return raw
+            ulen, = struct.unpack_from("<q", raw, 0)
+            return raw[8:] if ulen == -1 else lz4_frame_decode(raw[8:], ulen)
+        return take
+
     while True:
         marker, = struct.unpack_from("<I", blob, pos)
         if marker == 0xFFFFFFFF:
@@ -119,32 +151,31 @@ def read_blob(blob: bytes, schema: Optional[List[Tuple[str, str]]] = None) -> Di
         body = pos + meta_len
         if header_type == 1:
             p, n = fb.vector(header, 1)
-            fields = []
+            fields, encodings = [], []
             for i in range(n):
                 f = p + 4 * i + fb.u("I", p + 4 * i)
                 fields.append((fb.string(f, 0), _field_type(fb, f)))
+                encodings.append(_field_dictionary(fb, f))
+            pos = body + body_len
+            continue
+        if header_type == 2:  # DictionaryBatch {id, data: RecordBatch of one string column, isDelta}
+            data = fb.table(header, 1)
+            if fb.scalar(header, 2, "B"):
+                raise ValueError("Unsupported: delta dictionary")
+            entries = fb.scalar(data, 0, "q")
+            take = buffers_of(fb, body, data)
+            take()  # validity: dictionaries with null entries are not decoded
+            offsets = take()
+            dictionaries[fb.scalar(header, 0, "q")] = {
+                "offsets": np.frombuffer(offsets, dtype=np.int32, count=entries + 1).copy() if entries or len(offsets) >= 4 else np.zeros(1, np.int32),
+                "chars": bytes(take())}
             pos = body + body_len
             continue
         if header_type != 3:
             raise ValueError(f"unexpected message type {header_type}")
         rows = fb.scalar(header, 0, "q")
         nodes, nnodes = fb.vector(header, 1)
-        bufs, nbufs = fb.vector(header, 2)
-        comp = fb.table(header, 3)
-        codec = fb.scalar(comp, 0, "b") if comp else -1
-        if codec == 1:
-            raise ValueError("Unsupported: ZSTD")
-        bi = 0
-
-        def take():
-            nonlocal bi
-            off, ln = struct.unpack_from("<qq", fb.b, bufs + 16 * bi)
-            bi += 1
-            raw = blob[body + off: body + off + ln]
-            if codec == -1 or ln == 0:
-                return raw
-            ulen, = struct.unpack_from("<q", raw, 0)
-            return raw[8:] if ulen == -1 else lz4_frame_decode(raw[8:], ulen)
+        take = buffers_of(fb, body, header)
 
         out: Dict[str, dict] = {}
         for i in range(nnodes):
@@ -156,7 +187,17 @@ def read_blob(blob: bytes, schema: Optional[List[Tuple[str, str]]] = None) -> Di
                 valid = np.unpackbits(np.frombuffer(vbits, dtype=np.uint8), bitorder="little")[:length].astype(np.bool_)
             col = {"type": typ, "valid": valid}
             data = take()
-            if typ in ("string", "binary"):
+            if i < len(encodings) and encodings[i] is not None:
+                # a dictionary-encoded column read as the column it stands for (dictionary/conversion.h:13-15,
+                # DictionaryToArray): every row the entry its code names, a null row the empty string
+                d = dictionaries[encodings[i][0]]
+                codes = np.frombuffer(data, dtype=_NP[encodings[i][1]], count=length).astype(np.int64)
+                strs = [d["chars"][d["offsets"][c]:d["offsets"][c + 1]] if ok else b"" for c, ok in zip(codes, valid)]
+                col["offsets"] = np.concatenate([[0], np.cumsum([len(x) for x in strs])]).astype(np.int32)
+                col["chars"] = b"".join(strs)
+                col["codes"] = codes
+                col["entries"] = len(d["offsets"]) - 1
+            elif typ in ("string", "binary"):
                 col["offsets"] = np.frombuffer(data, dtype=np.int32, count=length + 1).copy() if length or len(data) >= 4 else np.zeros(1, np.int32)
                 col["chars"] = bytes(take())
             elif typ == "bool":

@@ -72,7 +72,12 @@ def full_stream(t, codec):
     sink = io.BytesIO()
     opts = ipc.IpcWriteOptions(compression=codec)
     with ipc.new_stream(sink, t.schema, options=opts) as w:
-        w.write_batch(t.to_batches()[0] if t.num_rows else pa.RecordBatch.from_pylist([], schema=t.schema))
+        if t.num_rows:
+            w.write_batch(t.to_batches()[0])
+        elif any(pa.types.is_dictionary(f.type) for f in t.schema):
+            w.write_batch(pa.RecordBatch.from_arrays([c.combine_chunks() for c in t.columns], schema=t.schema))  # (keeps the dictionaries)
+        else:
+            w.write_batch(pa.RecordBatch.from_pylist([], schema=t.schema))
     return sink.getvalue()
 
 
@@ -88,6 +93,28 @@ def payload_only(t, codec):
     m2, meta2 = struct.unpack_from("<II", whole, pos)
     assert m2 == 0xFFFFFFFF
     return whole[pos:len(whole) - 8]
+
+
+def dictionary_table(n, rng):
+    """Dictionary-encoded string columns as the dictionary transformer stores them (ArrayToDictionary,
+    ydb/core/formats/arrow/dictionary/conversion.h:11-12): codes of several widths, nulls among the rows, entries no row
+    uses, the empty string as an entry; a plain column next to them."""
+    words = ["", "N", "R", "A", "google", "the quick brown fox jumps over the lazy dog", "never used"]
+    codes = rng.integers(0, len(words) - 1, n)
+    valid = rng.random(n) > 0.25
+    few = ["F", "O"]
+    cols = {
+        "ds": pa.DictionaryArray.from_arrays(pa.array(codes.astype(np.int32), mask=~valid), pa.array(words, type=pa.utf8())),
+        "flag": pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 2, n).astype(np.int8)), pa.array(few, type=pa.utf8())),
+        "db": pa.DictionaryArray.from_arrays(pa.array((codes % 5).astype(np.uint16)), pa.array([w.encode() for w in words[:5]], type=pa.binary())),
+        "v": pa.array(rng.integers(0, 100, n).astype(np.int64)),
+    }
+    return pa.table(cols)
+
+
+def expected_decoded(t):
+    return expected(pa.table({name: (t.column(name).combine_chunks().dictionary_decode() if pa.types.is_dictionary(t.schema.field(name).type)
+                                     else t.column(name)) for name in t.column_names}))
 
 
 def main():
@@ -111,7 +138,18 @@ def main():
                 cases.append({"name": case, "rows": n, "codec": codec or "raw", "form": form, "expected": name, "bytes": len(blob)})
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **exp)
     schema = [(f.name, str(f.type)) for f in table(1, rng).schema]
-    json.dump({"cases": cases, "schema": schema, "about": "made by tests/golden/make_ipc_fixtures.py with pyarrow " + pa.__version__},
+    drng = np.random.default_rng(2026)
+    for name, n in (("dict_empty", 0), ("dict_small", 700), ("dict_blocks", 40000)):
+        t = dictionary_table(n, drng)
+        for codec in (None, "lz4"):
+            blob = full_stream(t, codec)
+            case = f"{name}_{codec or 'raw'}_stream"
+            open(os.path.join(HERE, case + ".bin"), "wb").write(blob)
+            cases.append({"name": case, "rows": n, "codec": codec or "raw", "form": "stream", "expected": name, "bytes": len(blob), "dictionary": True})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **expected_decoded(t))
+    dict_schema = [("ds", "string"), ("flag", "string"), ("db", "binary"), ("v", "int64")]
+    json.dump({"cases": cases, "schema": schema, "dictionary_schema": dict_schema,
+               "about": "made by tests/golden/make_ipc_fixtures.py with pyarrow " + pa.__version__},
               open(os.path.join(HERE, "cases.json"), "w"), indent=1)
     print(sum(c["bytes"] for c in cases), "bytes of blobs in", len(cases), "cases")
 

@@ -7,16 +7,16 @@ import numpy as np
 import pytest
 
 from test_host_blob import CASES, IPC, schema_batch
-from test_oracle_ipc import SCHEMA, check_columns
+from test_oracle_ipc import DICT_SCHEMA, SCHEMA, check_columns, schema_of
 
 pytestmark = pytest.mark.gpu
 
 
-def container():
+def container(schema=None):
     from ydb_amd.program import ProgramContainer
     from ydb_amd.ssa_pb import Program
     pc = ProgramContainer()
-    ok, err = pc.Init([(i + 1, n) for i, (n, _) in enumerate(SCHEMA)], Program().project([1]))
+    ok, err = pc.Init([(i + 1, n) for i, (n, _) in enumerate(schema or SCHEMA)], Program().project([1]))
     assert ok, err
     return pc
 
@@ -43,16 +43,17 @@ def as_columns(exported):
 @pytest.mark.parametrize("case", [c for c in CASES["cases"] if c["codec"] != "zstd"], ids=lambda c: c["name"])
 def test_blob_decodes_to_the_columns_arrow_wrote(case):
     from oracle import ipc_oracle
-    pc = container()
+    schema = schema_of(case)
+    pc = container(schema)
     blob = open(os.path.join(IPC, case["name"] + ".bin"), "rb").read()
     payload = case["form"] == "payload"
     dev = pc.ImportBlob(blob, schema_batch() if payload else None)
     assert dev.rows == case["rows"]
-    got = as_columns(pc.Export(dev))
-    check_columns(got, np.load(os.path.join(IPC, case["expected"] + ".npz")), case["rows"])
+    got = as_columns(pc.Export(dev))  # (dictionary-encoded columns leave as the columns they stand for)
+    check_columns(got, np.load(os.path.join(IPC, case["expected"] + ".npz")), case["rows"], schema)
     # and byte for byte what the oracle reads, null slots included
     exp = ipc_oracle.read_blob(blob, SCHEMA if payload else None)
-    for name, typ in SCHEMA:
+    for name, typ in schema:
         if typ in ("string", "binary"):
             assert got[name]["chars"] == exp[name]["chars"][exp[name]["offsets"][0]:exp[name]["offsets"][-1]] or case["rows"] == 0
         else:
@@ -71,7 +72,7 @@ def test_many_blobs_in_one_call():
     assert len(devs) == len(blobs)
     by_name = {c["name"]: c for c in CASES["cases"]}
     for n, d in zip(names, devs):
-        check_columns(as_columns(pc.Export(d)), np.load(os.path.join(IPC, by_name[n]["expected"] + ".npz")), by_name[n]["rows"])
+        check_columns(as_columns(pc.Export(d)), np.load(os.path.join(IPC, by_name[n]["expected"] + ".npz")), by_name[n]["rows"], schema_of(by_name[n]))
 
 
 def test_zstd_is_declined_and_damage_is_an_error():
@@ -122,3 +123,42 @@ def test_program_over_a_decoded_blob():
             "s": Col([sc[so[i]:so[i + 1]].decode() for i in range(len(so) - 1)], type="string")}
     exp = ssa_oracle.Oracle(resolver, p).apply(host)
     compare_batches(got, exp, key_names=["u8", "s"], float_sum_names=["110"])
+
+
+def test_program_over_a_blob_with_dictionary_columns():
+    """Dictionary-encoded columns of a blob stay encoded in HBM: a filter on one of them is evaluated per entry, the
+    GROUP BY groups by code -- with the results of the decoded columns (dictionary/conversion.h:13-15)."""
+    import ctypes
+    from cases import compare_batches
+    from oracle import ssa_oracle
+    from ydb_amd import _lib
+    from ydb_amd.arrow_c import Col
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
+    exp_cols = np.load(os.path.join(IPC, "dict_blocks.npz"))
+    resolver = [(i + 1, n) for i, (n, _) in enumerate(DICT_SCHEMA)]
+    ids = {n: i for i, n in resolver}
+    p = (Program().assign_const(100, "Bytes", b"o").assign_func(101, F.STR_MATCH, [ids["ds"], 100]).filter(101)
+         .group_by([Aggregate(110, AGG.SUM, [ids["v"]]), Aggregate(111, AGG.COUNT, [ids["ds"]]), Aggregate(112, AGG.COUNT, [])],
+                   keys=[ids["flag"], ids["db"]]))
+    pc = ProgramContainer()
+    assert pc.Init(resolver, p)[0]
+
+    def on_codes():
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.load().ssa_dictionary_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value
+
+    before = on_codes()
+    dev = pc.ImportBlob(open(os.path.join(IPC, "dict_blocks_lz4_stream.bin"), "rb").read())
+    got = pc.Export(pc.ApplyDevice(dev))
+    assert on_codes() > before
+
+    def strings(name, as_text):
+        o, c, v = exp_cols[name + ".offsets"], exp_cols[name + ".chars"].tobytes(), exp_cols[name + ".valid"]
+        vals = [c[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+        return Col([x.decode() for x in vals] if as_text else vals, type="string" if as_text else "binary", valid=None if v.all() else v)
+
+    host = {"ds": strings("ds", True), "flag": strings("flag", True), "db": strings("db", False), "v": exp_cols["v.values"]}
+    exp = ssa_oracle.Oracle(resolver, p).apply(host)
+    compare_batches(got, exp, key_names=["flag", "db"])

@@ -43,7 +43,9 @@ def test_describe_fixture(case):
     head = text.splitlines()[0]
     assert f"rows={case['rows']} " in head
     assert {"raw": "codec=none", "lz4": "codec=lz4_frame", "zstd": "codec=zstd"}[case["codec"]] in head
-    assert len(text.splitlines()) == 1 + len(CASES["schema"])
+    assert len(text.splitlines()) == 1 + len(CASES["dictionary_schema"] if case.get("dictionary") else CASES["schema"])
+    if case.get("dictionary"):
+        assert text.count("dictionary(id") == 3 and "7 entries" in text and "2 entries" in text and "5 entries" in text
     if case["codec"] == "lz4" and case["rows"] >= 30000:
         assert "linked" in text and "blocks of 65536" in text   # what Arrow's codec writes: 64 KB blocks that refer back
 

@@ -16,12 +16,18 @@ CASES = json.load(open(os.path.join(IPC, "cases.json")))
 TYPE_OF = {"int64": "int64", "int32": "int32", "uint8": "uint8", "uint16": "uint16", "double": "double", "float": "float", "bool": "bool",
            "string": "string", "binary": "binary", "timestamp[us]": "timestamp", "decimal128(20, 2)": "decimal128"}
 SCHEMA = [(n, TYPE_OF[t]) for n, t in CASES["schema"]]
+DICT_SCHEMA = [tuple(x) for x in CASES["dictionary_schema"]]  # the cases with dictionary-encoded columns, as decoded
 
 
-def check_columns(got, exp, rows):
+def schema_of(case):
+    return DICT_SCHEMA if case.get("dictionary") else SCHEMA
+
+
+def check_columns(got, exp, rows, schema=None):
     """got: {name: {"type", "valid", "values" | "offsets" + "chars"}}; exp: the .npz of the case."""
-    assert list(got.keys()) == [n for n, _ in SCHEMA]
-    for name, typ in SCHEMA:
+    schema = schema or SCHEMA
+    assert list(got.keys()) == [n for n, _ in schema]
+    for name, typ in schema:
         g = got[name]
         assert g["type"] == typ, (name, g["type"])
         valid = exp[name + ".valid"]
@@ -47,7 +53,10 @@ def test_oracle_reads_arrow_blobs(case):
     blob = open(os.path.join(IPC, case["name"] + ".bin"), "rb").read()
     exp = np.load(os.path.join(IPC, case["expected"] + ".npz"))
     got = ipc_oracle.read_blob(blob, SCHEMA if case["form"] == "payload" else None)
-    check_columns(got, exp, case["rows"])
+    check_columns(got, exp, case["rows"], schema_of(case))
+    if case.get("dictionary"):  # read through the codes: the dictionary came in a message of its own
+        assert got["ds"]["entries"] == 7 and got["flag"]["entries"] == 2 and got["db"]["entries"] == 5
+        assert got["flag"]["codes"].max(initial=0) <= 1
 
 
 def lz4_frames_of(blob):

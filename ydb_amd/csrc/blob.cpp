@@ -32,7 +32,9 @@ namespace {
 
 struct PendingBuffer {
     size_t Blob;       // which blob
-    IpcBuffer Where;   // inside that blob's body
+    IpcBuffer Where;   // inside the body of one of that blob's messages ...
+    size_t Body;       // ... which starts here in the blob ...
+    int32_t Codec;     // ... and is compressed this way
     size_t MinBytes;   // bytes the column needs from it (0: whatever it holds)
     BufferPtr* Target; // receives the decoded buffer
     int64_t* Bytes;    // receives its length (may be null)
@@ -51,7 +53,9 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
     for (size_t i = 0; i < nb; ++i) {
         if (!blobs[i].first && blobs[i].second) return Status::Invalid("null blob");
         SSA_RETURN_NOT_OK(ParseIpcBlob(blobs[i].first, blobs[i].second, schema, parsed[i]));
-        if (parsed[i].Codec == IPC_ZSTD) return Status::Unsupported("ZSTD body compression of an IPC blob (LZ4_FRAME and uncompressed bodies are decoded)");
+        bool zstd = parsed[i].Codec == IPC_ZSTD;
+        for (const IpcDictionary& d : parsed[i].Dicts) zstd = zstd || d.Codec == IPC_ZSTD;
+        if (zstd) return Status::Unsupported("ZSTD body compression of an IPC blob (LZ4_FRAME and uncompressed bodies are decoded)");
         base[i] = total;
         total += (blobs[i].second + 255) & ~size_t(255);
     }
@@ -66,17 +70,46 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
 
     std::vector<BatchPtr> batches(nb);
     std::vector<PendingBuffer> pending;
-    std::vector<int64_t> dataBytes;  // per string column: bytes of its data buffer
+    // string columns (and dictionaries: their values are one) whose offsets are checked against their data buffers below
+    struct StringCheck {
+        Column* Col;
+        int64_t Bytes;
+    };
+    std::vector<StringCheck> strings;
     size_t nstrings = 0;
     for (size_t i = 0; i < nb; ++i) {
-        for (auto& c : parsed[i].Columns) nstrings += IsStringLike(c.Field.Type);
+        for (auto& c : parsed[i].Columns) nstrings += IsStringLike(c.Field.Type) && c.DictId < 0;
+        nstrings += parsed[i].Dicts.size();
     }
-    dataBytes.assign(nstrings, 0);
-    size_t stringIdx = 0;
+    strings.reserve(nstrings);  // (the pending buffers keep addresses of its elements)
+    std::vector<std::shared_ptr<DictInfo>> dictKeep;
     for (size_t i = 0; i < nb; ++i) {
+        // the blob's dictionaries: plain string columns the encoded columns share by id
+        std::vector<std::shared_ptr<DictInfo>> dicts;
+        for (const IpcDictionary& d : parsed[i].Dicts) {
+            if (d.NullCount > 0) return Status::Unsupported("dictionary with null entries");
+            auto info = std::make_shared<DictInfo>();
+            Column& e = info->Entries;
+            e.Length = d.Rows;
+            e.NullCount = 0;
+            const size_t rows = size_t(d.Rows);
+            if (rows == 0 && d.Values.Length == 0) {
+                e.Values = Buffer::Alloc(16);  // a single zero offset
+                if (!e.Values) return Status::Hip("out of device memory");
+                SSA_HIP(hipMemsetAsync(e.Values->Ptr, 0, 16, StreamHandle));
+            } else {
+                pending.push_back({i, d.Values, d.BodyOffset, d.Codec, (rows + 1) * 4, &e.Values, nullptr});
+            }
+            strings.push_back({&e, 0});
+            pending.push_back({i, d.Data, d.BodyOffset, d.Codec, 0, &e.Chars, &strings.back().Bytes});
+            dicts.push_back(info);
+            dictKeep.push_back(info);
+        }
         auto b = std::make_shared<Batch>();
         b->Rows = parsed[i].Rows;
         b->Cols.resize(parsed[i].Columns.size());
+        const size_t body = parsed[i].BodyOffset;
+        const int32_t codec = parsed[i].Codec;
         for (size_t c = 0; c < parsed[i].Columns.size(); ++c) {
             const IpcColumn& ic = parsed[i].Columns[c];
             Column& col = b->Cols[c];
@@ -87,8 +120,24 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
             const size_t rows = size_t(ic.Length);
             if (ic.NullCount > 0) {
                 if (ic.Validity.Length == 0) return Status::Invalid("column '" + ic.Field.Name + "' counts nulls but has no validity buffer");
-                pending.push_back({i, ic.Validity, (rows + 7) / 8, &col.Validity, nullptr});
+                pending.push_back({i, ic.Validity, body, codec, (rows + 7) / 8, &col.Validity, nullptr});
                 col.Field.Nullable = true;
+            }
+            if (ic.DictId >= 0) {
+                // stays encoded in HBM (Column::Dict): the codes here, the values with the dictionary; a column of a type
+                // of its own per use, sharing the buffers (DictInfo holds what is worked out per dictionary and use)
+                for (size_t k = 0; k < parsed[i].Dicts.size(); ++k) {
+                    if (parsed[i].Dicts[k].Id == ic.DictId) col.Dict = dicts[k];
+                }
+                if (!col.Dict) return Status::Invalid("column '" + ic.Field.Name + "' refers to a dictionary the blob does not carry");
+                if (col.Dict->Entries.Field.Type != T_NONE && (col.Dict->Entries.Field.Type != ic.Field.Type || col.Dict->IndexType != ic.IndexType)) {
+                    return Status::Unsupported("one dictionary shared by columns of differing types");
+                }
+                col.Dict->Entries.Field.Type = ic.Field.Type;
+                col.Dict->Entries.Field.Name = ic.Field.Name;
+                col.Dict->IndexType = ic.IndexType;
+                pending.push_back({i, ic.Values, body, codec, rows * size_t(TypeWidth(ic.IndexType)), &col.Values, nullptr});
+                continue;
             }
             size_t need;
             if (IsStringLike(ic.Field.Type)) need = (rows + 1) * 4;
@@ -99,11 +148,11 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
                 if (!col.Values) return Status::Hip("out of device memory");
                 SSA_HIP(hipMemsetAsync(col.Values->Ptr, 0, 16, StreamHandle));
             } else {
-                pending.push_back({i, ic.Values, need, &col.Values, nullptr});
+                pending.push_back({i, ic.Values, body, codec, need, &col.Values, nullptr});
             }
             if (IsStringLike(ic.Field.Type)) {
-                pending.push_back({i, ic.Data, 0, &col.Chars, &dataBytes[stringIdx]});
-                ++stringIdx;
+                strings.push_back({&col, 0});
+                pending.push_back({i, ic.Data, body, codec, 0, &col.Chars, &strings.back().Bytes});
             }
         }
         batches[i] = b;
@@ -114,14 +163,13 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
     std::vector<Lz4BlockRef> blocks;
     uint32_t maxBlock = 0;
     for (PendingBuffer& pb : pending) {
-        const IpcBatch& ib = parsed[pb.Blob];
         const uint8_t* host = blobs[pb.Blob].first;
-        const size_t bufPos = ib.BodyOffset + size_t(pb.Where.Offset);  // inside the blob
+        const size_t bufPos = pb.Body + size_t(pb.Where.Offset);  // inside the blob
         int64_t rawLen = pb.Where.Length;     // bytes to copy as they are
         size_t rawPos = bufPos;
         int64_t outLen = rawLen;
         bool frame = false;
-        if (ib.Codec == IPC_LZ4_FRAME && pb.Where.Length > 0) {
+        if (pb.Codec == IPC_LZ4_FRAME && pb.Where.Length > 0) {
             if (pb.Where.Length < 8) return Status::Invalid("compressed buffer without its length prefix");
             int64_t ulen;
             std::memcpy(&ulen, host + bufPos, 8);
@@ -190,18 +238,14 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
         SSA_HIP(hipStreamSynchronize(StreamHandle));
     }
     // RecordBatch::Validate of the reference: offsets of a string column must describe its data buffer
-    stringIdx = 0;
-    for (size_t i = 0; i < nb; ++i) {
-        for (Column& col : batches[i]->Cols) {
-            if (!IsStringLike(col.Field.Type)) continue;
-            const int64_t bytes = dataBytes[stringIdx++];
-            if (col.Length == 0) continue;
-            int32_t ends[2] = {0, 0};
-            SSA_HIP(hipMemcpyAsync(&ends[0], col.Values->Ptr, 4, hipMemcpyDeviceToHost, StreamHandle));
-            SSA_HIP(hipMemcpyAsync(&ends[1], static_cast<const int32_t*>(col.Values->Ptr) + col.Length, 4, hipMemcpyDeviceToHost, StreamHandle));
-            SSA_HIP(hipStreamSynchronize(StreamHandle));
-            if (ends[0] < 0 || ends[1] < ends[0] || int64_t(ends[1]) > bytes) return Status::Invalid("validation error: string offsets run past the data buffer");
-        }
+    for (const StringCheck& sc : strings) {
+        const Column& col = *sc.Col;
+        if (col.Length == 0) continue;
+        int32_t ends[2] = {0, 0};
+        SSA_HIP(hipMemcpyAsync(&ends[0], col.Values->Ptr, 4, hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipMemcpyAsync(&ends[1], static_cast<const int32_t*>(col.Values->Ptr) + col.Length, 4, hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        if (ends[0] < 0 || ends[1] < ends[0] || int64_t(ends[1]) > sc.Bytes) return Status::Invalid("validation error: string offsets run past the data buffer");
     }
     out = batches;
     return Status::OK();

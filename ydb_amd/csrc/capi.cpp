@@ -312,6 +312,13 @@ char* ssa_blob_describe(const uint8_t* blob, size_t size, const ArrowSchema* sch
     for (const IpcColumn& c : b.Columns) {
         text += c.Field.Name + ":" + std::to_string(c.Field.Type) + " nulls=" + std::to_string(c.NullCount) + " buffers=" +
                 std::to_string(c.Validity.Length) + "," + std::to_string(c.Values.Length) + "," + std::to_string(c.Data.Length);
+        if (c.DictId >= 0) {
+            for (const IpcDictionary& d : b.Dicts) {
+                if (d.Id == c.DictId) {
+                    text += " dictionary(id " + std::to_string(d.Id) + ", " + std::to_string(d.Rows) + " entries, codes of type " + std::to_string(c.IndexType) + ")";
+                }
+            }
+        }
         if (b.Codec == IPC_LZ4_FRAME) {
             for (const IpcBuffer* buf : {&c.Validity, &c.Values, &c.Data}) {
                 if (buf->Length <= 8) continue;

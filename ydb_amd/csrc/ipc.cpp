@@ -95,29 +95,43 @@ private:
 enum FbType : uint8_t { FB_Int = 2, FB_FloatingPoint = 3, FB_Binary = 4, FB_Utf8 = 5, FB_Bool = 6, FB_Decimal = 7, FB_Timestamp = 10, FB_Duration = 18 };
 enum FbHeader : uint8_t { FB_Schema = 1, FB_DictionaryBatch = 2, FB_RecordBatch = 3 };
 
-Status ReadField(Fb& fb, size_t field, FieldDesc& out) {
+Status IntType(Fb& fb, size_t type, int32_t& out) {
+    const int32_t bits = type ? fb.Scalar<int32_t>(type, 0, 0) : 0;
+    const bool sgn = type ? fb.Scalar<uint8_t>(type, 1, 0) != 0 : false;
+    switch (bits) {
+        case 8: out = sgn ? T_I8 : T_U8; break;
+        case 16: out = sgn ? T_I16 : T_U16; break;
+        case 32: out = sgn ? T_I32 : T_U32; break;
+        case 64: out = sgn ? T_I64 : T_U64; break;
+        default: return Status::Unsupported("integer column of " + std::to_string(bits) + " bits");
+    }
+    return Status::OK();
+}
+
+// `dictId` / `indexType`: the field's DictionaryEncoding {id, indexType (absent: int32), isOrdered, dictionaryKind}, -1
+// for a plain column.  The field's own type is then the type of the dictionary's values.
+Status ReadField(Fb& fb, size_t field, FieldDesc& out, int64_t& dictId, int32_t& indexType) {
     out = FieldDesc();
+    dictId = -1;
+    indexType = T_NONE;
     out.Name = fb.String(field, 0);
     out.Nullable = fb.Scalar<uint8_t>(field, 1, 0) != 0;
     const uint8_t tt = fb.Scalar<uint8_t>(field, 2, 0);
     const size_t type = fb.Table(field, 3);
-    if (fb.Field(field, 4)) return Status::Unsupported("dictionary-encoded column '" + out.Name + "' in an IPC blob");
+    if (const size_t enc = fb.Table(field, 4)) {
+        if (tt != FB_Utf8 && tt != FB_Binary) return Status::Unsupported("dictionary of non-string values in column '" + out.Name + "'");
+        if (fb.Scalar<int16_t>(enc, 3, 0) != 0) return Status::Unsupported("dictionary kind of column '" + out.Name + "'");
+        dictId = fb.Scalar<int64_t>(enc, 0, 0);
+        indexType = T_I32;
+        if (const size_t it = fb.Table(enc, 1)) SSA_RETURN_NOT_OK_IPC(IntType(fb, it, indexType));
+    }
     uint32_t nchildren = 0;
     (void)fb.Vector(field, 5, nchildren);
     if (nchildren != 0) return Status::Unsupported("nested column '" + out.Name + "'");
     switch (tt) {
-        case FB_Int: {
-            const int32_t bits = type ? fb.Scalar<int32_t>(type, 0, 0) : 0;
-            const bool sgn = type ? fb.Scalar<uint8_t>(type, 1, 0) != 0 : false;
-            switch (bits) {
-                case 8: out.Type = sgn ? T_I8 : T_U8; break;
-                case 16: out.Type = sgn ? T_I16 : T_U16; break;
-                case 32: out.Type = sgn ? T_I32 : T_U32; break;
-                case 64: out.Type = sgn ? T_I64 : T_U64; break;
-                default: return Status::Unsupported("integer column of " + std::to_string(bits) + " bits");
-            }
+        case FB_Int:
+            SSA_RETURN_NOT_OK_IPC(IntType(fb, type, out.Type));
             break;
-        }
         case FB_FloatingPoint: {
             const int16_t prec = type ? fb.Scalar<int16_t>(type, 0, 0) : 0;
             if (prec == 1) out.Type = T_F32;
@@ -154,6 +168,7 @@ Status ReadField(Fb& fb, size_t field, FieldDesc& out) {
 Status ParseIpcBlob(const uint8_t* blob, size_t size, const std::vector<FieldDesc>& schema, IpcBatch& out) {
     out = IpcBatch();
     std::vector<FieldDesc> fields = schema;
+    std::vector<std::pair<int64_t, int32_t>> encoding(schema.size(), {-1, T_NONE});  // per field: dictionary id, index type
     bool haveSchema = !schema.empty();
     size_t pos = 0;
     for (int guard = 0; guard < 64; ++guard) {
@@ -182,12 +197,16 @@ Status ParseIpcBlob(const uint8_t* blob, size_t size, const std::vector<FieldDes
             const size_t vec = fb.Vector(header, 1, n);
             if (fb.Scalar<int16_t>(header, 0, 0) != 0) return Status::Unsupported("big-endian IPC stream");
             std::vector<FieldDesc> own;
+            std::vector<std::pair<int64_t, int32_t>> ownEncoding;
             for (uint32_t i = 0; i < n; ++i) {
                 FieldDesc f;
+                int64_t dictId;
+                int32_t indexType;
                 const size_t field = fb.Indirect(vec + 4 * size_t(i));
                 if (!fb.Ok()) return Status::Invalid("damaged IPC schema");
-                SSA_RETURN_NOT_OK_IPC(ReadField(fb, field, f));
+                SSA_RETURN_NOT_OK_IPC(ReadField(fb, field, f, dictId, indexType));
                 own.push_back(f);
+                ownEncoding.push_back({dictId, indexType});
             }
             if (!fb.Ok()) return Status::Invalid("damaged IPC schema");
             if (haveSchema) {
@@ -197,11 +216,51 @@ Status ParseIpcBlob(const uint8_t* blob, size_t size, const std::vector<FieldDes
                 }
             }
             fields = own;
+            encoding = ownEncoding;
             haveSchema = true;
             pos = bodyPos + size_t(bodyLength);
             continue;
         }
-        if (headerType == FB_DictionaryBatch) return Status::Unsupported("dictionary batch in an IPC blob");
+        if (headerType == FB_DictionaryBatch) {
+            // {id, data: RecordBatch of one column, isDelta}
+            IpcDictionary d;
+            d.Id = fb.Scalar<int64_t>(header, 0, 0);
+            const size_t data = fb.Table(header, 1);
+            if (fb.Scalar<uint8_t>(header, 2, 0) != 0) return Status::Unsupported("delta dictionary batch in an IPC blob");
+            if (!fb.Ok() || !data) return Status::Invalid("damaged DictionaryBatch metadata");
+            d.Rows = fb.Scalar<int64_t>(data, 0, 0);
+            uint32_t nnodes = 0, nbuffers = 0;
+            const size_t nodes = fb.Vector(data, 1, nnodes);
+            const size_t buffers = fb.Vector(data, 2, nbuffers);
+            if (const size_t compression = fb.Table(data, 3)) {
+                d.Codec = fb.Scalar<int8_t>(compression, 0, 0);
+                if (fb.Scalar<int8_t>(compression, 1, 0) != 0) return Status::Unsupported("IPC body compression method other than BUFFER");
+                if (d.Codec != IPC_LZ4_FRAME && d.Codec != IPC_ZSTD) return Status::Unsupported("unknown IPC body compression codec");
+            }
+            if (!fb.Ok() || d.Rows < 0 || nnodes != 1 || nbuffers != 3) return Status::Unsupported("a dictionary that is not one column of strings");
+            d.NullCount = fb.Read<int64_t>(nodes + 8);
+            if (fb.Read<int64_t>(nodes) != d.Rows || d.NullCount < 0 || d.NullCount > d.Rows) return Status::Invalid("damaged DictionaryBatch field node");
+            d.BodyOffset = bodyPos;
+            d.BodyLength = bodyLength;
+            IpcBuffer* dst[3] = {&d.Validity, &d.Values, &d.Data};
+            for (int k = 0; k < 3; ++k) {
+                dst[k]->Offset = fb.Read<int64_t>(buffers + 16 * size_t(k));
+                dst[k]->Length = fb.Read<int64_t>(buffers + 16 * size_t(k) + 8);
+                if (!fb.Ok() || dst[k]->Offset < 0 || dst[k]->Length < 0 || dst[k]->Offset > bodyLength || dst[k]->Length > bodyLength - dst[k]->Offset) {
+                    return Status::Invalid("a DictionaryBatch buffer runs past its body");
+                }
+            }
+            bool replaced = false;
+            for (IpcDictionary& have : out.Dicts) {
+                if (have.Id == d.Id) {
+                    have = d;  // (a later dictionary of the same id replaces the earlier one)
+                    replaced = true;
+                }
+            }
+            if (!replaced) out.Dicts.push_back(d);
+            pos = bodyPos + size_t(bodyLength);
+            continue;
+        }
         if (headerType != FB_RecordBatch) return Status::Invalid("unexpected IPC message type " + std::to_string(int(headerType)));
         if (!haveSchema) return Status::Invalid("a RecordBatch message without a schema: give the schema of the column chunk");
         out.Rows = fb.Scalar<int64_t>(header, 0, 0);
@@ -233,7 +292,15 @@ Status ParseIpcBlob(const uint8_t* blob, size_t size, const std::vector<FieldDes
             col.NullCount = fb.Read<int64_t>(nodes + 16 * size_t(i) + 8);
             if (!fb.Ok() || col.Length != out.Rows || col.NullCount < 0 || col.NullCount > col.Length) return Status::Invalid("damaged RecordBatch field node");
             if (!nextBuffer(col.Validity) || !nextBuffer(col.Values)) return Status::Invalid("the RecordBatch lists too few buffers");
-            if (IsStringLike(col.Field.Type) && !nextBuffer(col.Data)) return Status::Invalid("the RecordBatch lists too few buffers");
+            col.DictId = encoding[i].first;
+            col.IndexType = encoding[i].second;
+            if (col.DictId >= 0) {
+                bool have = false;
+                for (const IpcDictionary& d : out.Dicts) have = have || d.Id == col.DictId;
+                if (!have) return Status::Invalid("column '" + col.Field.Name + "' refers to a dictionary the blob does not carry");
+            } else if (IsStringLike(col.Field.Type) && !nextBuffer(col.Data)) {
+                return Status::Invalid("the RecordBatch lists too few buffers");
+            }
             out.Columns.push_back(col);
         }
         if (b != nbuffers) return Status::Invalid("the RecordBatch lists more buffers than its columns have");

@@ -1,7 +1,9 @@
 // Arrow IPC messages as the column shard stores and ships them: the layout half of
 // NArrow::NSerialization::TNativeSerializer::DoDeserialize (ydb/core/formats/arrow/serializer/native.cpp:18-81).
 //
-// A blob is either a whole IPC stream (Schema message, RecordBatch message, end marker: DoSerializeFull, :42-58) or a
+// A blob is either a whole IPC stream (Schema message, DictionaryBatch messages for dictionary-encoded columns --
+// what the dictionary transformer of ydb/core/formats/arrow/transformer/dictionary.cpp:5-7 produces --, RecordBatch
+// message, end marker: DoSerializeFull, :42-58) or a
 // lone RecordBatch message whose schema the reader already has (DoSerializePayload, :83-103).  Each message is
 // [0xFFFFFFFF][int32 metadata size][flatbuffer Message][padding][body]; the RecordBatch metadata lists one FieldNode
 // {length, null_count} per column and one {offset, length} per buffer of the body, and may name a body compression
@@ -33,6 +35,22 @@ struct IpcColumn {
     int64_t Length = 0;
     int64_t NullCount = 0;
     IpcBuffer Validity, Values, Data;  // Values: fixed-width values, boolean bits or int32 offsets; Data: string bytes
+    // A dictionary-encoded column (the schema's field carries a DictionaryEncoding): Field.Type is the type of the
+    // dictionary's values, Values holds the codes of IndexType, there is no Data buffer; the values come with the
+    // DictionaryBatch message of the same id (IpcBatch::Dicts).
+    int64_t DictId = -1;
+    int32_t IndexType = T_NONE;
+};
+
+// A DictionaryBatch message: one column of values (strings here) with a body of its own.
+struct IpcDictionary {
+    int64_t Id = 0;
+    int64_t Rows = 0;
+    int64_t NullCount = 0;
+    int32_t Codec = IPC_RAW;
+    size_t BodyOffset = 0;
+    int64_t BodyLength = 0;
+    IpcBuffer Validity, Values, Data;  // Values: int32 offsets
 };
 
 struct IpcBatch {
@@ -41,6 +59,7 @@ struct IpcBatch {
     size_t BodyOffset = 0;   // of the RecordBatch message's body inside the blob
     int64_t BodyLength = 0;
     std::vector<IpcColumn> Columns;
+    std::vector<IpcDictionary> Dicts;  // the dictionaries the columns refer to, one per id (the last one sent)
 };
 
 // Parses `blob`.  `schema` (may be empty) is used when the blob is a lone RecordBatch message; a blob that carries its
