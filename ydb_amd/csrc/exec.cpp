@@ -172,6 +172,12 @@ Executor::Executor(int device) : Device(device) {
     if (cfgErr != hipSuccess) std::fprintf(stderr, "ydb_ssa_hip: cannot raise the LDS limit of the scan kernels: %s\n", hipGetErrorString(cfgErr));
     StatusWord = Buffer::Alloc(256);
     if (StatusWord) (void)hipMemset(StatusWord->Ptr, 0, 256);
+    void* pinned = nullptr;
+    if (hipHostMalloc(&pinned, kHostWords * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) {
+        HostWords = static_cast<int32_t*>(pinned);
+    } else {
+        (void)hipGetLastError();  // (the pageable paths below still work)
+    }
     hipError_t scratchErr = hipSuccess;
     NoAllocScratch = NoAllocScratchFor(device, &scratchErr);
     if (!NoAllocScratch) std::fprintf(stderr, "ydb_ssa_hip: no static scratch buffer on device %d: %s\n", device, hipGetErrorString(scratchErr));
@@ -184,6 +190,7 @@ Executor::~Executor() {
     if (EvTuneA) (void)hipEventDestroy(EvTuneA);
     if (EvTuneB) (void)hipEventDestroy(EvTuneB);
     if (StreamHandle) (void)hipStreamDestroy(StreamHandle);
+    if (HostWords) (void)hipHostFree(HostWords);
 }
 
 Status Executor::Sync() {
@@ -211,8 +218,14 @@ Status Executor::CheckScanStatus(bool* tableFull, bool* notUniform) {
     uint32_t st = 0;
     if (tableFull) *tableFull = false;
     if (notUniform) *notUniform = false;
-    SSA_HIP(hipMemcpyAsync(&st, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
-    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    if (HostWords) {
+        SSA_HIP(hipMemcpyAsync(HostWords, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        st = uint32_t(HostWords[0]);
+    } else {
+        SSA_HIP(hipMemcpyAsync(&st, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+    }
     if (st == 0) return Status::OK();
     SSA_HIP(hipMemsetAsync(StatusWord->Ptr, 0, sizeof(st), StreamHandle));
     if ((st & SCAN_NOT_UNIFORM) && notUniform) {  // the scan's results are void: the caller runs the step another way
@@ -1122,9 +1135,10 @@ Status Executor::RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, Bu
     SSA_HIP(LaunchTileScan(static_cast<const uint32_t*>(tileCounts->Ptr), ntiles, static_cast<int64_t*>(tileOffsets->Ptr),
                            static_cast<int64_t*>(total->Ptr), StreamHandle));
     int64_t sel = 0;
-    SSA_HIP(hipMemcpyAsync(&sel, total->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    int64_t* selAt = HostWords ? reinterpret_cast<int64_t*>(HostWords + 8) : &sel;  // (pinned: no staging copy)
+    SSA_HIP(hipMemcpyAsync(selAt, total->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
     SSA_RETURN_NOT_OK(CheckScanStatus());
-    selected = sel;
+    selected = *selAt;
     return Status::OK();
 }
 
@@ -1207,8 +1221,11 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
     uint8_t* dvalid = reinterpret_cast<uint8_t*>(dv + kMaxAggs);
     SSA_HIP(LaunchNoKeyFinalize(sink, cfg.grid, dv, dvalid, StreamHandle));
     uint64_t hv[kMaxAggs + 2] = {0};
-    SSA_HIP(hipMemcpyAsync(hv, outVals->Ptr, kMaxAggs * 8 + kMaxAggs, hipMemcpyDeviceToHost, StreamHandle));
+    static_assert(16 * 4 + kMaxAggs * 9 <= kHostWords * 4, "the key-less results fit the pinned words behind the status and count");
+    void* hvAt = HostWords ? static_cast<void*>(HostWords + 16) : static_cast<void*>(hv);  // (pinned: no staging copy)
+    SSA_HIP(hipMemcpyAsync(hvAt, outVals->Ptr, kMaxAggs * 8 + kMaxAggs, hipMemcpyDeviceToHost, StreamHandle));
     SSA_RETURN_NOT_OK(CheckScanStatus());
+    if (HostWords) std::memcpy(hv, hvAt, kMaxAggs * 8 + kMaxAggs);
     const uint8_t* hvalid = reinterpret_cast<const uint8_t*>(hv + kMaxAggs);
 
     // One output row; columns follow plan.Outs (aggregates in GroupBy order unless a projection reorders them).
@@ -1478,15 +1495,30 @@ Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan,
     // first, second and last offset of every such column: the strings can only all have one length when
     // offsets[rows] - offsets[0] == rows * (offsets[1] - offsets[0])
     std::vector<int32_t> probe(rewrites.size() * 3, 0);
+    ProbeWords words{};
     for (size_t i = 0; i < rewrites.size(); ++i) {
         const Column& col = in.Cols[size_t(rewrites[i].Column)];
         if (!col.Values || !col.Chars) return Status::OK();
         const int32_t* offs = static_cast<const int32_t*>(col.ValuesPtr());
         if (reinterpret_cast<uintptr_t>(offs) & 15) return Status::OK();
-        SSA_HIP(hipMemcpyAsync(&probe[3 * i], offs, 8, hipMemcpyDeviceToHost, StreamHandle));
-        SSA_HIP(hipMemcpyAsync(&probe[3 * i + 2], offs + in.Rows, 4, hipMemcpyDeviceToHost, StreamHandle));
+        words.addr[3 * i] = offs;
+        words.addr[3 * i + 1] = offs + 1;
+        words.addr[3 * i + 2] = offs + in.Rows;
     }
-    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    if (HostWords && probe.size() <= size_t(kMaxProbeWords) && probe.size() <= size_t(kHostWords)) {
+        // one launch that reads them all into pinned memory (a copy per word into pageable memory is a round trip each)
+        words.n = int32_t(probe.size());
+        words.out = HostWords;
+        SSA_HIP(LaunchProbeI32(words, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        for (size_t i = 0; i < probe.size(); ++i) probe[i] = HostWords[i];
+    } else {
+        for (size_t i = 0; i < rewrites.size(); ++i) {
+            SSA_HIP(hipMemcpyAsync(&probe[3 * i], words.addr[3 * i], 8, hipMemcpyDeviceToHost, StreamHandle));
+            SSA_HIP(hipMemcpyAsync(&probe[3 * i + 2], words.addr[3 * i + 2], 4, hipMemcpyDeviceToHost, StreamHandle));
+        }
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+    }
     for (size_t i = 0; i < rewrites.size(); ++i) {
         const int64_t first = probe[3 * i], len = int64_t(probe[3 * i + 1]) - first, last = probe[3 * i + 2];
         if (first < 0 || (len != 1 && len != 2 && len != 4 && len != 8) || last - first != len * in.Rows) return Status::OK();
@@ -1972,6 +2004,30 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
     }
     uint64_t totalCap = 0;
+    // Groups per tile of table slots, scanned: where each tile's groups go in the output, and how many there are (the
+    // count arrives with the next synchronisation of the stream).
+    int64_t ntilesT = 0;
+    BufferPtr tileCounts, tileOffsets, counter;
+    int64_t ngroups = 0;
+    int64_t* ngroupsAt = HostWords ? reinterpret_cast<int64_t*>(HostWords + 8) : &ngroups;  // (pinned: no staging copy)
+    bool counted = false;
+    auto countGroups = [&]() -> Status {
+        ntilesT = int64_t(totalCap / kTileRows);
+        tileCounts = Buffer::Alloc(size_t(ntilesT) * 4 + 64);
+        tileOffsets = Buffer::Alloc(size_t(ntilesT + 1 + (ntilesT + 4095) / 4096 + 2) * 8 + 64);
+        counter = Buffer::Alloc(256);
+        if (!tileCounts || !tileOffsets || !counter) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchKeyedTileCount(sink.t_key_lo, totalCap, static_cast<uint32_t*>(tileCounts->Ptr), StreamHandle));
+        SSA_HIP(LaunchTileScan(static_cast<const uint32_t*>(tileCounts->Ptr), ntilesT, static_cast<int64_t*>(tileOffsets->Ptr),
+                               static_cast<int64_t*>(counter->Ptr), StreamHandle));
+        SSA_HIP(hipMemcpyAsync(ngroupsAt, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+        if (many) {  // where each slice's groups begin: the offsets of the first tile of each table
+            many->GroupStart.assign(nslices + 1, 0);
+            const size_t tilesPerSlice = size_t(ntilesT) / nslices;
+            SSA_HIP(hipMemcpy2DAsync(many->GroupStart.data(), 8, tileOffsets->Ptr, tilesPerSlice * 8, 8, nslices, hipMemcpyDeviceToHost, StreamHandle));
+        }
+        return Status::OK();
+    };
     for (;;) {
         totalCap = cap * nslices;  // every slice has a table of its own, one after the other
         tLo = Buffer::Alloc(totalCap * 8);
@@ -2084,6 +2140,13 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             std::fprintf(stderr, "phases: stage %llu vm %llu keys %llu (exact packing %llu) upsert %llu hot %llu table %llu loop %llu\n", t[0], t[1],
                          t[2] + t[6], t[6], t[3], t[4], t[5], t[7]);
         }
+        // A small table is counted right behind the scan: status and group count then come back with one synchronisation
+        // instead of two (an apply of a shard-sized batch is made of little else).
+        counted = false;
+        if (!timedRun && !deferNow && !deferTimed && totalCap <= (uint64_t(1) << 16)) {
+            SSA_RETURN_NOT_OK(countGroups());
+            counted = true;
+        }
         bool tableFull = false;
         SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull, notUniform));
         if (*notUniform) return Status::OK();
@@ -2119,24 +2182,12 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         cap = std::min<uint64_t>(cap * 16, maxCap);
     }
 
-    // groups per tile of table slots, scanned: where each tile's groups go in the output
     cap = totalCap;  // (from here on the tables of all slices are one table: its slots in order are the slices in order)
-    const int64_t ntilesT = int64_t(cap / kTileRows);
-    BufferPtr tileCounts = Buffer::Alloc(size_t(ntilesT) * 4 + 64);
-    BufferPtr tileOffsets = Buffer::Alloc(size_t(ntilesT + 1 + (ntilesT + 4095) / 4096 + 2) * 8 + 64);
-    BufferPtr counter = Buffer::Alloc(256);
-    if (!tileCounts || !tileOffsets || !counter) return Status::Hip("out of device memory");
-    SSA_HIP(LaunchKeyedTileCount(sink.t_key_lo, cap, static_cast<uint32_t*>(tileCounts->Ptr), StreamHandle));
-    SSA_HIP(LaunchTileScan(static_cast<const uint32_t*>(tileCounts->Ptr), ntilesT, static_cast<int64_t*>(tileOffsets->Ptr),
-                           static_cast<int64_t*>(counter->Ptr), StreamHandle));
-    int64_t ngroups = 0;
-    SSA_HIP(hipMemcpyAsync(&ngroups, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
-    if (many) {  // where each slice's groups begin: the offsets of the first tile of each table
-        many->GroupStart.assign(nslices + 1, 0);
-        const size_t tilesPerSlice = size_t(ntilesT) / nslices;
-        SSA_HIP(hipMemcpy2DAsync(many->GroupStart.data(), 8, tileOffsets->Ptr, tilesPerSlice * 8, 8, nslices, hipMemcpyDeviceToHost, StreamHandle));
+    if (!counted) {
+        SSA_RETURN_NOT_OK(countGroups());
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
     }
-    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    ngroups = *ngroupsAt;
     int64_t maxGroups = ngroups;
     if (many) {
         many->GroupStart[nslices] = ngroups;

@@ -148,6 +148,10 @@ struct ManySlices {
 
 class Executor {
 public:
+    // A few words of pinned host memory: where small results (a scan's status, a group count, probed offsets) land
+    // without the staging copy an asynchronous copy into pageable memory takes.
+    int32_t* HostWords = nullptr;
+    static constexpr int kHostWords = 64;
     explicit Executor(int device);
     ~Executor();
 

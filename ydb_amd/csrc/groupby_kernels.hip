@@ -520,6 +520,10 @@ __global__ __launch_bounds__(kBlock) void IotaI32Kernel(int32_t* out, int64_t n,
 }
 
 // out[i] = *addrs[i]: a few words from many places (the first and last offsets of the string columns of many slices)
+__global__ __launch_bounds__(64) void ProbeI32Kernel(const ProbeWords p) {
+    if (int(threadIdx.x) < p.n) p.out[threadIdx.x] = *p.addr[threadIdx.x];
+}
+
 __global__ __launch_bounds__(kBlock) void GatherI32AtKernel(const int32_t* const* addrs, int64_t n, int32_t* out) {
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kBlock) out[i] = *addrs[i];
 }
@@ -639,6 +643,12 @@ hipError_t LaunchGatherFixed(const void* src, const uint8_t* srcValid, int64_t s
         default: return hipErrorInvalidValue;
     }
 #undef SSA_GATHER
+    return hipGetLastError();
+}
+
+hipError_t LaunchProbeI32(const ProbeWords& p, hipStream_t st) {
+    if (p.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ProbeI32Kernel, dim3(1), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 

@@ -239,6 +239,15 @@ hipError_t LaunchGatherValidity(const uint8_t* src_valid, int64_t src_valid_off,
 hipError_t LaunchIotaI32(int32_t* out, int64_t n, int32_t step, hipStream_t st);
 // out[i] = *addrs[i] (addrs: device array of device addresses)
 hipError_t LaunchGatherI32At(const int32_t* const* addrs, int64_t n, int32_t* out, hipStream_t st);
+// The same for a handful of addresses, passed with the launch: out[i] = *addrs[i], i < n <= kMaxProbeWords.  `out` may be
+// pinned host memory (the caller synchronises the stream and reads it: no copy of its own).
+constexpr int kMaxProbeWords = 24;
+struct ProbeWords {
+    const int32_t* addr[kMaxProbeWords];
+    int32_t n;
+    int32_t* out;
+};
+hipError_t LaunchProbeI32(const ProbeWords& p, hipStream_t st);
 hipError_t LaunchGatherStringLens(const int32_t* offsets, const uint64_t* rows, int64_t n, int32_t* out_lens, hipStream_t st);
 hipError_t LaunchGatherStringBytes(const int32_t* offsets, const uint8_t* chars, const uint64_t* rows, int64_t n,
                                    const int32_t* new_offsets, uint8_t* out_chars, hipStream_t st);
