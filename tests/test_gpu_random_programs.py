@@ -237,7 +237,15 @@ def test_random_group_bys(seed, monkeypatch):
     n = int(rng.choice([1, 64, 1025, 4097, 50_021]))
     batch = make_batch(rng, n, specials=seed % 2 == 1)   # every other seed: NaN, infinities and signed zeros in the floats
     program, keys, fsums = random_group_by(rng, int(rng.integers(0, 6)))
-    for jit in ("0", "1"):
+    # the generic kernels, the kernel built for the step, and that kernel run the third way (the rows that passed the
+    # filter taken one by one: where a step does not qualify for it the second way runs again)
+    for jit, way in (("0", None), ("1", None), ("1", "2")):
+        if way is not None and (not keys or seed % 2):
+            continue
+        if way is None:
+            monkeypatch.delenv("SSA_KEYED_HOT", raising=False)
+        else:
+            monkeypatch.setenv("SSA_KEYED_HOT", way)
         got, gerr, exp, oerr = run_both(program, batch, monkeypatch, jit)
         if oerr is not None:
             assert gerr is not None, (jit, oerr)
