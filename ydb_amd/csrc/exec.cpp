@@ -2365,12 +2365,44 @@ Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPt
     for (const Column& c : in->Cols) {
         if (c.Dict) return ApplyStepDict(step, in, out);
     }
-    return ApplyStepPlain(step, in, out);
+    return ApplyStepPlain(step, in, out, /*stable=*/true);
 }
 
-Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out) {
-    StepPlan plan;
-    SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FULL, plan, ForceSerializedKeys));
+Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable) {
+    std::shared_ptr<const StepPlan> kept;
+    std::string signature;
+    if (stable) {
+        // everything of the input the planner looks at: names, types, which columns carry nulls, decimal parameters
+        // (a scalar column's value takes part in constant folding: such batches are planned every time)
+        signature.reserve(32 + 24 * in->Cols.size());
+        const void* address = &step;
+        signature.append(reinterpret_cast<const char*>(&address), sizeof(address));
+        signature.push_back(ForceSerializedKeys ? 'S' : 'N');
+        for (const Column& c : in->Cols) {
+            if (c.Field.IsScalar) {
+                stable = false;
+                break;
+            }
+            signature.append(c.Field.Name);
+            signature.push_back('\0');
+            const int32_t words[4] = {c.Field.Type, c.Field.Nullable ? 1 : 0, c.Field.Precision, c.Field.Scale};
+            signature.append(reinterpret_cast<const char*>(words), sizeof(words));
+        }
+        if (stable) {
+            auto it = PlanCache.find(signature);
+            if (it != PlanCache.end()) kept = it->second;
+        }
+    }
+    if (!kept) {
+        auto fresh = std::make_shared<StepPlan>();
+        SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FULL, *fresh, ForceSerializedKeys));
+        kept = fresh;
+        if (stable) {
+            if (PlanCache.size() >= 64) PlanCache.clear();  // (a program sees a handful of schemas)
+            PlanCache[signature] = kept;
+        }
+    }
+    const StepPlan& plan = *kept;
     switch (plan.Kind) {
         case StepPlan::PASS_THROUGH:
         case StepPlan::PROJECT:

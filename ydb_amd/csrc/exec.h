@@ -222,7 +222,10 @@ public:
 
 private:
     Status ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
-    Status ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
+    // `stable`: `step` is one of the program's own steps (it lives as long as the executor does and never changes), so
+    // its plan for this input schema may be kept (PlanCache) -- planning is a tenth of an apply of a shard-sized batch.
+    Status ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable = false);
+    std::map<std::string, std::shared_ptr<const StepPlan>> PlanCache;  // (step address, input schema) -> plan
     // -- dictionary-encoded columns (dict.cpp) ---------------------------------------------------------------
     Status ApplyStepDict(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
     Status LowerDictStep(const TProgramStep& step, const BatchPtr& in, bool filterOnly, DictLowering& lowering);
