@@ -206,9 +206,10 @@ void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_
 /* Process-wide counter: GROUP BY scans that applied the rows missing the workgroups' own tables region by region of the
  * table in HBM (groupings of a million groups and more take this way; SSA_KEYED_PARTITION=0 / 1 forbids / forces it). */
 void ssa_keyed_stats(int64_t* scans_applied_by_region);
-/* Process-wide counter: GROUP BY scans run by a kernel that compacts every tile to the rows that passed the step's
- * filters before it aggregates them (steps behind a selective filter whose keys and aggregate arguments are plain
- * columns without nulls; timed against the other ways on the step's first large scans, SSA_KEYED_HOT=2 forces it). */
+/* Process-wide counter: GROUP BY scans run by the kernel that deals the rows that passed the step's filters out evenly
+ * over the lanes of a wave and aggregates them one by one (steps behind a selective filter whose keys and aggregate
+ * arguments are plain columns without nulls; timed against the other ways on the step's first large scans,
+ * SSA_KEYED_HOT=2 forces it). */
 void ssa_keyed_compact_stats(int64_t* scans_with_compacted_tiles);
 /* Download a batch into Arrow C Data structures. */
 int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, struct ArrowArray* out,

@@ -1,4 +1,4 @@
-"""GROUP BY behind a filter by the kernel that compacts every tile to the rows that passed before it aggregates them
+"""GROUP BY behind a filter by the kernel that takes the rows that passed the filter one by one
 (SSA_KEYED_HOT=2 forces that kernel wherever a step qualifies; by itself it is chosen by timing on large scans).  Results
 must equal the CPU oracle's and those of the kernel that does not compact."""
 import ctypes

@@ -1864,8 +1864,9 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             sink.hot_kind[k] = a.kind == AGG_SUM_F ? HOT_SUM_F64 : HOT_SUM_I64;
             sink.hot_off[k] = off;
         }
-        // The tiles a compacting kernel would have to compact: every operand of the sink a staged column without a
-        // validity bitmap (or a constant, or none), eight distinct tiles at most.  compact_n stays 0 otherwise.
+        // A step qualifies for the kernel that takes the rows behind the filter one by one when every operand of the sink
+        // is a staged column without a validity bitmap (or a constant, or none): that kernel reads them from the staged
+        // tiles at the row's index.  The tiles are listed (eight distinct ones at most); compact_n stays 0 otherwise.
         sink.compact_n = 0;
         if (plan.HasFilter && !hashed && !many) {
             bool can = true;
@@ -2159,7 +2160,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                     hint.HotChoice = hint.MsPerRow[1] <= hint.MsPerRow[0] ? 1 : 0;
                     if (third && hint.MsPerRow[2] < hint.MsPerRow[hint.HotChoice]) hint.HotChoice = 2;
                     if (std::getenv("SSA_DEBUG_PLAN")) {
-                        std::fprintf(stderr, "keyed: ns per row plain %.4f, register-held groups %.4f, compacted tiles %.4f -> %d\n", 1e6 * hint.MsPerRow[0],
+                        std::fprintf(stderr, "keyed: ns per row plain %.4f, register-held groups %.4f, rows one by one %.4f -> %d\n", 1e6 * hint.MsPerRow[0],
                                      1e6 * hint.MsPerRow[1], 1e6 * hint.MsPerRow[2], hint.HotChoice);
                     }
                 }

@@ -56,7 +56,7 @@ struct DictLowering;
 extern std::atomic<int64_t> gDictStepsOnCodes, gDictColumnsDecoded;
 // ... sets of slices (of one schema, under one step) that ApplyProgramMany scanned with one launch; sets it ran slice by slice.
 extern std::atomic<int64_t> gManyStepsOneLaunch, gManyStepsPerSlice;
-extern std::atomic<int64_t> gKeyedStepsCompacted;  // keyed scans run by a kernel that compacts its tiles behind the filter
+extern std::atomic<int64_t> gKeyedStepsCompacted;  // keyed scans run the third way: the rows behind the filter dealt out over the lanes, taken one by one
 extern std::atomic<int64_t> gKeyedStepsDeferred;  // keyed scans whose level-2 updates were applied region by region
 
 struct Column {
@@ -286,10 +286,10 @@ private:
         // The register-held groups pay when a few groups take most rows (TPC-H Q1: 2.7x) and cost registers and per-row
         // work when they do not (a selective filter in front of thirty groups: 0.6x).  A kernel built for the step is
         // timed once each way on its first large scans and the faster way is kept.
-        // Behind a selective filter a third way wins: no register-held groups, every tile compacted to the rows that passed
-        // before the sink looks at it (a 3 % filter in front of thirty groups: 2x over the plain way); timed like the others
-        // when the step qualifies (KeyedSink.compact_n).
-        int HotChoice = -1;      // -1 undecided, 0 off, 1 on, 2 off with compacted tiles
+        // Behind a selective filter a third way wins: no register-held groups, the rows that passed dealt out evenly over
+        // the lanes of the wave and taken one by one (a 3 % filter in front of thirty groups: 2x over the plain way);
+        // timed like the others when the step qualifies (KeyedSink.compact_n).
+        int HotChoice = -1;      // -1 undecided, 0 off, 1 on, 2 off with the rows behind the filter one by one
         bool UniformKeysFailed = false;  // a batch of this step had string keys of differing lengths: no further attempts
         double MsPerRow[3] = {0, 0, 0};  // by way, as timed
         // Groupings of a million groups and more: records sorted by table region and applied inside LDS, or every row
