@@ -1843,6 +1843,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
         sink.two_words = twoWords;
         sink.hashed = hashed;
+        sink.rec_raw64 = (!hashed && keyBits == 64) ? 1 : 0;
         sink.lds_cap = L;
         sink.lds_rep = R;
             for (int k = 0; k < kHotAggs && k < naggs; ++k) {
@@ -2073,6 +2074,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 image.abort_check = 0;
                 image.acc_stride = 0;
                 image.rec_lo = image.rec_hi = image.rec_val = nullptr;
+                image.rec_present = nullptr;
                 image.rec_mask = nullptr;
                 std::string defines = std::string("#define SSA_SPEC_U ") + std::to_string(specRows) + "\n#define SSA_SPEC_HASHED " +
                                       (hashed ? "1" : "0") + "\n#define SSA_SPEC_SLICES " + (many ? "1" : "0") + "\n";
@@ -2100,13 +2102,14 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 const size_t n = size_t(in.Rows);
                 if (!recLo) {
                     recLo = Buffer::Alloc(n * 8);
-                    recHi = Buffer::Alloc(twoWords ? n * 8 : 64);
+                    recHi = Buffer::Alloc(twoWords && !ssink.rec_raw64 ? n * 8 : (ssink.rec_raw64 ? (n / 64 + 2) * 8 : 64));  // (or the bitmap of the rows with records)
                     recVal = Buffer::Alloc(size_t(nvals) * n * 8 + 64);
                     recMask = Buffer::Alloc(needMask ? n * 4 : 64);
                     if (!recLo || !recHi || !recVal || !recMask) return Status::Hip("out of device memory");
                 }
                 ssink.rec_lo = static_cast<uint64_t*>(recLo->Ptr);
-                ssink.rec_hi = static_cast<uint64_t*>(recHi->Ptr);
+                ssink.rec_hi = ssink.rec_raw64 ? nullptr : static_cast<uint64_t*>(recHi->Ptr);
+                ssink.rec_present = ssink.rec_raw64 ? static_cast<uint64_t*>(recHi->Ptr) : nullptr;
                 ssink.rec_val = static_cast<uint64_t*>(recVal->Ptr);
                 ssink.rec_mask = needMask ? static_cast<uint32_t*>(recMask->Ptr) : nullptr;
             }

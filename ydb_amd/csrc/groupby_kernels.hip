@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void RadixCountKernel(const RadixArgs) {
     __syncthreads();
     uint32_t begin, end;
     RadixChunk(a, begin, end);
-    const bool two = a.two_words != 0;
+    const bool two = a.two_words != 0, raw = a.raw64 != 0;
     for (uint32_t r0 = begin; r0 < end; r0 += kRadixTile) {
         // (loads without conditions, so that all of them are in flight together: a row past the end reads the last one)
         uint64_t lo[kRadixPerThread], hi[kRadixPerThread];
@@ -71,11 +71,24 @@ __global__ __launch_bounds__(kBlock) void RadixCountKernel(const RadixArgs) {
             lo[u] = a.src.lo[r < end ? r : end - 1];
             hi[u] = 0;
         }
-        if (two) {
+        if (two && !raw) {
 #pragma unroll
             for (int u = 0; u < kRadixPerThread; ++u) {
                 const uint32_t r = r0 + u * kBlock + threadIdx.x;
                 hi[u] = a.src.hi[r < end ? r : end - 1];
+            }
+        }
+        if (raw) {
+            // 64-bit keys in one word: the table's two words from it; which indices hold a record at all, the first
+            // round reads from the bitmap (64 consecutive records are one wave's load: one word of it)
+#pragma unroll
+            for (int u = 0; u < kRadixPerThread; ++u) {
+                const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                const bool there = r < end && (a.present == nullptr || ((a.present[r >> 6] >> (r & 63u)) & 1ull) != 0);
+                uint64_t l, h;
+                RawKeyWords(lo[u], l, h);
+                lo[u] = there ? l : kEmpty;
+                hi[u] = h;
             }
         }
 #pragma unroll
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
     __shared__ uint16_t lOrder[kRadixTile];
     __shared__ uint8_t lDigit[kRadixTile];
     const int seg = blockIdx.x / a.chunks;
-    const bool more = a.two_words != 0 || a.dst.mask != nullptr || a.dst.row != nullptr || a.nvals > 0;  // more than the lo word to move
+    const bool more = (a.two_words != 0 && a.raw64 == 0) || a.dst.mask != nullptr || a.dst.row != nullptr || a.nvals > 0;  // more than the lo word to move
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     lCount[threadIdx.x] = 0;
     if (int(threadIdx.x) < a.ndigits) {
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
     __syncthreads();
     uint32_t begin, end;
     RadixChunk(a, begin, end);
-    const bool two = a.two_words != 0;
+    const bool two = a.two_words != 0, raw = a.raw64 != 0;
     for (uint32_t r0 = begin; r0 < end; r0 += kRadixTile) {
         // (loads without conditions, so that all of them are in flight together: a row past the end reads the last one)
         uint64_t lo[kRadixPerThread], hi[kRadixPerThread];
@@ -176,11 +189,24 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
             lo[u] = a.src.lo[r < end ? r : end - 1];
             hi[u] = 0;
         }
-        if (two) {
+        if (two && !raw) {
 #pragma unroll
             for (int u = 0; u < kRadixPerThread; ++u) {
                 const uint32_t r = r0 + u * kBlock + threadIdx.x;
                 hi[u] = a.src.hi[r < end ? r : end - 1];
+            }
+        }
+        if (raw) {
+            // 64-bit keys in one word: the table's two words from it; which indices hold a record at all, the first
+            // round reads from the bitmap (64 consecutive records are one wave's load: one word of it)
+#pragma unroll
+            for (int u = 0; u < kRadixPerThread; ++u) {
+                const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                const bool there = r < end && (a.present == nullptr || ((a.present[r >> 6] >> (r & 63u)) & 1ull) != 0);
+                uint64_t l, h;
+                RawKeyWords(lo[u], l, h);
+                lo[u] = there ? l : kEmpty;
+                hi[u] = h;
             }
         }
 #pragma unroll
@@ -224,10 +250,11 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         for (uint32_t p = threadIdx.x; p < n; p += kBlock) {
             const uint32_t d = lDigit[p];
             const uint32_t at = lCursor[d] + (p - lBase[d]);
-            a.dst.lo[at] = lSortedLo[p];
-            if (!more) continue;
             const uint32_t r = r0 + lOrder[p];
-            if (two) a.dst.hi[at] = a.src.hi[r];
+            // (64-bit keys in one word: the word as it came, read once more -- from the cache)
+            a.dst.lo[at] = raw ? a.src.lo[r] : lSortedLo[p];
+            if (!more) continue;
+            if (two && !raw) a.dst.hi[at] = a.src.hi[r];
             if (a.dst.mask != nullptr) a.dst.mask[at] = a.src.mask[r];
             if (a.dst.row != nullptr) a.dst.row[at] = a.src.row != nullptr ? a.src.row[r] : r;
             for (int v = 0; v < a.nvals; ++v) a.dst.val[size_t(v) * size_t(a.stride) + at] = a.src.val[size_t(v) * size_t(a.stride) + r];
@@ -290,9 +317,13 @@ __global__ __launch_bounds__(kBlock) void RegionApplyKernel(const RegionApplyArg
               his[j] = 0;
               masks[j] = ~0u;
           }
-          if (two) {
+          if (two && !s.rec_raw64) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) his[j] = a.rec.hi[i0 + j * kBlock < last ? i0 + j * kBlock : i0];
+          }
+          if (s.rec_raw64) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) RawKeyWords(los[j], los[j], his[j]);
           }
           if (a.rec.mask != nullptr) {
 #pragma unroll

@@ -82,6 +82,13 @@ struct KeyedSink {
     uint64_t* rec_hi;            // [nrows] key hi word (two-word keys)
     uint64_t* rec_val;           // [nvals][nrows] operand of every accumulator that is no counter, in accumulator order
     uint32_t* rec_mask;          // [nrows] bit k: the row updates accumulator k (nullptr: every record updates all of them)
+    // Keys of exactly 64 bits (one int64 column: ClickBench's UserID) need the second key word for one bit.  Their records
+    // carry the 64 packed bits in rec_lo alone (rec_raw64; every value is a key then, so the rows that left a record are
+    // marked in a bitmap of their own, bit row & 63 of word row >> 6); the passes of the sort move half the bytes, and
+    // the table's two words are made from the 64 bits where they are needed (RawKeyWords).
+    int32_t rec_raw64;
+    int32_t pad2_;
+    uint64_t* rec_present;
     // A scan whose number of groups is not known yet (or is large) may find level 2 too small: with this set, the first
     // lane that finds no slot raises SCAN_TABLE_FULL in the status word at once, probe loops and the tile loop look at
     // the word and give up, and the host repeats the step with a larger table after microseconds instead of a whole scan.
@@ -189,13 +196,20 @@ struct RecordSet {
     uint32_t* mask;           // nullptr: every record updates all accumulators
     uint32_t* row;            // the record's row (nullptr where it is not carried: in the scan's output the record's index)
 };
+// The table's key words of a 64-bit key carried as one word (KeyedSink.rec_raw64): what KeyBuilder::Finish makes of it.
+__device__ __forceinline__ void RawKeyWords(uint64_t raw, uint64_t& lo, uint64_t& hi) {
+    lo = raw & 0x7FFFFFFFFFFFFFFFull;
+    hi = raw >> 63;
+}
 // One round of the sort: the records of each segment of `src` (seg_start) to `dst`, ordered by digit inside the segment.
 struct RadixArgs {
     RecordSet src, dst;
     int64_t stride;               // elements between two operand arrays of a record set (the batch's row count)
     int32_t nvals;
     int32_t two_words;
-    int32_t skip_free;            // src.lo may hold ~0: no record at that index
+    int32_t raw64;                // the records carry 64-bit keys in one word (KeyedSink.rec_raw64): no hi arrays
+    const uint64_t* present;      // raw64, first round: bit i says whether index i of src holds a record (nullptr: all do)
+    int32_t skip_free;            // src.lo may hold ~0: no record at that index (not with raw64)
     uint64_t table_mask;
     int32_t region_shift;         // region of a slot = slot >> region_shift
     int32_t digit_shift;          // digit = (region >> digit_shift) & (ndigits - 1)

@@ -663,7 +663,18 @@ __device__ __forceinline__ void ScanKeyedBody() {
             }
             continue;
         }
-        if (m.P == 0) {
+        if (kDefer && s.rec_raw64) {
+            // (the bitmap of the rows that leave records is written by the wave as a whole: no lane leaves the tile early)
+            if (!__any(m.P != 0)) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (m.Row(u) < m.nrows) rs.rec_present[uint64_t(m.Row(u)) >> 6] = 0ull;
+                    }
+                }
+                continue;
+            }
+        } else if (m.P == 0) {
             if (kDefer) {  // no row of the tile leaves a record
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -878,7 +889,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
                     slot[u] = int64_t(seenId[u]);
                     continue;
                 }
-                if (twoWords) rs.rec_hi[uint64_t(m.Row(u))] = kb.hi[u];
+                if (twoWords && !s.rec_raw64) rs.rec_hi[uint64_t(m.Row(u))] = kb.hi[u];
                 slot[u] = kDeferredSlot;
             }
             pending = 0;
@@ -901,7 +912,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 auto sameRows = [&](uint64_t rep) { return SameKeyRows(m.cols, s, row, rep); };
                 if (L > 0) sl = LdsUpsertDense(lLo, lHi, lRep, lDense, lCount, lHotKey, uint32_t(L - 1), h, klo, khi, twoWords, row, ldsProbes, byHash, sameRows);
                 if (kDefer && sl < 0) {
-                    if (twoWords) rs.rec_hi[row] = khi;  // (the lo word: at the end of the tile, for every row)
+                    if (twoWords && !s.rec_raw64) rs.rec_hi[row] = khi;  // (the lo word: at the end of the tile, for every row)
                     sl = kDeferredSlot;
                 } else if (sl < 0) {
                     const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
@@ -1090,7 +1101,16 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 }
             }
         }
-        if (kDefer) {
+        if (kDefer && s.rec_raw64) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool leaves = slot[u] == kDeferredSlot;
+                const uint64_t present = __ballot(leaves);
+                if (m.Row(u) < m.nrows) rs.rec_lo[uint64_t(m.Row(u))] = kb.lo[u] | (kb.hi[u] << 63);  // (Finish() undone)
+                if (lane == 0 && m.Row(u) < m.nrows) rs.rec_present[uint64_t(m.Row(u)) >> 6] = present;
+                if (rs.rec_mask != nullptr && leaves) rs.rec_mask[uint64_t(m.Row(u))] = recMask[u];
+            }
+        } else if (kDefer) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (m.Row(u) < m.nrows) rs.rec_lo[uint64_t(m.Row(u))] = slot[u] == kDeferredSlot ? kb.lo[u] : kEmpty;

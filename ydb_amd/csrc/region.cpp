@@ -44,7 +44,8 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
                      (unsigned long long)regions, (unsigned long long)R, bitsA, bitsB);
     }
 
-    BufferPtr partLo = Buffer::Alloc(n * 8), partHi = Buffer::Alloc(twoWords ? n * 8 : 64);
+    const bool raw64 = sink.rec_raw64 != 0;  // (64-bit keys in one word: no hi arrays)
+    BufferPtr partLo = Buffer::Alloc(n * 8), partHi = Buffer::Alloc(twoWords && !raw64 ? n * 8 : 64);
     BufferPtr partVal = Buffer::Alloc(size_t(nvals) * n * 8 + 64), partMask = Buffer::Alloc(needMask ? n * 4 : 64);
     BufferPtr partRow = Buffer::Alloc(hashed ? n * 4 : 64), recRow = Buffer::Alloc(hashed && bitsB > 0 ? n * 4 : 64);
     if (!partLo || !partHi || !partVal || !partMask || !partRow || !recRow) return Status::Hip("out of device memory");
@@ -60,6 +61,8 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
     ra.stride = rows;
     ra.nvals = nvals;
     ra.two_words = twoWords;
+    ra.raw64 = raw64;
+    ra.present = raw64 ? sink.rec_present : nullptr;
     ra.skip_free = 1;
     ra.table_mask = sink.table_mask;
     ra.region_shift = Log2Of(R);
@@ -86,6 +89,7 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
         rb.src = part;
         rb.dst = back;
         rb.skip_free = 0;
+        rb.present = nullptr;  // (the first round kept the records only)
         rb.digit_shift = 0;
         rb.ndigits = 1 << bitsB;
         rb.nseg = 1 << bitsA;
