@@ -1971,9 +1971,11 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         if (deferWanted && hint.Groups > 0) cap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(hint.Groups) + uint64_t(hint.Groups) / 3), 1024), maxCap);
     }
     BufferPtr recLo, recHi, recVal, recMask;
-    // slots of a region: what one workgroup holds in 48 KB of LDS (SSA_KEYED_REGION: experiments and tests)
+    // slots of a region: what one workgroup holds in 48 KB of LDS (SSA_KEYED_REGION / SSA_KEYED_REGION_KB: experiments and tests)
     int regionSlots = 4096;
-    while (regionSlots > 256 && size_t(regionSlots) * (8 + (twoWords ? 8 : 0) + (hashed ? 8 : 0) + 8 * size_t(naggs) + 4) > 48 * 1024) regionSlots >>= 1;
+    size_t regionLds = 48 * 1024;
+    if (const char* env = std::getenv("SSA_KEYED_REGION_KB")) regionLds = size_t(std::max(8, std::min(64, std::atoi(env)))) * 1024;
+    while (regionSlots > 256 && size_t(regionSlots) * (8 + (twoWords ? 8 : 0) + (hashed ? 8 : 0) + 8 * size_t(naggs) + 4) > regionLds) regionSlots >>= 1;
     if (const char* env = std::getenv("SSA_KEYED_REGION")) {
         const int r = std::atoi(env);
         if (r >= 64 && r <= regionSlots && (r & (r - 1)) == 0) regionSlots = r;

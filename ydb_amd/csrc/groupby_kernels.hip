@@ -301,11 +301,19 @@ __global__ __launch_bounds__(kBlock) void RegionApplyKernel(const RegionApplyArg
                 }
             }
         };
+        // The keys first: nearly all slots are still free (what the table holds before this pass is what the workgroups'
+        // own tables held at the end of the scan), and a free slot's other words are known without reading them.
         load(lLo, s.t_key_lo + slot0);
-        if (two) load(lHi, s.t_key_hi + slot0);
-        if (hashed) load(lRep, s.t_rep_row + slot0);
-        for (int k = 0; k < s.naggs; ++k) load(lAcc + size_t(k) * R, s.t_acc + size_t(k) * s.acc_stride + slot0);
-        for (int i = threadIdx.x; i < R; i += kBlock) lSeen[i] = s.t_seen[slot0 + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < R; i += kBlock) {
+            const bool taken = lLo[i] != kEmpty;
+            if (two) lHi[i] = taken ? s.t_key_hi[slot0 + i] : kUnpublished;
+            if (hashed) lRep[i] = taken ? s.t_rep_row[slot0 + i] : ~0ull;
+            lSeen[i] = taken ? s.t_seen[slot0 + i] : 0u;
+            for (int k = 0; k < s.naggs; ++k) {
+                lAcc[size_t(k) * R + i] = taken ? s.t_acc[size_t(k) * s.acc_stride + slot0 + i] : TableIdentity(s.aggs[k].kind);
+            }
+        }
         __syncthreads();
         for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += 4 * kBlock) {
           uint64_t los[4], his[4];
