@@ -100,3 +100,29 @@ def test_steps_that_do_not_qualify_run_the_other_kernels(monkeypatch):
     compact, plain, oracle = run_both(monkeypatch, res, p, batch, expect_compact=False)
     compare_batches(compact, oracle, key_names=["k"])
     del flt
+
+
+def test_shard_sized_batches_try_every_way_and_settle(monkeypatch):
+    """Batches of a million rows: the step's first applies cycle through the ways of running its kernel until each has
+    been timed on four million rows, then one is kept.  Whatever way runs, the result is the oracle's."""
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    monkeypatch.setenv("SSA_JIT", "1")
+    monkeypatch.delenv("SSA_KEYED_HOT", raising=False)
+    rng = np.random.default_rng(81)
+    n = 1_100_000
+    adv = rng.integers(1, 31, n).astype(np.int16)
+    adv[rng.random(n) >= 0.03] = 0
+    batch = {"adv": adv, "w": rng.integers(0, 2000, n).astype(np.int16)}
+    res = [(1, "adv"), (2, "w")]
+    p = (Program().assign_const(50, "Int32", 0).assign_func(51, F.CMP_NOT_EQUAL, [1, 50]).filter(51)
+         .group_by([Aggregate(100, AGG.COUNT, []), Aggregate(101, AGG.SUM, [2]), Aggregate(102, AGG.MAX, [2])], keys=[1]))
+    exp = ssa_oracle.Oracle(res, p).apply(batch)
+    pc = ProgramContainer()
+    ok, err = pc.Init(res, p)
+    assert ok, err
+    dev = pc.Import(batch)
+    before = compacted_scans()
+    for _ in range(16):
+        compare_batches(pc.Export(pc.ApplyDevice(dev)), exp, key_names=["adv"])
+    assert compacted_scans() - before >= 4  # (the third way was among those timed)

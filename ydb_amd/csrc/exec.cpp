@@ -1989,8 +1989,14 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         const bool canCompact = specCompactTiles > 0 && !deferWanted;
         if (const char* env = std::getenv("SSA_KEYED_HOT")) hint.HotChoice = std::max(0, std::min(2, std::atoi(env)));
         if (hint.HotChoice == 2 && !canCompact) hint.HotChoice = 0;
-        hotMode = hint.HotChoice >= 0 ? hint.HotChoice : (hint.MsPerRow[1] == 0 ? 1 : (hint.MsPerRow[0] == 0 ? 0 : 2));
-        timedWanted = hint.HotChoice < 0 && totalRows >= (int64_t(1) << 22) && (!many || maxRows >= (int64_t(1) << 16));
+        hotMode = hint.HotChoice;
+        if (hotMode < 0) {  // the way with the fewest rows timed so far, in the order 1, 0, 2
+            hotMode = 1;
+            for (int way : {0, 2}) {
+                if ((way != 2 || canCompact) && hint.TunedRows[way] < hint.TunedRows[hotMode]) hotMode = way;
+            }
+        }
+        timedWanted = hint.HotChoice < 0 && totalRows >= (int64_t(1) << 16) && (!many || maxRows >= (int64_t(1) << 16));
         if (hint.HotChoice < 0 && !timedWanted) hotMode = 1;
         if (hotMode == 2 && !canCompact) hotMode = 0;
         // Row by row behind the filter, the per-tile work is what is left to shrink: such a kernel takes 16 rows per thread
@@ -2159,14 +2165,18 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         if (timedRun && !tableFull) {  // (the stream has been synchronised by the status check)
             float ms = 0;
             if (hipEventElapsedTime(&ms, EvTuneA, EvTuneB) == hipSuccess && ms > 0) {
-                hint.MsPerRow[hotMode] = double(ms) / double(in.Rows);
-                const bool third = specCompactTiles > 0 && !deferWanted;  // a compacting way exists
-                if (hint.MsPerRow[1] > 0 && hint.MsPerRow[0] > 0 && (!third || hint.MsPerRow[2] > 0)) {
-                    hint.HotChoice = hint.MsPerRow[1] <= hint.MsPerRow[0] ? 1 : 0;
-                    if (third && hint.MsPerRow[2] < hint.MsPerRow[hint.HotChoice]) hint.HotChoice = 2;
+                hint.TunedMs[hotMode] += double(ms);
+                hint.TunedRows[hotMode] += totalRows;
+                const bool third = specCompactTiles > 0 && !deferWanted;  // the third way exists for this step
+                constexpr int64_t kEnough = int64_t(1) << 22;
+                if (hint.TunedRows[1] >= kEnough && hint.TunedRows[0] >= kEnough && (!third || hint.TunedRows[2] >= kEnough)) {
+                    double perRow[3] = {0, 0, 0};
+                    for (int way = 0; way < 3; ++way) perRow[way] = hint.TunedRows[way] > 0 ? hint.TunedMs[way] / double(hint.TunedRows[way]) : 0;
+                    hint.HotChoice = perRow[1] <= perRow[0] ? 1 : 0;
+                    if (third && perRow[2] < perRow[hint.HotChoice]) hint.HotChoice = 2;
                     if (std::getenv("SSA_DEBUG_PLAN")) {
-                        std::fprintf(stderr, "keyed: ns per row plain %.4f, register-held groups %.4f, rows one by one %.4f -> %d\n", 1e6 * hint.MsPerRow[0],
-                                     1e6 * hint.MsPerRow[1], 1e6 * hint.MsPerRow[2], hint.HotChoice);
+                        std::fprintf(stderr, "keyed: ns per row plain %.4f, register-held groups %.4f, rows one by one %.4f -> %d\n", 1e6 * perRow[0],
+                                     1e6 * perRow[1], 1e6 * perRow[2], hint.HotChoice);
                     }
                 }
             }

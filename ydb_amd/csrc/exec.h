@@ -291,7 +291,10 @@ private:
         // timed like the others when the step qualifies (KeyedSink.compact_n).
         int HotChoice = -1;      // -1 undecided, 0 off, 1 on, 2 off with the rows behind the filter one by one
         bool UniformKeysFailed = false;  // a batch of this step had string keys of differing lengths: no further attempts
-        double MsPerRow[3] = {0, 0, 0};  // by way, as timed
+        // Milliseconds and rows of the scans that timed each way: one scan of four million rows settles a way, shard-sized
+        // batches (64 K rows and more) add up to that over their first applies.
+        double TunedMs[3] = {0, 0, 0};
+        int64_t TunedRows[3] = {0, 0, 0};
         // Groupings of a million groups and more: records sorted by table region and applied inside LDS, or every row
         // updating the table in HBM itself.  The sorted way wins where the key is in the record (fixed-width keys:
         // ClickBench UserID 1.6x), the direct way where every update compares key bytes in memory anyway (long string
