@@ -46,12 +46,17 @@ def main():
     for _ in range(2):
         out = pc.ImportBlobs(blobs)
     torch.cuda.synchronize()
+    pc.EnableProfile(True)
+    pc.ReadProfile()
     t0 = time.perf_counter()
     K = 5
     for _ in range(K):
         out = pc.ImportBlobs(blobs)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
+    kernel_ms, launches, _ = pc.ReadProfile()
+    pc.EnableProfile(False)
+    print(f"decode kernel: {kernel_ms / max(1, launches):.1f} ms per import (HIP events)", flush=True)
     print(f"{nportions} portions x {rows} rows: {packed / 1e6:.1f} MB stored -> {raw / 1e6:.1f} MB of columns; "
           f"{dt * 1e3:.2f} ms per import (host copy of the blobs included), {raw / dt / 1e9:.1f} GB/s of columns, {nportions * rows / dt / 1e9:.2f} G rows/s", flush=True)
     t0 = time.perf_counter()

@@ -6,6 +6,9 @@
 // reference's default, native.h:54-57); ZSTD is declined with SSA_UNSUPPORTED.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "exec.h"
@@ -47,6 +50,15 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
     (void)hipSetDevice(Device);
     out.clear();
     const size_t nb = blobs.size();
+    const bool timing = std::getenv("SSA_DEBUG_PLAN") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(StreamHandle);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "blobs: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     std::vector<IpcBatch> parsed(nb);
     std::vector<size_t> base(nb, 0);   // offset of each blob in the device copy
     size_t total = 0;
@@ -68,6 +80,7 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
         }
     }
 
+    mark("parse + copy to the device");
     std::vector<BatchPtr> batches(nb);
     std::vector<PendingBuffer> pending;
     // string columns (and dictionaries: their values are one) whose offsets are checked against their data buffers below
@@ -211,6 +224,7 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
         }
         tasks.push_back(t);
     }
+    mark("buffers allocated, frames parsed, stored buffers copied");
     if (maxBlock > 90u * 1024u) return Status::Unsupported("LZ4 frame with blocks of more than 64 KB");
     if (!tasks.empty()) {
         BufferPtr dtasks = Buffer::Alloc(tasks.size() * sizeof(Lz4FrameTask));
@@ -237,6 +251,7 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
     } else {
         SSA_HIP(hipStreamSynchronize(StreamHandle));
     }
+    mark("decode");
     // RecordBatch::Validate of the reference: offsets of a string column must describe its data buffer
     for (const StringCheck& sc : strings) {
         const Column& col = *sc.Col;
@@ -247,6 +262,7 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
         SSA_HIP(hipStreamSynchronize(StreamHandle));
         if (ends[0] < 0 || ends[1] < ends[0] || int64_t(ends[1]) > sc.Bytes) return Status::Invalid("validation error: string offsets run past the data buffer");
     }
+    mark("validation");
     out = batches;
     return Status::OK();
 }

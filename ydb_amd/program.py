@@ -159,7 +159,9 @@ class ProgramContainer:
         """TNativeSerializer::DoDeserialize on the GPU: IPC blobs (whole streams, or lone RecordBatch messages read with
         `schema`: a HostBatch whose schema is the chunk's) -> resident batches, one launch for all compressed buffers."""
         n = len(blobs)
-        keep = [ctypes.create_string_buffer(bytes(b), len(b)) for b in blobs]
+        # (the library reads the blobs where they lie: a bytes object's buffer is handed over as it is, anything else
+        # through one copy)
+        keep = [ctypes.c_char_p(b) if isinstance(b, bytes) else ctypes.create_string_buffer(bytes(b), len(b)) for b in blobs]
         ptrs = (ctypes.c_void_p * max(1, n))(*[ctypes.cast(k, ctypes.c_void_p).value for k in keep])
         sizes = (ctypes.c_size_t * max(1, n))(*[len(b) for b in blobs])
         outs = (ctypes.c_void_p * max(1, n))()
