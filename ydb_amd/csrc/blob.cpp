@@ -192,6 +192,7 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
                 outLen = rawLen;
             } else {
                 if (ulen < 0 || ulen > (int64_t(1) << 40)) return Status::Invalid("compressed buffer announces an impossible length");
+                if (ulen >= (int64_t(1) << 32)) return Status::Unsupported("compressed buffer of 4 GB or more");  // (the decode kernel counts in 32 bits)
                 frame = true;
                 outLen = ulen;
             }
@@ -236,7 +237,7 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
         }
         ProfileBegin();
         SSA_HIP(LaunchLz4Decode(static_cast<const uint8_t*>(dblob->Ptr), static_cast<const Lz4FrameTask*>(dtasks->Ptr), int64_t(tasks.size()),
-                                static_cast<const Lz4BlockRef*>(dblocks->Ptr), maxBlock, static_cast<uint32_t*>(StatusWord->Ptr), StreamHandle));
+                                static_cast<const Lz4BlockRef*>(dblocks->Ptr), static_cast<uint32_t*>(StatusWord->Ptr), StreamHandle));
         int64_t produced = 0;
         for (auto& t : tasks) produced += int64_t(t.dst_bytes);
         ProfileEnd("Lz4DecodeKernel", produced);

@@ -315,10 +315,8 @@ struct Lz4FrameTask {
     uint64_t dst_bytes;    // the length the buffer announces
 };
 // Decodes every frame (one wavefront each) from the blob in device memory (256-byte aligned, 64 bytes of padding
-// behind it); maxBlockBytes = the largest compressed block among them.  A frame that does not decode to its announced
-// length raises SCAN_BAD_BLOB in *status.
-hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t maxBlockBytes,
-                           uint32_t* status, hipStream_t st);
+// behind it).  A frame that does not decode to its announced length raises SCAN_BAD_BLOB in *status.
+hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t* status, hipStream_t st);
 
 constexpr int kMaxShardKeys = 8;  // key columns of a sharding hash / a predicate border
 

@@ -3,9 +3,9 @@
 // The format is the published LZ4 frame / block format (lz4_Frame_format.md, lz4_Block_format.md; the reference
 // vendors the library as contrib/libs/lz4 and reaches it through arrow::util::Codec, serializer/native.h:54-57).  Arrow
 // writes every buffer as one frame of 64 KB blocks that may refer back into the previous block ("linked" blocks), so
-// a frame decodes front to back.  One wavefront takes one frame: the compressed block is staged into LDS with wide
-// loads, the token stream is parsed by the whole wave in lockstep (wave-uniform scalars), and the bytes of every
-// literal run and every match are copied by the 64 lanes side by side.  The last 64 KB of output live in an LDS ring,
+// a frame decodes front to back.  One wavefront takes one frame: the token stream is parsed by the whole wave in
+// lockstep out of registers (wave-uniform scalars), and the bytes of every literal run and every match are copied by
+// the 64 lanes side by side.  The last 64 KB of output live in an LDS ring,
 // which is where matches read from (LDS accesses of one wave complete in issue order, so a match sees the bytes
 // earlier sequences wrote); every byte goes to the ring and to the output buffer in HBM, 64 consecutive bytes per
 // store instruction.  Parallelism across frames comes from the grid: a blob has up to three buffers per column, a
@@ -20,22 +20,26 @@ namespace {
 
 constexpr uint32_t kRing = 65536;
 
-__global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const Lz4FrameTask* tasks, const Lz4BlockRef* blocks,
-                                                     uint32_t inBytes, uint32_t* status) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lz4Lds[];
-    uint8_t* ring = lz4Lds;
-    uint8_t* in = lz4Lds + kRing;
+// One wave, one instruction at a time: the decode is bound by the number of instructions a sequence takes (there is no
+// second wave on the SIMD to fill the gaps), so the common sequence is kept short and free of branches.
+__global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const Lz4FrameTask* tasks, const Lz4BlockRef* blocks, uint32_t* status) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     const uint32_t lane = threadIdx.x;
+    const float laneF = float(lane);
     const Lz4FrameTask t = tasks[blockIdx.x];
-    uint8_t* dst = t.dst;
-    uint64_t op = 0;
+    // (a pointer read from memory is of no known address space: said to be global, the stores below do not count as LDS
+    // operations, which the waits for the ring would wait for too)
+    __attribute__((address_space(1))) uint8_t* dst = (__attribute__((address_space(1))) uint8_t*)t.dst;
+    const uint32_t total = uint32_t(t.dst_bytes);  // (the host hands over frames of less than 4 GB)
+    uint32_t op = 0;
     bool bad = false;
     for (uint32_t b = 0; b < t.nblocks && !bad; ++b) {
         const Lz4BlockRef blk = blocks[t.first_block + b];
         const uint8_t* src = blob + blk.Src;
         const uint32_t n = blk.SrcBytes;
+        if (n == 0) continue;
         if (blk.Stored) {
-            if (op + n > t.dst_bytes) {
+            if (n > total - op) {
                 bad = true;
                 break;
             }
@@ -47,75 +51,147 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
             op += n;
             continue;
         }
-        if (n + 32 > inBytes) {
-            bad = true;
-            break;
-        }
-        // stage the compressed block: whole 16-byte pieces from the aligned address below it (the blob's allocation is
-        // 256-byte aligned and padded, so the pieces around the block are readable)
-        const uint32_t skew = uint32_t(reinterpret_cast<uintptr_t>(src) & 15u);
-        const uint4* a = reinterpret_cast<const uint4*>(src - skew);
-        const uint32_t pieces = (skew + n + 15u) >> 4;
-        for (uint32_t i = lane; i < pieces; i += 64) reinterpret_cast<uint4*>(in)[i] = a[i];
-        const uint8_t* q = in + skew;
+        // The compressed bytes are parsed out of registers.  Register A holds 256 bytes of the block, one 32-bit word
+        // per lane, counted from the aligned word below the block's first byte; B holds the 256 bytes behind them.  A
+        // word comes out of A by lane number (v_readlane: the position is the same for the whole wave), so token, lengths
+        // and offset of a sequence are scalar arithmetic with no trip to memory.  When the parse nears A's end, A moves
+        // up to the word the parse stands at (lanes shifted through A and B) and B is loaded anew: those bytes are needed
+        // 240 bytes of input later.  Words past the block's last are not read.
+        const uint32_t skew = uint32_t(reinterpret_cast<uintptr_t>(src) & 3u);
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(src - skew);
+        const uint32_t lastWord = (skew + n - 1u) >> 2;
+        auto load = [&](uint32_t first) -> uint32_t {
+            const uint32_t i = first + lane;
+            return words[i < lastWord ? i : lastWord];
+        };
+        uint32_t wbase = 0;  // the word in A's lane 0
+        uint32_t A = load(0), B = load(64);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // (as in rebase below)
+        auto rebase = [&](uint32_t d) {
+            const uint32_t s = d - wbase;
+            if (s < 64u) {
+                const uint32_t j = (lane + s) & 63u;
+                const uint32_t a = uint32_t(__shfl(int(A), int(j))), c = uint32_t(__shfl(int(B), int(j)));
+                A = lane + s < 64u ? a : c;
+            } else {  // (a long run of literals was stepped over)
+                A = load(d);
+                // waited for here, so that the common path, which reads A right away, need not wait for whatever loads
+                // and stores are in flight: vmcnt 0, the other counters left alone
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            B = load(d + 64u);
+            wbase = d;
+        };
+        // twelve bytes of the block from byte `at` on
+        auto fetch = [&](uint32_t at, uint64_t& w0, uint32_t& w1) {
+            const uint32_t y = skew + at;
+            uint32_t r = (y >> 2) - wbase;
+            if (r > 60u) {
+                rebase(y >> 2);
+                r = 0;
+            }
+            const uint32_t x0 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r)));
+            const uint32_t x1 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 1u)));
+            const uint32_t x2 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 2u)));
+            const uint32_t x3 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 3u)));
+            const uint32_t sh = 8u * (y & 3u);
+            const uint32_t b0 = uint32_t((uint64_t(x0) | (uint64_t(x1) << 32)) >> sh);
+            const uint32_t b1 = uint32_t((uint64_t(x1) | (uint64_t(x2) << 32)) >> sh);
+            w1 = uint32_t((uint64_t(x2) | (uint64_t(x3) << 32)) >> sh);
+            w0 = uint64_t(b0) | (uint64_t(b1) << 32);
+        };
         uint32_t ip = 0;
-        const uint64_t blockStart = op;
+        // the bytes of a length that follow a token's 15: adds them to `len`, stops behind the first that is not 255
+        auto readLength = [&](uint32_t& len) {
+            for (;;) {
+                if (ip >= n) {
+                    bad = true;
+                    return;
+                }
+                uint64_t a;
+                uint32_t unused;
+                fetch(ip, a, unused);
+                for (int k = 0; k < 8; ++k) {
+                    if (ip >= n) {
+                        bad = true;
+                        return;
+                    }
+                    const uint32_t x = uint32_t(a) & 0xFFu;
+                    a >>= 8;
+                    ++ip;
+                    len += x;
+                    if (x != 255u) return;
+                }
+            }
+        };
+        const uint32_t blockStart = op;
         while (ip < n) {
-            // The common sequence -- at most five literals, a match of at most 18 bytes -- lies inside the eight bytes
-            // that start at its token: one LDS round trip brings token, literals and offset, a second the match's source.
-            // (The staged block is followed by 32 readable bytes.)  Everything else, and the end of a block, takes the
-            // general code below.
+            uint64_t w0;
+            uint32_t w1;
+            fetch(ip, w0, w1);
+            const uint32_t token = uint32_t(w0) & 0xFFu;
+            // The common sequence -- at most nine literals, a match of at most 18 bytes -- lies inside the twelve bytes
+            // that start at its token.  Its bytes, literals and match alike, are written by one lane each in one step:
+            // a literal comes out of the scalar registers, a match byte out of the ring -- or out of the scalar registers
+            // too, where the match reaches back into the literals of its own sequence.
             {
-                uint64_t w = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) w |= uint64_t(q[ip + k]) << (8 * k);
-                const uint32_t tk = uint32_t(w) & 0xFFu, fl = tk >> 4, fm = (tk & 15u) + 4u;
-                if (fl <= 5u && (tk & 15u) != 15u && ip + 3u + fl <= n) {
-                    const uint32_t off = uint32_t(w >> (8u * (1u + fl))) & 0xFFFFu;
-                    const uint64_t mp = op + fl;  // where the match lands
-                    const uint64_t reach = t.linked ? mp : mp - blockStart;
-                    if (off == 0 || off > reach || mp + fm > t.dst_bytes) {
+                const uint32_t fl = token >> 4, fm = (token & 15u) + 4u;
+                if (fl <= 9u && (token & 15u) != 15u && ip + 3u + fl <= n) {
+                    const uint64_t mid = (w0 >> 32) | (uint64_t(w1) << 32);  // bytes 4..11
+                    const uint32_t p = 8u * (1u + fl);
+                    const uint32_t off = uint32_t(p <= 48u ? w0 >> p : mid >> (p - 32u)) & 0xFFFFu;
+                    const uint32_t mp = op + fl;  // where the match lands
+                    const uint32_t reach = t.linked ? mp : mp - blockStart;
+                    if (off == 0 || off > reach || fl + fm > total - op) {
                         bad = true;
                         break;
                     }
-                    if (lane < fl) {
-                        const uint8_t x = uint8_t(w >> (8u * (1u + lane)));
+                    // match byte m comes from `off` bytes back; a match that overlaps its own output repeats a pattern of
+                    // `off` bytes: m mod off (m < 18: the rounded quotient is exact)
+                    const float mF = laneF - float(fl);
+                    const uint32_t m = lane - fl;
+                    const uint32_t q = uint32_t((mF + 0.5f) * __builtin_amdgcn_rcpf(float(off)));
+                    const uint32_t r = m - q * off;
+                    const uint32_t back = off - r;                 // bytes before the match's start
+                    const bool literal = lane < fl || back <= fl;  // (for a lane of the match: its source is a literal)
+                    const uint32_t li = lane < fl ? lane : fl - back;
+                    const uint32_t k = 8u * (li + 1u);
+                    const uint8_t fromWords = uint8_t((k <= 56u ? w0 : mid) >> (k <= 56u ? k : k - 32u));
+                    const uint8_t fromRing = ring[(mp - back) & (kRing - 1)];
+                    if (lane < fl + fm) {
+                        const uint8_t x = literal ? fromWords : fromRing;
                         ring[(op + lane) & (kRing - 1)] = x;
                         dst[op + lane] = x;
-                    }
-                    if (lane < fm) {
-                        uint32_t r = lane;
-                        if (off < fm) r = lane - off * uint32_t(__fdividef(float(lane) + 0.5f, float(off)));  // lane % off (lane < 19)
-                        const uint8_t x = ring[(mp - off + r) & (kRing - 1)];
-                        ring[(mp + lane) & (kRing - 1)] = x;
-                        dst[mp + lane] = x;
                     }
                     ip += 3u + fl;
                     op = mp + fm;
                     continue;
                 }
             }
-            const uint32_t token = q[ip++];
+            ++ip;
             uint32_t lit = token >> 4;
-            if (lit == 15) {
-                uint32_t x;
-                do {
-                    if (ip >= n) {
-                        bad = true;
-                        break;
-                    }
-                    x = q[ip++];
-                    lit += x;
-                } while (x == 255);
-            }
-            if (bad || lit > n - ip || op + lit > t.dst_bytes) {
+            if (lit == 15u) readLength(lit);
+            if (bad || lit > n - ip || lit > total - op) {
                 bad = true;
                 break;
             }
-            for (uint32_t i = lane; i < lit; i += 64) {
-                const uint8_t x = q[ip + i];
-                ring[(op + i) & (kRing - 1)] = x;
-                dst[op + i] = x;
+            for (uint32_t base = 0; base < lit; base += 64) {
+                const uint32_t m = lit - base < 64u ? lit - base : 64u;
+                const uint32_t y0 = skew + ip + base;
+                uint8_t x;
+                if (((y0 + m - 1u) >> 2) - wbase < 128u) {  // the piece lies in A and B
+                    const uint32_t yb = y0 + lane;
+                    const uint32_t wi = (yb >> 2) - wbase;
+                    const uint32_t a = uint32_t(__shfl(int(A), int(wi & 63u))), c = uint32_t(__shfl(int(B), int(wi & 63u)));
+                    x = uint8_t((wi < 64u ? a : c) >> (8u * (yb & 3u)));
+                } else {
+                    x = lane < m ? src[ip + base + lane] : uint8_t(0);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // (here, not at the top of the loop: see rebase)
+                }
+                if (lane < m) {
+                    ring[(op + base + lane) & (kRing - 1)] = x;
+                    dst[op + base + lane] = x;
+                }
             }
             ip += lit;
             op += lit;
@@ -124,23 +200,14 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
                 bad = true;
                 break;
             }
-            const uint32_t off = uint32_t(q[ip]) | (uint32_t(q[ip + 1]) << 8);
+            fetch(ip, w0, w1);
+            const uint32_t off = uint32_t(w0) & 0xFFFFu;
             ip += 2;
             uint32_t ml = token & 15u;
-            if (ml == 15) {
-                uint32_t x;
-                do {
-                    if (ip >= n) {
-                        bad = true;
-                        break;
-                    }
-                    x = q[ip++];
-                    ml += x;
-                } while (x == 255);
-            }
+            if (ml == 15u) readLength(ml);
             ml += 4;
-            const uint64_t reach = t.linked ? op : op - blockStart;  // how far back a match may point
-            if (bad || off == 0 || off > reach || op + ml > t.dst_bytes) {
+            const uint32_t reach = t.linked ? op : op - blockStart;  // how far back a match may point
+            if (bad || off == 0 || off > reach || ml > total - op) {
                 bad = true;
                 break;
             }
@@ -168,24 +235,14 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
             op += ml;
         }
     }
-    if ((bad || op != t.dst_bytes) && lane == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
+    if ((bad || op != total) && lane == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
 }
 
 }  // namespace
 
-hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t maxBlockBytes,
-                           uint32_t* status, hipStream_t st) {
+hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t* status, hipStream_t st) {
     if (ntasks <= 0) return hipSuccess;
-    const uint32_t inBytes = (maxBlockBytes + 32u + 255u) & ~255u;
-    const uint32_t lds = kRing + inBytes;
-    static int configured = 0;  // bytes the attribute was last raised to (per process; the value only grows)
-    if (int(lds) > configured) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&Lz4DecodeKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        if (e != hipSuccess) return e;
-        configured = 160 * 1024 - 1024;
-    }
-    if (lds > 160u * 1024u - 1024u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(Lz4DecodeKernel, dim3(uint32_t(ntasks)), dim3(64), lds, st, blob, tasks, blocks, inBytes, status);
+    hipLaunchKernelGGL(Lz4DecodeKernel, dim3(uint32_t(ntasks)), dim3(64), 0, st, blob, tasks, blocks, status);
     return hipGetLastError();
 }
 
