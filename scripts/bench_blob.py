@@ -2,8 +2,10 @@
 LZ4_FRAME bodies (what TNativeSerializer writes by default, ydb/core/formats/arrow/serializer/native.h:54-57), imported in
 one ssa_batches_from_blobs call.  Reports decompressed GB/s (column bytes produced) and rows/s, next to pyarrow's own
 single-thread read of the same blobs on the host.
-Run from the repository root: PYTHONPATH=. python scripts/bench_blob.py [portions]"""
+Run from the repository root: PYTHONPATH=. python scripts/bench_blob.py [portions]
+(BLOB_COLUMNS=l_quantity,l_tax keeps those columns only: which kind of column costs what.)"""
 import io
+import os
 import sys
 import time
 
@@ -22,6 +24,9 @@ def portion(row0, rows):
     cols = {"l_shipdate": pa.array(li["l_shipdate"]), "l_quantity": pa.array(li["l_quantity"]), "l_extendedprice": pa.array(li["l_extendedprice"]),
             "l_discount": pa.array(li["l_discount"]), "l_tax": pa.array(li["l_tax"]),
             "l_returnflag": pa.array(list(li["l_returnflag"]), type=pa.utf8()), "l_linestatus": pa.array(list(li["l_linestatus"]), type=pa.utf8())}
+    keep = os.environ.get("BLOB_COLUMNS")
+    if keep:
+        cols = {k: v for k, v in cols.items() if k in keep.split(",")}
     t = pa.table(cols)
     sink = io.BytesIO()
     with ipc.new_stream(sink, t.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:

@@ -134,6 +134,34 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
             // that start at its token.  Its bytes, literals and match alike, are written by one lane each in one step:
             // a literal comes out of the scalar registers, a match byte out of the ring -- or out of the scalar registers
             // too, where the match reaches back into the literals of its own sequence.
+            // Sequences without literals (a token below 15: three bytes, columns of few distinct values are made of
+            // them): up to four come out of one fetch.
+            if (__builtin_expect(token < 15u, 0) && ip + 3u <= n) {
+                uint32_t avail = 12u;
+                do {
+                    const uint32_t fm = (uint32_t(w0) & 15u) + 4u;
+                    const uint32_t off = uint32_t(w0 >> 8) & 0xFFFFu;
+                    const uint32_t reach = t.linked ? op : op - blockStart;
+                    if (off == 0 || off > reach || fm > total - op) {
+                        bad = true;
+                        break;
+                    }
+                    uint32_t r = lane;
+                    if (off < fm) r = lane - __umul24(uint32_t((laneF + 0.5f) * __builtin_amdgcn_rcpf(float(off))), off);  // lane mod off (lane < 18)
+                    if (lane < fm) {
+                        const uint8_t x = ring[(op - off + r) & (kRing - 1)];
+                        ring[(op + lane) & (kRing - 1)] = x;
+                        dst[op + lane] = x;
+                    }
+                    ip += 3u;
+                    op += fm;
+                    w0 = (w0 >> 24) | (uint64_t(w1) << 40);
+                    w1 >>= 24;
+                    avail -= 3u;
+                } while (avail >= 3u && (uint32_t(w0) & 0xFFu) < 15u && ip + 3u <= n);
+                if (bad) break;
+                continue;
+            }
             {
                 const uint32_t fl = token >> 4, fm = (token & 15u) + 4u;
                 if (fl <= 9u && (token & 15u) != 15u && ip + 3u + fl <= n) {
@@ -148,10 +176,9 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
                     }
                     // match byte m comes from `off` bytes back; a match that overlaps its own output repeats a pattern of
                     // `off` bytes: m mod off (m < 18: the rounded quotient is exact)
-                    const float mF = laneF - float(fl);
                     const uint32_t m = lane - fl;
-                    const uint32_t q = uint32_t((mF + 0.5f) * __builtin_amdgcn_rcpf(float(off)));
-                    const uint32_t r = m - q * off;
+                    uint32_t r = m;
+                    if (off < fm) r = m - __umul24(uint32_t((laneF - float(fl) + 0.5f) * __builtin_amdgcn_rcpf(float(off))), off);
                     const uint32_t back = off - r;                 // bytes before the match's start
                     const bool literal = lane < fl || back <= fl;  // (for a lane of the match: its source is a literal)
                     const uint32_t li = lane < fl ? lane : fl - back;
