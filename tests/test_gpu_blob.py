@@ -75,6 +75,47 @@ def test_many_blobs_in_one_call():
         check_columns(as_columns(pc.Export(d)), np.load(os.path.join(IPC, by_name[n]["expected"] + ".npz")), by_name[n]["rows"], schema_of(by_name[n]))
 
 
+def shapes_blob(rows, seed):
+    """An LZ4 stream whose buffers hold every shape of block the decoder knows: stored blocks between compressed ones
+    (a stretch of random numbers inside a column that otherwise compresses), long runs of literals (text), matches of
+    tens of kilobytes (zeros: lengths of many 255 bytes), sequences without literals (a repeating pattern), and frames of
+    many linked blocks."""
+    import io
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    rng = np.random.default_rng(seed)
+    third = rows // 3
+    mixed = np.concatenate([np.tile(np.arange(7, dtype=np.int64), third // 7 + 1)[:third], rng.integers(-2**62, 2**62, third),
+                            np.arange(rows - 2 * third, dtype=np.int64) * 3])
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 12))).astype(np.uint8)) for _ in range(3000)]
+    text = [b" ".join(words[j] for j in rng.integers(0, 3000, int(rng.integers(1, 9)))) for _ in range(rows // 4)] + [b""] * (rows - rows // 4)
+    sparse = np.where(rng.random(rows) < 0.02, rng.integers(0, 2**31 - 1, rows), 0).astype(np.int32)
+    t = pa.table({"mixed": pa.array(mixed), "text": pa.array(text, type=pa.binary()), "zeros": pa.array(np.zeros(rows, dtype=np.int64)),
+                  "sparse": pa.array(sparse)})
+    sink = io.BytesIO()
+    with ipc.new_stream(sink, t.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+        w.write_table(t, max_chunksize=rows)
+    return sink.getvalue()
+
+
+@pytest.mark.parametrize("rows,seed", [(120_000, 77), (50_001, 78), (700_000, 79)])
+def test_lz4_blocks_of_every_shape(rows, seed):
+    from oracle import ipc_oracle
+    schema = [("mixed", "int64"), ("text", "binary"), ("zeros", "int64"), ("sparse", "int32")]
+    blob = shapes_blob(rows, seed)
+    pc = container(schema)
+    dev = pc.ImportBlob(blob)
+    assert dev.rows == rows
+    got = as_columns(pc.Export(dev))
+    exp = ipc_oracle.read_blob(blob, None)
+    for name, typ in schema:
+        if typ == "binary":
+            assert got[name]["chars"] == bytes(exp[name]["chars"][exp[name]["offsets"][0]:exp[name]["offsets"][-1]])
+            assert np.array_equal(got[name]["offsets"], np.asarray(exp[name]["offsets"]) - exp[name]["offsets"][0])
+        else:
+            assert np.array_equal(np.asarray(got[name]["values"]), np.asarray(exp[name]["values"])), name
+
+
 def test_zstd_is_declined_and_damage_is_an_error():
     from ydb_amd import _lib
     from ydb_amd.program import SsaError

@@ -43,11 +43,23 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
                 bad = true;
                 break;
             }
-            for (uint32_t i = lane; i < n; i += 64) {
-                const uint8_t x = src[i];
-                ring[(op + i) & (kRing - 1)] = x;
-                dst[op + i] = x;
+            for (uint32_t base = 0; base < n; base += 1024) {  // (sixteen loads in flight per lane: the copy is bound by their latency)
+                uint8_t x[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k) {
+                    const uint32_t i = base + k * 64 + lane;
+                    x[k] = i < n ? src[i] : uint8_t(0);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k) {
+                    const uint32_t i = base + k * 64 + lane;
+                    if (i < n) {
+                        ring[(op + i) & (kRing - 1)] = x[k];
+                        dst[op + i] = x[k];
+                    }
+                }
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // (see rebase below)
             op += n;
             continue;
         }
