@@ -23,6 +23,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -247,11 +248,11 @@ def main():
         """`warmup` untimed steps, then exactly `steps` timed ones; one step runs every program of the stream once."""
         results = [None] * len(scans_)
         # The executor builds the step program's kernel at the first large scan and settles how it runs it
-        # (register-held groups on or off) on the second: with fewer than two warm-up steps asked for, those passes run
-        # here, untimed, like the generation of the table.
-        # Groupings of a million groups take a third such pass (records sorted by table region, or row-by-row updates),
-        # and so do groupings behind a filter (the rows that passed taken one by one).
-        for _ in range(max(0, (3 if clickbench_run else 2) - warmup) + warmup):
+        # (register-held groups on or off) on the second; groupings of a million groups take a third such pass (records
+        # sorted by table region, or row-by-row updates), and so do groupings behind a filter (the rows that passed taken
+        # one by one).  Those passes run here, untimed, like the generation of the table -- each is a second of hiprtc on
+        # the host with the GPU idle -- and the warm-up steps asked for come after them.
+        for _ in range((3 if clickbench_run else 2) + warmup):
             for i, s in enumerate(scans_):
                 results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device)
         for s in scans_:
@@ -259,12 +260,21 @@ def main():
             s.local.ReadProfile()
         barrier()
         third_way[0] = one_by_one_scans()
+        # (as timeit does: a collection of Python's cyclic garbage inside the timed region is a millisecond of host time
+        # that has nothing to do with the scan)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(steps):
             for i, s in enumerate(scans_):
                 results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device)
+            marks.append(time.perf_counter())
         barrier()
         elapsed = time.perf_counter() - t0
+        gc.enable()
+        if os.environ.get("BENCH_STEP_TIMES"):  # (every step ends with its result on the host: the marks are step ends)
+            print("steps, ms: " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip(marks, marks[1:])), file=sys.stderr, flush=True)
         third_way[0] = one_by_one_scans() - third_way[0]
         profiles = [s.local.ReadProfile() for s in scans_]
         for s in scans_:
@@ -351,6 +361,7 @@ def main():
                        "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr if not mixed else sum(b for _, _, _, b, _ in stream),
                        "groups": groups,
                        "kernels_built_at_run_time": built, "kernel_build_ms_before_the_timed_steps": build_ms,
+                       "untimed_passes_that_build_and_settle_the_kernels_before_the_warmup": 3 if clickbench_run else 2,
                        "float_sum_tolerance": "relative 1e-12 against the CPU oracle up to 1e5 rows, 1e-10 at millions of rows "
                                               "(the reference's own sequential sum is off by n * 2^-53), checked in tests/",
                        "parallelism": f"row-range shards x{world}, partial aggregates merged by " +

@@ -768,6 +768,7 @@ void ssa_batch_destroy(ssa_batch_t* batch) { delete batch; }
 void ssa_profile_enable(ssa_program_t* program, int enabled) {
     std::lock_guard<std::mutex> g(program->Lock);
     if (!EnsureExecutor(program).ok()) return;
+    program->Exec->ProfileCollect();
     program->Exec->Profile.Enabled = enabled != 0;
 }
 
@@ -786,6 +787,7 @@ void ssa_profile_read(ssa_program_t* program, double* scan_ms, int64_t* launches
     if (launches) *launches = 0;
     if (algorithmic_bytes) *algorithmic_bytes = 0;
     if (!program->Exec) return;
+    program->Exec->ProfileCollect();
     KernelProfile& p = program->Exec->Profile;
     if (scan_ms) *scan_ms = p.ScanMs;
     if (launches) *launches = p.ScanLaunches;

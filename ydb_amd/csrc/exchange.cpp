@@ -191,6 +191,70 @@ Status Executor::PackData(const Batch& in, void* dst, size_t capacity) {
     return RunSegments(segs);
 }
 
+Status Executor::PackToHost(const Batch& in, std::vector<HostColumnView>& views, bool& done) {
+    done = false;
+    if (in.Rows <= 0 || in.Rows > 16384 || in.Cols.empty()) return Status::OK();
+    for (const Column& c : in.Cols) {
+        if (c.Dict || c.Field.IsScalar || !c.Values || c.Length != in.Rows) return Status::OK();
+        if (IsStringLike(c.Field.Type) && !c.Chars) return Status::OK();
+    }
+    (void)hipSetDevice(Device);
+    if (!HostStaging) {
+        void* pinned = nullptr;
+        if (hipHostMalloc(&pinned, kHostStagingBytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();  // (the copies buffer by buffer still work)
+            return Status::OK();
+        }
+        HostStaging = static_cast<uint8_t*>(pinned);
+    }
+    std::vector<int32_t> bounds;
+    SSA_RETURN_NOT_OK(StringBounds(in, bounds));
+    std::vector<uint8_t> header;
+    std::vector<Region> regions;
+    uint64_t dataBytes = 0;
+    SSA_RETURN_NOT_OK(Layout(in, bounds, &header, &regions, dataBytes));
+    if (dataBytes > kHostStagingBytes) return Status::OK();
+    std::vector<CopySegment> segs;
+    BufferPtr staged = Buffer::Alloc(size_t(dataBytes) + 64);
+    if (!staged) return Status::Hip("out of device memory");
+    uint8_t* dst = static_cast<uint8_t*>(staged->Ptr);
+    uint64_t maxCount = 0;
+    for (const Region& r : regions) {
+        if (!r.src) continue;
+        if (r.offsets) segs.push_back(CopySegment{static_cast<const uint8_t*>(r.src), dst + r.off, r.bytes / 4, SEG_I32_ADD, r.shift});
+        else segs.push_back(CopySegment{static_cast<const uint8_t*>(r.src), dst + r.off, r.bytes, SEG_BYTES, 0});
+        maxCount = std::max(maxCount, r.bytes);
+    }
+    BufferPtr dsegs = Buffer::Alloc(segs.size() * sizeof(CopySegment) + 64);
+    if (!dsegs) return Status::Hip("out of device memory");
+    if (!segs.empty()) {
+        SSA_HIP(hipMemcpyAsync(dsegs->Ptr, segs.data(), segs.size() * sizeof(CopySegment), hipMemcpyHostToDevice, StreamHandle));
+        SSA_HIP(LaunchCopySegments(static_cast<const CopySegment*>(dsegs->Ptr), int(segs.size()), maxCount, StreamHandle));
+    }
+    SSA_HIP(hipMemcpyAsync(HostStaging, dst, size_t(dataBytes), hipMemcpyDeviceToHost, StreamHandle));
+    SSA_HIP(hipStreamSynchronize(StreamHandle));  // (the host array and the device buffers are read until here)
+    views.assign(in.Cols.size(), HostColumnView{});
+    for (size_t i = 0; i < in.Cols.size(); ++i) {
+        PackedColumn pc;
+        std::memcpy(&pc, header.data() + sizeof(PackedHeader) + i * sizeof(PackedColumn), sizeof(pc));
+        HostColumnView& v = views[i];
+        v.Values = HostStaging + pc.values_off;
+        v.ValuesBytes = size_t(pc.values_bytes);
+        v.ValBitOff = pc.val_bit_off;
+        if (pc.valid_off != kNone) {
+            v.Valid = HostStaging + pc.valid_off;
+            v.ValidBytes = size_t(pc.valid_bytes);
+            v.ValidBitOff = pc.valid_bit_off;
+        }
+        if (IsStringLike(pc.type)) {
+            v.Chars = HostStaging + pc.chars_off;
+            v.CharsBytes = size_t(pc.chars_bytes);
+        }
+    }
+    done = true;
+    return Status::OK();
+}
+
 // A batch whose columns are views of `data` (device memory that the caller keeps alive as long as the batch lives).
 Status UnpackBatch(const uint8_t* header, size_t headerBytes, void* data, size_t dataBytes, BatchPtr& out) {
     PackedHeader h;

@@ -191,6 +191,7 @@ Executor::~Executor() {
     if (EvTuneB) (void)hipEventDestroy(EvTuneB);
     if (StreamHandle) (void)hipStreamDestroy(StreamHandle);
     if (HostWords) (void)hipHostFree(HostWords);
+    if (HostStaging) (void)hipHostFree(HostStaging);
 }
 
 Status Executor::Sync() {
@@ -199,19 +200,34 @@ Status Executor::Sync() {
 }
 
 void Executor::ProfileBegin() {
-    if (Profile.Enabled) (void)hipEventRecord(EvStart, StreamHandle);
+    if (!Profile.Enabled) return;
+    ProfileCollect();
+    (void)hipEventRecord(EvStart, StreamHandle);
 }
 
+// The launch's time is read later (ProfileCollect: at the next launch to be timed, or when the profile is read): waiting
+// for the stop event here would keep the work that follows the kernel from being queued behind it.
 void Executor::ProfileEnd(const char* kernel, int64_t algoBytes) {
     if (!Profile.Enabled) return;
     (void)hipEventRecord(EvStop, StreamHandle);
+    ProfilePending = true;
+    ProfilePendingBytes = algoBytes;
+    Profile.LastKernel = kernel;
+}
+
+void Executor::ProfileCollect() {
+    if (!ProfilePending) return;
+    ProfilePending = false;
+    (void)hipSetDevice(Device);
     (void)hipEventSynchronize(EvStop);
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, EvStart, EvStop);
+    if (hipEventElapsedTime(&ms, EvStart, EvStop) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
     Profile.ScanMs += ms;
     Profile.ScanLaunches += 1;
-    Profile.ScanBytes += algoBytes;
-    Profile.LastKernel = kernel;
+    Profile.ScanBytes += ProfilePendingBytes;
 }
 
 Status Executor::CheckScanStatus(bool* tableFull, bool* notUniform) {
@@ -545,6 +561,10 @@ Status Executor::ExportBatch(const Batch& encoded, ArrowArray* outArray, ArrowSc
         }
     }
     const Batch& batch = anyDict ? decoded : encoded;
+    // a result of few rows comes over in one copy (a copy per buffer costs a round trip each: twenty for a Q1 result)
+    std::vector<HostColumnView> views;
+    bool packed = false;
+    SSA_RETURN_NOT_OK(PackToHost(batch, views, packed));
     SSA_HIP(hipStreamSynchronize(StreamHandle));
     InitSchema(outSchema, "+s", "", false);
     auto* sp = static_cast<ExportedSchema*>(outSchema->private_data);
@@ -565,7 +585,8 @@ Status Executor::ExportBatch(const Batch& encoded, ArrowArray* outArray, ArrowSc
         return st;
     };
 
-    for (const Column& col : batch.Cols) {
+    for (size_t ci = 0; ci < batch.Cols.size(); ++ci) {
+        const Column& col = batch.Cols[ci];
         if (col.Field.IsScalar) return fail(Status::Invalid("internal: scalar column in an exported batch"));
         auto* cs = new ArrowSchema();
         InitSchema(cs, FormatOf(col.Field), col.Field.Name, true);
@@ -579,22 +600,29 @@ Status Executor::ExportBatch(const Batch& encoded, ArrowArray* outArray, ArrowSc
         ap->Children.push_back(ca);
 
         const int64_t n = col.Length;
-        auto download = [&](const void* dev, size_t bytes, void*& host) -> Status {
+        const HostColumnView* view = packed ? &views[ci] : nullptr;
+        // `bytes` of a buffer into host memory of its own: from the packed copy where there is one, else from the device
+        auto download = [&](const void* dev, const uint8_t* staged, size_t bytes, void*& host) -> Status {
             host = std::malloc(bytes + 8);
             if (!host) return Status::Invalid("out of host memory");
             cp->Owned.push_back(host);
-            if (bytes && dev) SSA_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+            if (view) {
+                if (bytes && staged) std::memcpy(host, staged, bytes);
+            } else if (bytes && dev) {
+                SSA_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+            }
             return Status::OK();
         };
         // validity
         void* vhost = nullptr;
         if (col.Validity) {
-            const size_t rawBytes = size_t((col.ValidBitOff + n + 7) / 8);
+            const int bitOff = view ? view->ValidBitOff : col.ValidBitOff;
+            const size_t rawBytes = size_t((bitOff + n + 7) / 8);
             void* raw = nullptr;
-            Status st = download(col.Validity->Ptr, rawBytes, raw);
+            Status st = download(col.Validity->Ptr, view ? view->Valid : nullptr, rawBytes, raw);
             if (!st.ok()) return fail(st);
-            if (col.ValidBitOff != 0) {
-                std::vector<uint8_t> re = RealignBits(static_cast<uint8_t*>(raw), col.ValidBitOff, n);
+            if (bitOff != 0) {
+                std::vector<uint8_t> re = RealignBits(static_cast<uint8_t*>(raw), bitOff, n);
                 std::memcpy(raw, re.data(), re.size());
             }
             vhost = raw;
@@ -608,13 +636,13 @@ Status Executor::ExportBatch(const Batch& encoded, ArrowArray* outArray, ArrowSc
         cp->Buffers.push_back(vhost);
         if (IsStringLike(col.Field.Type)) {
             void* offs = nullptr;
-            Status st = download(col.ValuesPtr(), size_t(n + 1) * 4, offs);
+            Status st = download(col.ValuesPtr(), view ? view->Values : nullptr, size_t(n + 1) * 4, offs);
             if (!st.ok()) return fail(st);
             int32_t* o = static_cast<int32_t*>(offs);
             if (n == 0 && !col.Values) o[0] = 0;
-            const int32_t first = o[0], last = o[n];
+            const int32_t first = o[0], last = o[n];  // (the packed offsets start at 0)
             void* chars = nullptr;
-            st = download(col.Chars ? static_cast<const char*>(col.Chars->Ptr) + first : nullptr, size_t(last - first), chars);
+            st = download(col.Chars ? static_cast<const char*>(col.Chars->Ptr) + first : nullptr, view ? view->Chars : nullptr, size_t(last - first), chars);
             if (!st.ok()) return fail(st);
             if (first != 0) {
                 for (int64_t i = 0; i <= n; ++i) o[i] -= first;
@@ -622,18 +650,19 @@ Status Executor::ExportBatch(const Batch& encoded, ArrowArray* outArray, ArrowSc
             cp->Buffers.push_back(offs);
             cp->Buffers.push_back(chars);
         } else if (col.Field.Type == T_BOOL) {
-            const size_t rawBytes = size_t((col.ValBitOff + n + 7) / 8);
+            const int bitOff = view ? view->ValBitOff : col.ValBitOff;
+            const size_t rawBytes = size_t((bitOff + n + 7) / 8);
             void* raw = nullptr;
-            Status st = download(col.Values ? col.Values->Ptr : nullptr, rawBytes, raw);
+            Status st = download(col.Values ? col.Values->Ptr : nullptr, view ? view->Values : nullptr, rawBytes, raw);
             if (!st.ok()) return fail(st);
-            if (col.ValBitOff != 0) {
-                std::vector<uint8_t> re = RealignBits(static_cast<uint8_t*>(raw), col.ValBitOff, n);
+            if (bitOff != 0) {
+                std::vector<uint8_t> re = RealignBits(static_cast<uint8_t*>(raw), bitOff, n);
                 std::memcpy(raw, re.data(), re.size());
             }
             cp->Buffers.push_back(raw);
         } else {
             void* vals = nullptr;
-            Status st = download(col.ValuesPtr(), size_t(n) * TypeWidth(col.Field.Type), vals);
+            Status st = download(col.ValuesPtr(), view ? view->Values : nullptr, size_t(n) * TypeWidth(col.Field.Type), vals);
             if (!st.ok()) return fail(st);
             cp->Buffers.push_back(vals);
         }

@@ -146,12 +146,27 @@ struct ManySlices {
     std::vector<int32_t> HostMap;
 };
 
+// Where the buffers of one column lie in the executor's pinned staging memory after Executor::PackToHost (valid until
+// the executor's next call).
+struct HostColumnView {
+    const uint8_t* Values = nullptr;  // fixed width: the rows' values; BOOL: the bytes that hold the rows' bits; strings: rows + 1 offsets from 0
+    size_t ValuesBytes = 0;
+    int ValBitOff = 0;                // BOOL: bit of row 0 inside the first byte
+    const uint8_t* Valid = nullptr;   // null: no validity
+    size_t ValidBytes = 0;
+    int ValidBitOff = 0;
+    const uint8_t* Chars = nullptr;   // strings: the bytes in use
+    size_t CharsBytes = 0;
+};
+
 class Executor {
 public:
     // A few words of pinned host memory: where small results (a scan's status, a group count, probed offsets) land
     // without the staging copy an asynchronous copy into pageable memory takes.
     int32_t* HostWords = nullptr;
     static constexpr int kHostWords = 64;
+    uint8_t* HostStaging = nullptr;  // pinned, kHostStagingBytes, allocated at the first PackToHost
+    static constexpr size_t kHostStagingBytes = size_t(1) << 20;
     explicit Executor(int device);
     ~Executor();
 
@@ -207,6 +222,10 @@ public:
     // of its buffers) and the size of the data; PackData fills the data, UnpackBatch makes a batch of views of it.
     Status PackedLayout(const Batch& in, std::vector<uint8_t>& header, uint64_t& dataBytes);
     Status PackData(const Batch& in, void* dst, size_t capacity);
+    // A small batch (a result of few groups) to the host in one copy: packed on the device, copied into pinned memory.
+    // `done` stays false for batches this does not take (large ones, dictionary or scalar columns): the caller copies
+    // those buffer by buffer.
+    Status PackToHost(const Batch& in, std::vector<HostColumnView>& views, bool& done);
     Status ConcatBatches(const std::vector<BatchPtr>& parts, BatchPtr& out);
 
     // TMergePartialStream::AddSource + DrainAll (ydb/core/formats/arrow/reader/merger.h:78-95): sources sorted by
@@ -219,6 +238,7 @@ public:
     Status Sync();
     hipStream_t Stream() const { return StreamHandle; }
     KernelProfile Profile;
+    void ProfileCollect();  // the time of the last timed launch into Profile (waits for it)
 
 private:
     Status ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
@@ -265,6 +285,8 @@ private:
     Status GatherRows(const Column& src, const BufferPtr& rowIdx, int64_t n, bool keepValidity, Column& dst);
     void ProfileBegin();
     void ProfileEnd(const char* kernel, int64_t algoBytes);
+    bool ProfilePending = false;  // a timed launch whose events have not been read yet
+    int64_t ProfilePendingBytes = 0;
 
     static constexpr int64_t kUniformKeysMinRows = 65536;  // below, the probe's host round trip outweighs the gain
     int Device;
