@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W [--workload q1|q1_codes|q1_dict|q6|mixed|cb_*] [--rows R]
 
 One step = one pass of the program (TPC-H Q1 by default: filter, two computed columns, nine aggregates
-grouped by (l_returnflag, l_linestatus)) over this rank's SF100 lineitem shard, result on the host.  With
+grouped by (l_returnflag, l_linestatus)) over this rank's SF100 lineitem shard, result on the host (the Arrow structs
+ssa_batch_export fills: what a C++ caller of the library holds).  With
 N > 1 (one process per GPU, launched by torch.distributed.run) every rank scans its own SF100-sized
 row range and the partial aggregates are merged through one RCCL all-gather plus a merge program, all
 inside the timed region; `value` is the rows all ranks scanned divided by the slowest rank's time.
@@ -254,7 +255,7 @@ def main():
         # the host with the GPU idle -- and the warm-up steps asked for come after them.
         for _ in range((3 if clickbench_run else 2) + warmup):
             for i, s in enumerate(scans_):
-                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device)
+                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device, lazy=True)
         for s in scans_:
             s.local.EnableProfile(True)
             s.local.ReadProfile()
@@ -268,7 +269,7 @@ def main():
         marks = [t0]
         for _ in range(steps):
             for i, s in enumerate(scans_):
-                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device)
+                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device, lazy=True)
             marks.append(time.perf_counter())
         barrier()
         elapsed = time.perf_counter() - t0

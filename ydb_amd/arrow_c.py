@@ -9,6 +9,7 @@ tests and the benchmark exercise exactly the boundary a C++ host shim would use.
 from __future__ import annotations
 
 import ctypes
+from collections.abc import Mapping
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -356,3 +357,41 @@ def read_batch(array: ArrowArray, schema: ArrowSchema, release: bool = True) -> 
         if schema.release:
             schema.release(ctypes.byref(schema))
     return out
+
+
+class ExportedBatch(Mapping):
+    """A batch the library exported -- Arrow C data interface structs in host memory, what a C++ caller of
+    ssa_batch_export holds -- that reads as the dictionary read_batch makes of it; the numpy copies are made when a
+    column is first looked at, and the structs released then (or when the object goes away unread)."""
+
+    def __init__(self, array: ArrowArray, schema: ArrowSchema):
+        self._array, self._schema, self._cols = array, schema, None
+
+    def columns(self) -> Dict[str, ResultColumn]:
+        if self._cols is None:
+            self._cols = read_batch(self._array, self._schema)
+            self._array = self._schema = None
+        return self._cols
+
+    @property
+    def rows(self) -> int:
+        if self._cols is None:
+            return int(self._array.length)
+        return len(next(iter(self._cols.values())).valid) if self._cols else 0
+
+    def __getitem__(self, key):
+        return self.columns()[key]
+
+    def __iter__(self):
+        return iter(self.columns())
+
+    def __len__(self):
+        return len(self.columns())
+
+    def __del__(self):
+        if self._cols is None and self._array is not None:
+            if self._array.release:
+                self._array.release(ctypes.byref(self._array))
+            if self._schema.release:
+                self._schema.release(ctypes.byref(self._schema))
+            self._array = self._schema = None

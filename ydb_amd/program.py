@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 import numpy as np
 
 from . import _lib
-from .arrow_c import ArrowArray, ArrowSchema, Col, HostBatch, ResultColumn, read_batch
+from .arrow_c import ArrowArray, ArrowSchema, Col, ExportedBatch, HostBatch, ResultColumn, read_batch
 from .ssa_pb import Program, olap_program
 
 
@@ -234,11 +234,13 @@ class ProgramContainer:
     def ColumnNames(self, batch: DeviceBatch) -> List[str]:
         return [_lib.take_string(self._lib, self._lib.ssa_batch_column_name(batch._h, i)) for i in range(batch.num_columns)]
 
-    def Export(self, batch: DeviceBatch) -> Dict[str, ResultColumn]:
+    def Export(self, batch: DeviceBatch, lazy: bool = False) -> Dict[str, ResultColumn]:
+        """The batch on the host.  `lazy`: as the Arrow structs ssa_batch_export filled (what a C++ caller holds), turned
+        into numpy arrays only when a column is looked at."""
         out_a, out_s, err = ArrowArray(), ArrowSchema(), ctypes.c_void_p()
         rc = self._lib.ssa_batch_export(self._h, batch._h, ctypes.byref(out_a), ctypes.byref(out_s), ctypes.byref(err))
         self._check(rc, err)
-        return read_batch(out_a, out_s)
+        return ExportedBatch(out_a, out_s) if lazy else read_batch(out_a, out_s)
 
     # -- compute sharding of a result batch (THashConstructor::BuildHashUI64 + TShardingSplitIndex) ------------
     @staticmethod

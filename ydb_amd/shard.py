@@ -307,24 +307,25 @@ class ShardedScan:
     # partial tables larger than this go through the hash-partitioned exchange
     ALL_TO_ALL_GROUPS = 65536
 
-    def run(self, batch, gather_device=None, exchange: str = "auto", keep_on_device: bool = False):
+    def run(self, batch, gather_device=None, exchange: str = "auto", keep_on_device: bool = False, lazy: bool = False):
         """Local scan (HBM-resident `batch`), then -- when torch.distributed is initialised with more than one rank --
         the exchange of the partial tables and the merge program.  exchange = "allgather": every rank ends with the
         whole result; "alltoall": every rank ends with the groups whose key hash it owns (their union is the result);
         "auto": all-to-all once any rank's partial table exceeds ALL_TO_ALL_GROUPS rows.  `gather_device`: where the
         collective's tensors live -- the GPU (RCCL), or the CPU when the process group is gloo (a rehearsal of several
-        ranks on one GPU): the packed parts then cross the host on their way."""
+        ranks on one GPU): the packed parts then cross the host on their way.  `lazy`: the result stays in the Arrow
+        structs the library exported to the host (ProgramContainer.Export)."""
         import torch.distributed as dist
 
         single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         if single:
             result = self.local.ApplyDevice(batch)
-            return result if keep_on_device else self.local.Export(result)  # one rank: nothing to exchange
+            return result if keep_on_device else self.local.Export(result, lazy)  # one rank: nothing to exchange
         if self.merge is None:
             raise ValueError("sharded scan without aggregation: results stay on their shards")
         partial = self.head.ApplyDevice(batch)
         merged = self.merge.ApplyDevice(self.exchange_device(partial, gather_device, exchange))
-        return merged if keep_on_device else self.merge.Export(merged)
+        return merged if keep_on_device else self.merge.Export(merged, lazy)
 
     @property
     def head(self):
