@@ -98,9 +98,14 @@ def shapes_blob(rows, seed):
     return sink.getvalue()
 
 
+@pytest.mark.parametrize("split", ["1", "0"], ids=["parse_and_copy_apart", "one_wave_does_both"])
 @pytest.mark.parametrize("rows,seed", [(120_000, 77), (50_001, 78), (700_000, 79)])
-def test_lz4_blocks_of_every_shape(rows, seed):
+def test_lz4_blocks_of_every_shape(rows, seed, split, monkeypatch):
+    """Both ways the library decodes LZ4 frames: the blocks parsed side by side into records and the frames' waves left
+    with the copies (the default), and one wave per frame doing both (what it falls back to without room for the
+    records; SSA_LZ4_SPLIT=0 asks for it)."""
     from oracle import ipc_oracle
+    monkeypatch.setenv("SSA_LZ4_SPLIT", split)
     schema = [("mixed", "int64"), ("text", "binary"), ("zeros", "int64"), ("sparse", "int32")]
     blob = shapes_blob(rows, seed)
     pc = container(schema)
@@ -116,8 +121,10 @@ def test_lz4_blocks_of_every_shape(rows, seed):
             assert np.array_equal(np.asarray(got[name]["values"]), np.asarray(exp[name]["values"])), name
 
 
-def test_zstd_is_declined_and_damage_is_an_error():
+@pytest.mark.parametrize("split", ["1", "0"], ids=["parse_and_copy_apart", "one_wave_does_both"])
+def test_zstd_is_declined_and_damage_is_an_error(split, monkeypatch):
     from ydb_amd import _lib
+    monkeypatch.setenv("SSA_LZ4_SPLIT", split)
     from ydb_amd.program import SsaError
     pc = container()
     with pytest.raises(SsaError) as e:

@@ -235,9 +235,34 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
         if (!blocks.empty()) {
             SSA_HIP(hipMemcpyAsync(dblocks->Ptr, blocks.data(), blocks.size() * sizeof(Lz4BlockRef), hipMemcpyHostToDevice, StreamHandle));
         }
+        // Room for the records of every block (a sequence per three compressed bytes at most): the parse then runs block by
+        // block side by side and the frames' waves are left with the copies.  Without that room (the records of highly
+        // compressible columns take twice the columns' own bytes) one wave does both, frame by frame.
+        const char* splitEnv = std::getenv("SSA_LZ4_SPLIT");  // (read at every import: a test runs both ways in one process)
+        const bool splitWanted = !(splitEnv && splitEnv[0] == '0');
+        std::vector<uint64_t> recStart(blocks.size() + 1, 0);
+        for (size_t g = 0; g < blocks.size(); ++g) recStart[g + 1] = recStart[g] + (blocks[g].Stored ? 0u : blocks[g].SrcBytes / 3u + 2u);
+        BufferPtr drecStart, drecs, dcounts;
+        if (splitWanted && !blocks.empty() && recStart.back() > 0 && recStart.back() * sizeof(Lz4Seq) <= (size_t(32) << 30)) {
+            drecStart = Buffer::Alloc(recStart.size() * 8);
+            dcounts = Buffer::Alloc(blocks.size() * sizeof(Lz4BlockSummary) + 64);
+            drecs = Buffer::Alloc(size_t(recStart.back()) * sizeof(Lz4Seq) + 64);
+            if (!drecStart || !dcounts || !drecs) {
+                (void)hipGetLastError();
+                drecs = nullptr;
+            }
+        }
         ProfileBegin();
-        SSA_HIP(LaunchLz4Decode(static_cast<const uint8_t*>(dblob->Ptr), static_cast<const Lz4FrameTask*>(dtasks->Ptr), int64_t(tasks.size()),
-                                static_cast<const Lz4BlockRef*>(dblocks->Ptr), static_cast<uint32_t*>(StatusWord->Ptr), StreamHandle));
+        if (drecs) {
+            SSA_HIP(hipMemcpyAsync(drecStart->Ptr, recStart.data(), recStart.size() * 8, hipMemcpyHostToDevice, StreamHandle));
+            SSA_HIP(LaunchLz4DecodeSplit(static_cast<const uint8_t*>(dblob->Ptr), static_cast<const Lz4FrameTask*>(dtasks->Ptr), int64_t(tasks.size()),
+                                         static_cast<const Lz4BlockRef*>(dblocks->Ptr), int64_t(blocks.size()), static_cast<const uint64_t*>(drecStart->Ptr),
+                                         static_cast<Lz4Seq*>(drecs->Ptr), static_cast<Lz4BlockSummary*>(dcounts->Ptr), static_cast<uint32_t*>(StatusWord->Ptr),
+                                         StreamHandle));
+        } else {
+            SSA_HIP(LaunchLz4Decode(static_cast<const uint8_t*>(dblob->Ptr), static_cast<const Lz4FrameTask*>(dtasks->Ptr), int64_t(tasks.size()),
+                                    static_cast<const Lz4BlockRef*>(dblocks->Ptr), static_cast<uint32_t*>(StatusWord->Ptr), StreamHandle));
+        }
         int64_t produced = 0;
         for (auto& t : tasks) produced += int64_t(t.dst_bytes);
         ProfileEnd("Lz4DecodeKernel", produced);

@@ -277,11 +277,320 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
     if ((bad || op != total) && lane == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
 }
 
+
+// ---- the same decode split in two: the parse of all blocks side by side, then the copies frame by frame -------------
+// The parse of a block needs nothing but the block (tokens, lengths, offsets); only the copies chain through the frame
+// (a match may read what the previous block wrote).  Lz4ParseKernel gives every block a wave and writes one record per
+// sequence; Lz4CopyKernel walks a frame's records in order and is left with the copies: four v_readlane per sequence
+// instead of the token arithmetic.
+
+constexpr uint32_t kSeqSlow = 0x80000000u;      // Lz4Seq::lit: not the common shape (literals outside the record, or more than 64 bytes in all)
+constexpr uint32_t kSeqExternal = 0x40000000u;  // the literals are not in the record (lo = where they start in the block)
+constexpr uint32_t kSeqOverlap = 0x20000000u;   // the match is longer than its offset: a pattern of `offset` bytes repeated
+constexpr uint32_t kSeqCount = 0x00FFFFFFu;
+
+__global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const Lz4BlockRef* blocks, const uint64_t* recStart, Lz4Seq* recs,
+                                                    Lz4BlockSummary* summaries, uint32_t* status) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    const Lz4BlockRef blk = blocks[g];
+    const uint8_t* src = blob + blk.Src;
+    const uint32_t n = blk.SrcBytes;
+    if (blk.Stored || n == 0) {
+        if (lane == 0) summaries[g] = Lz4BlockSummary{0, 0, 0, 0};
+        return;
+    }
+    Lz4Seq* out = recs + recStart[g];
+    const uint32_t cap = n / 3u + 2u;  // (a sequence with a match takes three bytes at least, the last one at least one)
+    uint32_t k = 0;
+    uint32_t produced = 0;  // bytes the block's sequences so far decode to
+    uint32_t reachesBack = 0;  // how far before the block's first byte its matches read (0: the block stands alone)
+    bool bad = false;
+    auto emit = [&](uint32_t lit, uint32_t match, uint32_t lo, uint32_t hi) {
+        if (k >= cap) {
+            bad = true;
+            return;
+        }
+        if (lane == 0) out[k] = Lz4Seq{lit, match, lo, hi};
+        ++k;
+    };
+    // every match: its offset is checked here, against the bytes the block itself has produced, so that the copy kernel
+    // checks a block once (its size, and how far it reaches back) instead of every sequence
+    auto account = [&](uint32_t lit, uint32_t ml, uint32_t off) {
+        if (lit > 0x7FFFFFFFu - produced) {
+            bad = true;
+            return;
+        }
+        produced += lit;
+        if (ml != 0) {
+            if (off == 0 || ml > 0x7FFFFFFFu - produced) {
+                bad = true;
+                return;
+            }
+            if (off > produced && off - produced > reachesBack) reachesBack = off - produced;
+            produced += ml;
+        }
+    };
+    // (the window over the compressed bytes: as in Lz4DecodeKernel)
+    const uint32_t skew = uint32_t(reinterpret_cast<uintptr_t>(src) & 3u);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(src - skew);
+    const uint32_t lastWord = (skew + n - 1u) >> 2;
+    auto load = [&](uint32_t first) -> uint32_t {
+        const uint32_t i = first + lane;
+        return words[i < lastWord ? i : lastWord];
+    };
+    uint32_t wbase = 0;
+    uint32_t A = load(0), B = load(64);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto rebase = [&](uint32_t d) {
+        const uint32_t s = d - wbase;
+        if (s < 64u) {
+            const uint32_t j = (lane + s) & 63u;
+            const uint32_t a = uint32_t(__shfl(int(A), int(j))), c = uint32_t(__shfl(int(B), int(j)));
+            A = lane + s < 64u ? a : c;
+        } else {
+            A = load(d);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        B = load(d + 64u);
+        wbase = d;
+    };
+    auto fetch = [&](uint32_t at, uint64_t& w0, uint32_t& w1) {
+        const uint32_t y = skew + at;
+        uint32_t r = (y >> 2) - wbase;
+        if (r > 60u) {
+            rebase(y >> 2);
+            r = 0;
+        }
+        const uint32_t x0 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r)));
+        const uint32_t x1 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 1u)));
+        const uint32_t x2 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 2u)));
+        const uint32_t x3 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 3u)));
+        const uint32_t sh = 8u * (y & 3u);
+        const uint32_t b0 = uint32_t((uint64_t(x0) | (uint64_t(x1) << 32)) >> sh);
+        const uint32_t b1 = uint32_t((uint64_t(x1) | (uint64_t(x2) << 32)) >> sh);
+        w1 = uint32_t((uint64_t(x2) | (uint64_t(x3) << 32)) >> sh);
+        w0 = uint64_t(b0) | (uint64_t(b1) << 32);
+    };
+    uint32_t ip = 0;
+    auto readLength = [&](uint32_t& len) {
+        for (;;) {
+            if (ip >= n) {
+                bad = true;
+                return;
+            }
+            uint64_t a;
+            uint32_t unused;
+            fetch(ip, a, unused);
+            for (int q = 0; q < 8; ++q) {
+                if (ip >= n) {
+                    bad = true;
+                    return;
+                }
+                const uint32_t x = uint32_t(a) & 0xFFu;
+                a >>= 8;
+                ++ip;
+                len += x;
+                if (x != 255u) return;
+            }
+        }
+    };
+    while (ip < n && !bad) {
+        uint64_t w0;
+        uint32_t w1;
+        fetch(ip, w0, w1);
+        const uint32_t token = uint32_t(w0) & 0xFFu;
+        const uint32_t fl = token >> 4;
+        if (fl <= 8u && (token & 15u) != 15u && ip + 3u + fl <= n) {  // the record holds the literals themselves
+            const uint64_t mid = (w0 >> 32) | (uint64_t(w1) << 32);  // bytes 4..11
+            const uint32_t p = 8u * (1u + fl);
+            const uint32_t off = uint32_t(p <= 48u ? w0 >> p : mid >> (p - 32u)) & 0xFFFFu;
+            const uint32_t fm = (token & 15u) + 4u;
+            const uint64_t lits = (w0 >> 8) | (uint64_t(w1) << 56);  // bytes 1..8
+            account(fl, fm, off);
+            emit(fl | (off < fm ? kSeqOverlap : 0u), fm | (off << 16), uint32_t(lits), uint32_t(lits >> 32));
+            ip += 3u + fl;
+            continue;
+        }
+        ++ip;
+        uint32_t lit = fl;
+        if (lit == 15u) readLength(lit);
+        if (bad || lit > n - ip || lit > kSeqCount) {
+            bad = true;
+            break;
+        }
+        const uint32_t litAt = ip;
+        ip += lit;
+        if (ip >= n) {  // the last sequence of a block is literals only
+            account(lit, 0, 0);
+            emit(lit | kSeqSlow | kSeqExternal, 0, litAt, 0);
+            break;
+        }
+        if (n - ip < 2) {
+            bad = true;
+            break;
+        }
+        fetch(ip, w0, w1);
+        const uint32_t off = uint32_t(w0) & 0xFFFFu;
+        ip += 2;
+        uint32_t ml = token & 15u;
+        if (ml == 15u) readLength(ml);
+        if (bad) break;
+        ml += 4;
+        account(lit, ml, off);
+        // (a record's match length has sixteen bits: a longer match is as many records, each reading `off` bytes back)
+        uint32_t piece = ml < 65535u ? ml : 65535u;
+        emit(lit | kSeqSlow | kSeqExternal, piece | (off << 16), litAt, 0);
+        for (ml -= piece; ml > 0 && !bad; ml -= piece) {
+            piece = ml < 65535u ? ml : 65535u;
+            emit(kSeqSlow, piece | (off << 16), 0, 0);
+        }
+    }
+    if (lane == 0) {
+        summaries[g] = bad ? Lz4BlockSummary{0, 0, 0, 0} : Lz4BlockSummary{k, produced, reachesBack, 0};
+        if (bad) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
+    }
+}
+
+__global__ __launch_bounds__(64) void Lz4CopyKernel(const uint8_t* blob, const Lz4FrameTask* tasks, const Lz4BlockRef* blocks, const uint64_t* recStart,
+                                                   const Lz4Seq* recs, const Lz4BlockSummary* summaries, uint32_t* status) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    const uint32_t lane = threadIdx.x;
+    const Lz4FrameTask t = tasks[blockIdx.x];
+    __attribute__((address_space(1))) uint8_t* dst = (__attribute__((address_space(1))) uint8_t*)t.dst;
+    const uint32_t total = uint32_t(t.dst_bytes);
+    uint32_t op = 0;
+    bool bad = false;
+    for (uint32_t b = 0; b < t.nblocks && !bad; ++b) {
+        const uint64_t g = t.first_block + b;
+        const Lz4BlockRef blk = blocks[g];
+        const uint8_t* src = blob + blk.Src;
+        const uint32_t n = blk.SrcBytes;
+        if (n == 0) continue;
+        if (blk.Stored) {
+            if (n > total - op) {
+                bad = true;
+                break;
+            }
+            for (uint32_t base = 0; base < n; base += 1024) {
+                uint8_t x[16];
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) {
+                    const uint32_t i = base + q * 64 + lane;
+                    x[q] = i < n ? src[i] : uint8_t(0);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) {
+                    const uint32_t i = base + q * 64 + lane;
+                    if (i < n) {
+                        ring[(op + i) & (kRing - 1)] = x[q];
+                        dst[op + i] = x[q];
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            op += n;
+            continue;
+        }
+        const Lz4BlockSummary sum = summaries[g];
+        // the parse has checked every sequence against the block itself: what is left is the block against the frame --
+        // its bytes fit, and its matches reach back no further than the frame's bytes before it (none, if blocks stand alone)
+        if (sum.Sequences == 0 || sum.Bytes > total - op || sum.ReachesBack > (t.linked ? op : 0u)) {
+            bad = true;
+            break;
+        }
+        const uint32_t nrec = sum.Sequences;
+        const uint4* rec = reinterpret_cast<const uint4*>(recs + recStart[g]);
+        // sixty-four records at a time, one per lane; the next sixty-four are on their way meanwhile
+        uint4 next = lane < nrec ? rec[lane] : uint4{0, 0, 0, 0};
+        for (uint32_t k0 = 0; k0 < nrec; k0 += 64) {
+            const uint4 cur = next;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            next = k0 + 64u + lane < nrec ? rec[k0 + 64u + lane] : uint4{0, 0, 0, 0};
+            const uint32_t m = nrec - k0 < 64u ? nrec - k0 : 64u;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t x0 = uint32_t(__builtin_amdgcn_readlane(int(cur.x), int(j)));
+                const uint32_t x1 = uint32_t(__builtin_amdgcn_readlane(int(cur.y), int(j)));
+                const uint32_t x2 = uint32_t(__builtin_amdgcn_readlane(int(cur.z), int(j)));
+                const uint32_t x3 = uint32_t(__builtin_amdgcn_readlane(int(cur.w), int(j)));
+                const uint32_t lit = x0 & kSeqCount, ml = x1 & 0xFFFFu, off = x1 >> 16;
+                const uint32_t mp = op + lit;  // where the match lands
+                if (!(x0 & kSeqSlow)) {
+                    // At most eight literals and a match of at most 19 bytes, written by one lane each in one step: a literal
+                    // comes out of the record, a match byte out of the ring -- or out of the record too, where the match
+                    // reaches back into the literals of its own sequence.
+                    const uint64_t lits = uint64_t(x2) | (uint64_t(x3) << 32);
+                    const uint32_t mi = lane - lit;
+                    uint32_t r = mi;
+                    if (x0 & kSeqOverlap) {  // mi mod off (mi < 19: the rounded quotient is exact)
+                        r = mi - __umul24(uint32_t((float(int(mi)) + 0.5f) * __builtin_amdgcn_rcpf(float(off))), off);
+                    }
+                    const uint32_t back = off - r;  // bytes before the match's start
+                    const bool literal = lane < lit || back <= lit;
+                    const uint32_t li = lane < lit ? lane : lit - back;
+                    const uint8_t fromWords = uint8_t(lits >> (8u * (li & 7u)));
+                    const uint8_t fromRing = ring[(mp - back) & (kRing - 1)];
+                    if (lane < lit + ml) {
+                        const uint8_t x = literal ? fromWords : fromRing;
+                        ring[(op + lane) & (kRing - 1)] = x;
+                        dst[op + lane] = x;
+                    }
+                    op = mp + ml;
+                    continue;
+                }
+                if (x0 & kSeqExternal) {
+                    for (uint32_t base = 0; base < lit; base += 64) {
+                        const uint32_t i = base + lane;
+                        const uint8_t x = i < lit ? src[x2 + i] : uint8_t(0);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (i < lit) {
+                            ring[(op + i) & (kRing - 1)] = x;
+                            dst[op + i] = x;
+                        }
+                    }
+                }
+                op = mp;
+                if (off >= 64) {
+                    for (uint32_t base = 0; base < ml; base += 64) {
+                        const uint32_t i = base + lane;
+                        if (i < ml) {
+                            const uint8_t x = ring[(op + i - off) & (kRing - 1)];
+                            ring[(op + i) & (kRing - 1)] = x;
+                            dst[op + i] = x;
+                        }
+                    }
+                } else if (ml != 0) {
+                    for (uint32_t base = 0; base < ml; base += 64) {
+                        const uint32_t i = base + lane;
+                        if (i < ml) {
+                            const uint8_t x = ring[(op - off + (i % off)) & (kRing - 1)];
+                            ring[(op + i) & (kRing - 1)] = x;
+                            dst[op + i] = x;
+                        }
+                    }
+                }
+                op += ml;
+            }
+        }
+    }
+    if ((bad || op != total) && lane == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
+}
+
 }  // namespace
 
 hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t* status, hipStream_t st) {
     if (ntasks <= 0) return hipSuccess;
     hipLaunchKernelGGL(Lz4DecodeKernel, dim3(uint32_t(ntasks)), dim3(64), 0, st, blob, tasks, blocks, status);
+    return hipGetLastError();
+}
+
+hipError_t LaunchLz4DecodeSplit(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, int64_t nblocks,
+                                const uint64_t* recStart, Lz4Seq* recs, Lz4BlockSummary* summaries, uint32_t* status, hipStream_t st) {
+    if (ntasks <= 0 || nblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(Lz4ParseKernel, dim3(uint32_t(nblocks)), dim3(64), 0, st, blob, blocks, recStart, recs, summaries, status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(Lz4CopyKernel, dim3(uint32_t(ntasks)), dim3(64), 0, st, blob, tasks, blocks, recStart, recs, summaries, status);
     return hipGetLastError();
 }
 
