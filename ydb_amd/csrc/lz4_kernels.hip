@@ -3,13 +3,16 @@
 // The format is the published LZ4 frame / block format (lz4_Frame_format.md, lz4_Block_format.md; the reference
 // vendors the library as contrib/libs/lz4 and reaches it through arrow::util::Codec, serializer/native.h:54-57).  Arrow
 // writes every buffer as one frame of 64 KB blocks that may refer back into the previous block ("linked" blocks), so
-// a frame decodes front to back.  One wavefront takes one frame: the token stream is parsed by the whole wave in
+// the copies of a frame go front to back; the parse of a block needs nothing but the block.  Two ways of decoding follow.
+// Lz4DecodeKernel: one wavefront takes one frame and does both -- the token stream is parsed by the whole wave in
 // lockstep out of registers (wave-uniform scalars), and the bytes of every literal run and every match are copied by
-// the 64 lanes side by side.  The last 64 KB of output live in an LDS ring,
-// which is where matches read from (LDS accesses of one wave complete in issue order, so a match sees the bytes
-// earlier sequences wrote); every byte goes to the ring and to the output buffer in HBM, 64 consecutive bytes per
-// store instruction.  Parallelism across frames comes from the grid: a blob has up to three buffers per column, a
-// portion many blobs.  Bound: latency of the serial token chain, not HBM.
+// the 64 lanes side by side.  The last 64 KB of output live in an LDS ring, which is where matches read from (LDS
+// accesses of one wave complete in issue order, so a match sees the bytes earlier sequences wrote); every byte goes to
+// the ring and to the output buffer in HBM, 64 consecutive bytes per store instruction.
+// Lz4ParseKernel + Lz4CopyKernel (the default, given room for the records): every block is parsed by a wavefront of its
+// own into one record per sequence, then one wavefront per frame walks the records and does the copies as above.
+// Parallelism across frames comes from the grid: a blob has up to three buffers per column, a portion many blobs.
+// Bound: the serial chain of a frame's copies (instructions per sequence of one wave), not HBM.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
