@@ -290,7 +290,13 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
 constexpr uint32_t kSeqSlow = 0x80000000u;      // Lz4Seq::lit: not the common shape (literals outside the record, or more than 64 bytes in all)
 constexpr uint32_t kSeqExternal = 0x40000000u;  // the literals are not in the record (lo = where they start in the block)
 constexpr uint32_t kSeqOverlap = 0x20000000u;   // the match is longer than its offset: a pattern of `offset` bytes repeated
+constexpr uint32_t kSeqFar = 0x10000000u;       // the match reads further back than the copy kernel's ring reaches: from the output itself
 constexpr uint32_t kSeqCount = 0x00FFFFFFu;
+// The copy kernel keeps the last 32 KB of a frame's output in LDS, so that four frames share a CU; the few matches that
+// read further back (an offset has 16 bits) take their bytes from the output in HBM.  kCopyNear: the largest offset the
+// ring serves, whatever the piece of the sequence that is being copied (64 bytes at most at a time).
+constexpr uint32_t kCopyRing = 32768;
+constexpr uint32_t kCopyNear = kCopyRing - 128;
 
 __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const Lz4BlockRef* blocks, const uint64_t* recStart, Lz4Seq* recs,
                                                     Lz4BlockSummary* summaries, uint32_t* status) {
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
             const uint32_t fm = (token & 15u) + 4u;
             const uint64_t lits = (w0 >> 8) | (uint64_t(w1) << 56);  // bytes 1..8
             account(fl, fm, off);
-            emit(fl | (off < fm ? kSeqOverlap : 0u), fm | (off << 16), uint32_t(lits), uint32_t(lits >> 32));
+            emit(fl | (off < fm ? kSeqOverlap : 0u) | (off > kCopyNear ? kSeqSlow | kSeqFar : 0u), fm | (off << 16), uint32_t(lits), uint32_t(lits >> 32));
             ip += 3u + fl;
             continue;
         }
@@ -443,10 +449,11 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
         account(lit, ml, off);
         // (a record's match length has sixteen bits: a longer match is as many records, each reading `off` bytes back)
         uint32_t piece = ml < 65535u ? ml : 65535u;
-        emit(lit | kSeqSlow | kSeqExternal, piece | (off << 16), litAt, 0);
+        const uint32_t far = off > kCopyNear ? kSeqFar : 0u;
+        emit(lit | kSeqSlow | kSeqExternal | far, piece | (off << 16), litAt, 0);
         for (ml -= piece; ml > 0 && !bad; ml -= piece) {
             piece = ml < 65535u ? ml : 65535u;
-            emit(kSeqSlow, piece | (off << 16), 0, 0);
+            emit(kSeqSlow | far, piece | (off << 16), 0, 0);
         }
     }
     if (lane == 0) {
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
 
 __global__ __launch_bounds__(64) void Lz4CopyKernel(const uint8_t* blob, const Lz4FrameTask* tasks, const Lz4BlockRef* blocks, const uint64_t* recStart,
                                                    const Lz4Seq* recs, const Lz4BlockSummary* summaries, uint32_t* status) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kCopyRing];
     const uint32_t lane = threadIdx.x;
     const Lz4FrameTask t = tasks[blockIdx.x];
     __attribute__((address_space(1))) uint8_t* dst = (__attribute__((address_space(1))) uint8_t*)t.dst;
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(64) void Lz4CopyKernel(const uint8_t* blob, const L
                 for (uint32_t q = 0; q < 16; ++q) {
                     const uint32_t i = base + q * 64 + lane;
                     if (i < n) {
-                        ring[(op + i) & (kRing - 1)] = x[q];
+                        ring[(op + i) & (kCopyRing - 1)] = x[q];
                         dst[op + i] = x[q];
                     }
                 }
@@ -532,10 +539,10 @@ __global__ __launch_bounds__(64) void Lz4CopyKernel(const uint8_t* blob, const L
                     const bool literal = lane < lit || back <= lit;
                     const uint32_t li = lane < lit ? lane : lit - back;
                     const uint8_t fromWords = uint8_t(lits >> (8u * (li & 7u)));
-                    const uint8_t fromRing = ring[(mp - back) & (kRing - 1)];
+                    const uint8_t fromRing = ring[(mp - back) & (kCopyRing - 1)];
                     if (lane < lit + ml) {
                         const uint8_t x = literal ? fromWords : fromRing;
-                        ring[(op + lane) & (kRing - 1)] = x;
+                        ring[(op + lane) & (kCopyRing - 1)] = x;
                         dst[op + lane] = x;
                     }
                     op = mp + ml;
@@ -547,27 +554,49 @@ __global__ __launch_bounds__(64) void Lz4CopyKernel(const uint8_t* blob, const L
                         const uint8_t x = i < lit ? src[x2 + i] : uint8_t(0);
                         __builtin_amdgcn_s_waitcnt(0x0F70);
                         if (i < lit) {
-                            ring[(op + i) & (kRing - 1)] = x;
+                            ring[(op + i) & (kCopyRing - 1)] = x;
                             dst[op + i] = x;
                         }
                     }
+                } else if (lane < lit) {  // (at most eight, in the record)
+                    const uint8_t x = uint8_t((uint64_t(x2) | (uint64_t(x3) << 32)) >> (8u * lane));
+                    ring[(op + lane) & (kCopyRing - 1)] = x;
+                    dst[op + lane] = x;
                 }
                 op = mp;
-                if (off >= 64) {
+                if (x0 & kSeqFar) {
+                    // further back than the ring reaches: the bytes are in the output, written at least 32 KB ago -- their
+                    // cache lines were complete before anything read them, the stores before this read are waited for
+                    for (uint32_t base = 0; base < ml; base += 64) {
+                        const uint32_t i = base + lane;
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        const uint8_t x = i < ml ? dst[op + i - off] : uint8_t(0);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (i < ml) {
+                            ring[(op + i) & (kCopyRing - 1)] = x;
+                            dst[op + i] = x;
+                        }
+                    }
+                } else if (off >= 64) {
                     for (uint32_t base = 0; base < ml; base += 64) {
                         const uint32_t i = base + lane;
                         if (i < ml) {
-                            const uint8_t x = ring[(op + i - off) & (kRing - 1)];
-                            ring[(op + i) & (kRing - 1)] = x;
+                            const uint8_t x = ring[(op + i - off) & (kCopyRing - 1)];
+                            ring[(op + i) & (kCopyRing - 1)] = x;
                             dst[op + i] = x;
                         }
                     }
                 } else if (ml != 0) {
+                    // The match overlaps its own output: a pattern of `off` bytes repeated.  The first 128 bytes are taken
+                    // from the pattern before the match; further on (a match may be longer than the ring, which by then
+                    // no longer holds those bytes) from the match's own output, a whole number of periods back.
+                    const uint32_t periods = off * ((63u + off) / off);  // the least multiple of off that is 64 or more
                     for (uint32_t base = 0; base < ml; base += 64) {
                         const uint32_t i = base + lane;
                         if (i < ml) {
-                            const uint8_t x = ring[(op - off + (i % off)) & (kRing - 1)];
-                            ring[(op + i) & (kRing - 1)] = x;
+                            const uint32_t from = i < 128u ? op - off + (i % off) : op + i - periods;
+                            const uint8_t x = ring[from & (kCopyRing - 1)];
+                            ring[(op + i) & (kCopyRing - 1)] = x;
                             dst[op + i] = x;
                         }
                     }
