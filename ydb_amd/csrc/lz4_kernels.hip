@@ -10,7 +10,8 @@
 // accesses of one wave complete in issue order, so a match sees the bytes earlier sequences wrote); every byte goes to
 // the ring and to the output buffer in HBM, 64 consecutive bytes per store instruction.
 // Lz4ParseKernel + Lz4CopyKernel (the default, given room for the records): every block is parsed by a wavefront of its
-// own into one record per sequence, then one wavefront per frame walks the records and does the copies as above.
+// own into one record per sequence, then one wavefront per frame walks the records and does the copies as above (with
+// a ring of 32 KB: four frames to a CU; matches that read further back take their bytes from the output).
 // Parallelism across frames comes from the grid: a blob has up to three buffers per column, a portion many blobs.
 // Bound: the serial chain of a frame's copies (instructions per sequence of one wave), not HBM.
 #include <hip/hip_runtime.h>
