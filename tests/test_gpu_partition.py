@@ -1,7 +1,8 @@
-"""GROUP BY whose rows that miss the workgroups' own tables are written out as records, sorted by region of the table
-in HBM and applied region by region inside LDS (what groupings of a million groups and more do by themselves; forced
-here on small inputs with SSA_KEYED_PARTITION=1, with regions of the size LDS allows -- one round of the sort -- and of
-64 slots -- two rounds).  Every result must equal the CPU oracle's and the row-by-row path's."""
+"""GROUP BY whose rows that miss the workgroups' own tables are written out as records, sorted by region and aggregated
+region by region inside LDS -- emitted from there straight into the output columns, or (SSA_KEYED_EMIT=0) applied to a
+table in HBM -- which is what groupings of a million groups and more do by themselves; forced here on small inputs with
+SSA_KEYED_PARTITION=1, with regions of the size LDS allows -- one round of the sort -- and of 64 slots -- two rounds.
+Every result must equal the CPU oracle's and the row-by-row path's."""
 import ctypes
 
 import numpy as np
@@ -18,6 +19,12 @@ pytestmark = pytest.mark.gpu
 def region_slots(request, monkeypatch):
     if request.param is not None:
         monkeypatch.setenv("SSA_KEYED_REGION", request.param)
+    return request.param
+
+
+@pytest.fixture(params=["1", "0"], ids=["emitted_from_lds", "table_in_hbm"], autouse=True)
+def emit_mode(request, monkeypatch):
+    monkeypatch.setenv("SSA_KEYED_EMIT", request.param)
     return request.param
 
 
@@ -171,6 +178,26 @@ def test_some_takes_the_first_row_of_each_group(monkeypatch):
     region, direct, oracle = run_three_ways(monkeypatch, res, p, batch)
     compare_batches(region, direct, key_names=["k"])
     compare_batches(region, oracle, key_names=["k"])
+
+
+def test_more_groups_than_the_last_scan_found(monkeypatch):
+    """The output columns of the region pass are sized by the step's last scan: a batch with many times the groups
+    runs the pass again with longer ones."""
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    monkeypatch.setenv("SSA_JIT", "1")
+    monkeypatch.setenv("SSA_KEYED_PARTITION", "1")
+    rng = np.random.default_rng(510)
+    few = {"k": rng.integers(0, 500, 100_000).astype(np.int64), "v": rng.integers(0, 100, 100_000).astype(np.int32)}
+    many = {"k": rng.integers(0, 1 << 40, 400_000).astype(np.int64), "v": rng.integers(0, 100, 400_000).astype(np.int32)}
+    p = Program().group_by([Aggregate(100, AGG.COUNT, []), Aggregate(101, AGG.SUM, [2])], keys=[1])
+    res = [(1, "k"), (2, "v")]
+    pc = ProgramContainer()
+    ok, err = pc.Init(res, p)
+    assert ok, err
+    for batch in (few, few, many, few, many):
+        got = pc.Export(pc.ApplyDevice(pc.Import(batch)))
+        compare_batches(got, ssa_oracle.Oracle(res, p).apply(batch), key_names=["k"])
 
 
 def test_large_grouping_takes_the_region_pass_by_itself(monkeypatch, region_slots):

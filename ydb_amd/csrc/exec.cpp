@@ -168,7 +168,8 @@ Executor::Executor(int device) : Device(device) {
     (void)hipEventCreate(&EvTuneB);
     (void)hipEventCreate(&EvStop);
     // dynamic LDS the scan kernels may ask for: everything but 1 KiB kept for their static arrays
-    const hipError_t cfgErr = ConfigureScanKernels(160 * 1024 - 1024);
+    hipError_t cfgErr = ConfigureScanKernels(160 * 1024 - 1024);
+    if (cfgErr == hipSuccess) cfgErr = ConfigureRegionKernels(128 * 1024);
     if (cfgErr != hipSuccess) std::fprintf(stderr, "ydb_ssa_hip: cannot raise the LDS limit of the scan kernels: %s\n", hipGetErrorString(cfgErr));
     StatusWord = Buffer::Alloc(256);
     if (StatusWord) (void)hipMemset(StatusWord->Ptr, 0, 256);
@@ -2003,7 +2004,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     // slots of a region: what one workgroup holds in 48 KB of LDS (SSA_KEYED_REGION / SSA_KEYED_REGION_KB: experiments and tests)
     int regionSlots = 4096;
     size_t regionLds = 48 * 1024;
-    if (const char* env = std::getenv("SSA_KEYED_REGION_KB")) regionLds = size_t(std::max(8, std::min(64, std::atoi(env)))) * 1024;
+    if (const char* env = std::getenv("SSA_KEYED_REGION_KB")) regionLds = size_t(std::max(8, std::min(128, std::atoi(env)))) * 1024;
     while (regionSlots > 256 && size_t(regionSlots) * (8 + (twoWords ? 8 : 0) + (hashed ? 8 : 0) + 8 * size_t(naggs) + 4) > regionLds) regionSlots >>= 1;
     if (const char* env = std::getenv("SSA_KEYED_REGION")) {
         const int r = std::atoi(env);
@@ -2043,6 +2044,12 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
     }
     uint64_t totalCap = 0;
+    // A scan that leaves records: its groups are built region by region in LDS and emitted from there (RegionEmitKernel),
+    // unless SSA_KEYED_EMIT=0 asks for the table in HBM brought up to date region by region (RegionApplyKernel).
+    const bool emitWanted = !(std::getenv("SSA_KEYED_EMIT") && std::atoi(std::getenv("SSA_KEYED_EMIT")) == 0);
+    bool emitNow = false, emitted = false;
+    int ldsSlots = 0, smallSlots = 0;
+    uint64_t regionCount = 0;
     // Groups per tile of table slots, scanned: where each tile's groups go in the output, and how many there are (the
     // count arrives with the next synchronisation of the stream).
     int64_t ntilesT = 0;
@@ -2067,38 +2074,81 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
         return Status::OK();
     };
+    // The output columns, with room for `rowsCap` groups, and what the kernels that fill them need to know (`fa`; the table
+    // it reads, where there is one, is set by the caller).
+    KeyedFinalizeArgs fa{};
+    std::vector<Column> aggCols, keyCols;
+    std::vector<BufferPtr> aggValid, aggRowIdx, keyValid;
+    BufferPtr repRows;
+    auto prepareOutputs = [&](int64_t rowsCap) -> Status {
+        fa = KeyedFinalizeArgs{};
+        fa.naggs = naggsUser;
+        fa.nkeys = nkeys;
+        fa.two_words = twoWords;
+        fa.hashed = hashed;
+        aggCols.assign(size_t(naggsUser), Column{});
+        keyCols.assign(size_t(nkeys), Column{});
+        aggValid.assign(size_t(naggsUser), nullptr);
+        aggRowIdx.assign(size_t(naggsUser), nullptr);
+        keyValid.assign(size_t(nkeys), nullptr);
+        if (hashed) {
+            repRows = Buffer::Alloc(size_t(rowsCap) * 8 + 16);
+            if (!repRows) return Status::Hip("out of device memory");
+            fa.group_rep_row = static_cast<uint64_t*>(repRows->Ptr);
+        }
+        for (int k = 0; k < naggsUser; ++k) {
+            const AggPlan& ap = plan.Aggs[size_t(k)];
+            fa.aggs[k] = ap.Spec;
+            fa.agg_src[k] = aggSrc[size_t(k)];
+            fa.agg_nan_src[k] = ap.NanTag >= 0 ? aggSrc[size_t(ap.NanTag)] : -1;
+            fa.agg_zero_src[k] = ap.ZeroTag >= 0 ? aggSrc[size_t(ap.ZeroTag)] : -1;
+            Column& col = aggCols[size_t(k)];
+            col.Field.Type = ap.OutType;
+            col.Length = rowsCap;
+            fa.agg_out_type[k] = ap.OutType == T_DEC128 ? int32_t(T_U64) : ap.OutType;  // decimal: the low-part sum
+            if (ap.SomeInputColumn >= 0) {
+                aggRowIdx[size_t(k)] = Buffer::Alloc(size_t(rowsCap) * 8 + 16);
+                if (!aggRowIdx[size_t(k)]) return Status::Hip("out of device memory");
+                fa.agg_row_index[k] = 1;
+                fa.agg_vals[k] = aggRowIdx[size_t(k)]->Ptr;
+                continue;
+            }
+            col.Values = Buffer::Alloc(size_t(rowsCap) * 8 + 16);
+            if (!col.Values) return Status::Hip("out of device memory");
+            fa.agg_vals[k] = col.Values->Ptr;
+            if (ap.Spec.kind != AGG_COUNT && ap.Spec.check_valid) {
+                aggValid[size_t(k)] = Buffer::Alloc(size_t(rowsCap) + 16);
+                if (!aggValid[size_t(k)]) return Status::Hip("out of device memory");
+                fa.agg_valid_bytes[k] = static_cast<uint8_t*>(aggValid[size_t(k)]->Ptr);
+            }
+        }
+        for (int k = 0; k < nkeys; ++k) {
+            fa.keys[k] = sink.keys[k];
+            if (hashed) continue;
+            const KeyPlan& kp = plan.Keys[size_t(k)];
+            Column& col = keyCols[size_t(k)];
+            col.Field.Type = kp.Spec.type;
+            col.Length = rowsCap;
+            col.Values = Buffer::Alloc(size_t(rowsCap) * TypeWidth(kp.Spec.type) + 16);
+            if (!col.Values) return Status::Hip("out of device memory");
+            fa.key_vals[k] = col.Values->Ptr;
+            if (kp.Spec.nullable) {
+                keyValid[size_t(k)] = Buffer::Alloc(size_t(rowsCap) + 16);
+                if (!keyValid[size_t(k)]) return Status::Hip("out of device memory");
+                fa.key_valid_bytes[k] = static_cast<uint8_t*>(keyValid[size_t(k)]->Ptr);
+            }
+        }
+        return Status::OK();
+    };
     for (;;) {
-        totalCap = cap * nslices;  // every slice has a table of its own, one after the other
-        tLo = Buffer::Alloc(totalCap * 8);
-        tHi = Buffer::Alloc(twoWords ? totalCap * 8 : 64);
-        tAcc = Buffer::Alloc(size_t(naggs) * totalCap * 8);
-        tSeen = Buffer::Alloc(totalCap * 4);
-        tRep = Buffer::Alloc(hashed ? totalCap * 8 : 64);
-        if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
-        for (KeyedSink* k : {&sink, &ssink}) {
-            k->table_mask = cap - 1;
-            k->region_mask = cap - 1;
-            k->abort_check = abortCheck;
-            k->acc_stride = totalCap;
-            k->t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
-            k->t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
-            k->t_acc = static_cast<uint64_t*>(tAcc->Ptr);
-            k->t_seen = static_cast<uint32_t*>(tSeen->Ptr);
-            k->t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
-        }
-        {
-            KeyedSink all = sink;
-            all.table_mask = totalCap - 1;  // (the capacity, not a mask, when there are several tables)
-            SSA_HIP(LaunchKeyedTableInit(all, twoWords != 0, hashed, StreamHandle));
-        }
         bool timedRun = timedWanted;
         bool deferNow = false;
         bool specUsed = false;
         std::chrono::steady_clock::time_point deferT0;
+        // a scan of many rows runs the kernel built for this step program, when that can be had
+        hipFunction_t spec = nullptr;
+        LaunchCfg specCfg = scfg;
         if (totalRows > 0) {
-            // a scan of many rows runs the kernel built for this step program, when that can be had
-            hipFunction_t spec = nullptr;
-            LaunchCfg specCfg = scfg;
             if (JitEnabled()) {
                 ssink.use_hot = hotMode == 1 ? 1 : 0;
                 if (hotMode != 2) ssink.compact_n = 0;
@@ -2133,8 +2183,45 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 }
                 ScanRowsPerThread = kRowsPerThread;
             }
+        }
+        // The table in HBM.  A scan that leaves records, to be aggregated region by region and emitted from LDS (emitNow),
+        // touches it only when its workgroups end and merge their own tables into it: a small table then, cut into the
+        // same regions as the records (`smallSlots` slots each).
+        emitNow = deferNow && emitWanted;
+        uint64_t tableCap = cap;
+        if (emitNow) {
+            ldsSlots = int(std::min<uint64_t>(cap, uint64_t(regionSlots)));
+            regionCount = cap / uint64_t(ldsSlots);
+            const uint64_t entries = uint64_t(std::max(specCfg.grid, 1)) * uint64_t(std::max(L, 1));  // what the workgroups' own tables hold
+            smallSlots = int(std::min<uint64_t>(uint64_t(ldsSlots), std::max<uint64_t>(16, NextPow2((4 * entries + regionCount - 1) / regionCount))));
+            tableCap = regionCount * uint64_t(smallSlots);
+        }
+        totalCap = tableCap * nslices;  // every slice has a table of its own, one after the other
+        tLo = Buffer::Alloc(totalCap * 8);
+        tHi = Buffer::Alloc(twoWords ? totalCap * 8 : 64);
+        tAcc = Buffer::Alloc(size_t(naggs) * totalCap * 8);
+        tSeen = Buffer::Alloc(totalCap * 4);
+        tRep = Buffer::Alloc(hashed ? totalCap * 8 : 64);
+        if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
+        for (KeyedSink* k : {&sink, &ssink}) {
+            k->table_mask = tableCap - 1;
+            k->region_mask = tableCap - 1;
+            k->abort_check = abortCheck;
+            k->acc_stride = totalCap;
+            k->t_key_lo = static_cast<uint64_t*>(tLo->Ptr);
+            k->t_key_hi = static_cast<uint64_t*>(tHi->Ptr);
+            k->t_acc = static_cast<uint64_t*>(tAcc->Ptr);
+            k->t_seen = static_cast<uint32_t*>(tSeen->Ptr);
+            k->t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
+        }
+        {
+            KeyedSink all = sink;
+            all.table_mask = totalCap - 1;  // (the capacity, not a mask, when there are several tables)
+            SSA_HIP(LaunchKeyedTableInit(all, twoWords != 0, hashed, StreamHandle));
+        }
+        if (totalRows > 0) {
             ssink.defer = deferNow ? 1 : 0;
-            ssink.region_mask = deferNow ? std::min<uint64_t>(cap, uint64_t(regionSlots)) - 1 : cap - 1;
+            ssink.region_mask = emitNow ? uint64_t(smallSlots) - 1 : (deferNow ? std::min<uint64_t>(cap, uint64_t(regionSlots)) - 1 : cap - 1);
             if (deferNow) {
                 const size_t n = size_t(in.Rows);
                 if (!recLo) {
@@ -2210,7 +2297,35 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 }
             }
         }
-        if (!tableFull && deferNow) {
+        if (!tableFull && deferNow && emitNow) {
+            SortedRecords sorted;
+            Status st = SortDeferredRecords(ssink, in.Rows, nvals, needMask, (63 - __builtin_clzll(uint64_t(smallSlots))), regionCount, sorted);
+            // Room for the groups of the step's last scan and an eighth more; a scan that finds more is told so by the count
+            // the pass leaves and runs the pass (not the scan, not the sort) again.
+            int64_t outCap = std::max<int64_t>(hint.Groups + hint.Groups / 8 + 4096, int64_t(1) << 16);
+            outCap = std::min<int64_t>(outCap, in.Rows + int64_t(tableCap));
+            int64_t found = 0;
+            for (int attempt = 0; st.ok() && attempt < 3; ++attempt) {
+                st = prepareOutputs(outCap);
+                if (!st.ok()) break;
+                fa.capacity = uint64_t(outCap);
+                st = EmitDeferredRecords(ssink, sargs, sorted, in.Rows, nvals, ldsSlots, smallSlots, regionCount, fa, &found);
+                if (!st.ok()) break;
+                st = CheckScanStatus(&tableFull, nullptr);
+                if (!st.ok() || tableFull || found <= outCap) break;
+                outCap = found;
+            }
+            if (!st.ok()) {
+                (void)hipStreamSynchronize(StreamHandle);  // (the buffers of the sort are freed on the way out)
+                return st;
+            }
+            if (!tableFull && found > outCap) return Status::Invalid("internal: the groups of a region pass changed between two runs");
+            gKeyedStepsDeferred.fetch_add(1, std::memory_order_relaxed);
+            if (!tableFull) {
+                emitted = true;
+                ngroups = found;
+            }
+        } else if (!tableFull && deferNow) {
             SSA_RETURN_NOT_OK(ApplyDeferredRecords(ssink, sargs, in.Rows, nvals, needMask, regionSlots, cap));
             gKeyedStepsDeferred.fetch_add(1, std::memory_order_relaxed);
             SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull, nullptr));
@@ -2228,11 +2343,13 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     }
 
     cap = totalCap;  // (from here on the tables of all slices are one table: its slots in order are the slices in order)
-    if (!counted) {
-        SSA_RETURN_NOT_OK(countGroups());
-        SSA_HIP(hipStreamSynchronize(StreamHandle));
+    if (!emitted) {
+        if (!counted) {
+            SSA_RETURN_NOT_OK(countGroups());
+            SSA_HIP(hipStreamSynchronize(StreamHandle));
+        }
+        ngroups = *ngroupsAt;
     }
-    ngroups = *ngroupsAt;
     int64_t maxGroups = ngroups;
     if (many) {
         many->GroupStart[nslices] = ngroups;
@@ -2249,74 +2366,19 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     hint.ManyGroups = maxGroups > 128;
     hint.Groups = maxGroups;
 
-    KeyedFinalizeArgs fa{};
-    fa.capacity = cap;
-    fa.t_key_lo = sink.t_key_lo;
-    fa.t_key_hi = sink.t_key_hi;
-    fa.t_acc = sink.t_acc;
-    fa.t_seen = sink.t_seen;
-    fa.tile_offsets = static_cast<const int64_t*>(tileOffsets->Ptr);
-    fa.t_rep_row = sink.t_rep_row;
-    fa.naggs = naggsUser;
-    fa.nkeys = nkeys;
-    fa.two_words = twoWords;
-    fa.hashed = hashed;
-    std::vector<Column> aggCols, keyCols;
-    aggCols.resize(size_t(naggsUser));
-    keyCols.resize(size_t(nkeys));
-    std::vector<BufferPtr> aggValid, aggRowIdx, keyValid;
-    aggValid.resize(size_t(naggsUser));
-    aggRowIdx.resize(size_t(naggsUser));
-    keyValid.resize(size_t(nkeys));
-    BufferPtr repRows;
-    if (hashed) {
-        repRows = Buffer::Alloc(size_t(ngroups) * 8 + 16);
-        if (!repRows) return Status::Hip("out of device memory");
-        fa.group_rep_row = static_cast<uint64_t*>(repRows->Ptr);
+    if (!emitted) {
+        SSA_RETURN_NOT_OK(prepareOutputs(ngroups));
+        fa.capacity = cap;
+        fa.t_key_lo = sink.t_key_lo;
+        fa.t_key_hi = sink.t_key_hi;
+        fa.t_acc = sink.t_acc;
+        fa.t_seen = sink.t_seen;
+        fa.tile_offsets = static_cast<const int64_t*>(tileOffsets->Ptr);
+        fa.t_rep_row = sink.t_rep_row;
+        if (ngroups > 0) SSA_HIP(LaunchKeyedEmit(fa, StreamHandle));
     }
-    for (int k = 0; k < naggsUser; ++k) {
-        const AggPlan& ap = plan.Aggs[size_t(k)];
-        fa.aggs[k] = ap.Spec;
-        fa.agg_src[k] = aggSrc[size_t(k)];
-        fa.agg_nan_src[k] = ap.NanTag >= 0 ? aggSrc[size_t(ap.NanTag)] : -1;
-        fa.agg_zero_src[k] = ap.ZeroTag >= 0 ? aggSrc[size_t(ap.ZeroTag)] : -1;
-        Column& col = aggCols[size_t(k)];
-        col.Field.Type = ap.OutType;
-        col.Length = ngroups;
-        fa.agg_out_type[k] = ap.OutType == T_DEC128 ? int32_t(T_U64) : ap.OutType;  // decimal: the low-part sum
-        if (ap.SomeInputColumn >= 0) {
-            aggRowIdx[size_t(k)] = Buffer::Alloc(size_t(ngroups) * 8 + 16);
-            if (!aggRowIdx[size_t(k)]) return Status::Hip("out of device memory");
-            fa.agg_row_index[k] = 1;
-            fa.agg_vals[k] = aggRowIdx[size_t(k)]->Ptr;
-            continue;
-        }
-        col.Values = Buffer::Alloc(size_t(ngroups) * 8 + 16);
-        if (!col.Values) return Status::Hip("out of device memory");
-        fa.agg_vals[k] = col.Values->Ptr;
-        if (ap.Spec.kind != AGG_COUNT && ap.Spec.check_valid) {
-            aggValid[size_t(k)] = Buffer::Alloc(size_t(ngroups) + 16);
-            if (!aggValid[size_t(k)]) return Status::Hip("out of device memory");
-            fa.agg_valid_bytes[k] = static_cast<uint8_t*>(aggValid[size_t(k)]->Ptr);
-        }
-    }
-    for (int k = 0; k < nkeys; ++k) {
-        fa.keys[k] = sink.keys[k];
-        if (hashed) continue;
-        const KeyPlan& kp = plan.Keys[size_t(k)];
-        Column& col = keyCols[size_t(k)];
-        col.Field.Type = kp.Spec.type;
-        col.Length = ngroups;
-        col.Values = Buffer::Alloc(size_t(ngroups) * TypeWidth(kp.Spec.type) + 16);
-        if (!col.Values) return Status::Hip("out of device memory");
-        fa.key_vals[k] = col.Values->Ptr;
-        if (kp.Spec.nullable) {
-            keyValid[size_t(k)] = Buffer::Alloc(size_t(ngroups) + 16);
-            if (!keyValid[size_t(k)]) return Status::Hip("out of device memory");
-            fa.key_valid_bytes[k] = static_cast<uint8_t*>(keyValid[size_t(k)]->Ptr);
-        }
-    }
-    if (ngroups > 0) SSA_HIP(LaunchKeyedEmit(fa, StreamHandle));
+    for (Column& c : aggCols) c.Length = ngroups;
+    for (Column& c : keyCols) c.Length = ngroups;
     for (int k = 0; k < naggsUser; ++k) {
         const AggPlan& ap = plan.Aggs[size_t(k)];
         if (ap.DecMid >= 0) {

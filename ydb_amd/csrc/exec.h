@@ -261,8 +261,18 @@ private:
     Status RunKeyedUniform(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out, bool& done);
     Status RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
                         const std::vector<OffsetCheck>& checks, bool* notUniform, ManySlices* many = nullptr);
+    // The records of a scan in region order (region.cpp); `keep` holds the buffers behind the pointers.
+    struct SortedRecords {
+        RecordSet set{};
+        const uint32_t* region_start = nullptr;
+        std::vector<BufferPtr> keep;
+    };
+    Status SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nvals, bool needMask, int regionShift, uint64_t regions,
+                               SortedRecords& out);
     Status ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& args, int64_t rows, int nvals, bool needMask, int regionSlots,
                                 uint64_t cap);
+    Status EmitDeferredRecords(const KeyedSink& sink, const ScanArgs& args, const SortedRecords& sorted, int64_t rows, int nvals,
+                               int ldsSlots, int smallSlots, uint64_t regions, const KeyedFinalizeArgs& fa, int64_t* groups);
     Status DescribeSlices(const StepPlan& plan, ManySlices& many, ScanArgs& args, int64_t tileRows, uint64_t cap, LaunchCfg& cfg,
                           BufferPtr& descs, BufferPtr& map);
     Status RunSegments(const std::vector<CopySegment>& segments);

@@ -404,6 +404,68 @@ __global__ __launch_bounds__(kBlock) void KeyedTileCountKernel(const uint64_t* t
     }
 }
 
+// One group's row of the output: aggregate results (type conversions, nulls, the order-dependent MIN / MAX rules) and,
+// for keys that are packed exactly, the key columns decoded from the table's key words.  accAt(j): accumulator j of the group.
+template <class AccAt>
+__device__ __forceinline__ void EmitGroup(const KeyedFinalizeArgs& f, int64_t g, uint64_t klo, uint64_t khi, uint32_t seen, uint64_t rep,
+                                          AccAt accAt) {
+    if (f.group_rep_row != nullptr) f.group_rep_row[g] = rep;
+    for (int k = 0; k < f.naggs; ++k) {
+        const int kind = f.aggs[k].kind;
+        uint64_t v = accAt(f.agg_src[k]);
+        bool valid = true;
+        if (f.agg_row_index[k]) {
+            valid = v != ~0ull;  // smallest row with a non-null argument, none -> null
+            if (valid) v &= kRowIndexMask;  // (the order of the single-byte-key path sits above the row index)
+        } else {
+            if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
+                v = F64FromOrdered(v);
+                // the group's first non-null argument was a NaN: the reference's state never leaves it
+                if (f.agg_nan_src[k] >= 0) {
+                    const uint64_t first = accAt(f.agg_nan_src[k]);
+                    if (first != ~0ull && (first & 1ull)) v = 0x7FF8000000000000ull;
+                }
+                // a zero result: the first zero that arrived stays, `<` / `>` do not tell the two zeros apart
+                if (f.agg_zero_src[k] >= 0 && (v << 1) == 0) {
+                    const uint64_t first = accAt(f.agg_zero_src[k]);
+                    if (first != ~0ull) v = (first & 1ull) << 63;
+                }
+            }
+            if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> f.agg_src[k]) & 1u;
+            if (!valid) v = 0;
+            v = PayloadToStored(v, f.agg_out_type[k]);
+        }
+        if (f.agg_vals[k] != nullptr) {
+            StoreTyped(f.agg_vals[k], f.agg_row_index[k] ? 8 : TypeWidth(f.agg_out_type[k]), g, v);
+            if (f.agg_valid_bytes[k] != nullptr) f.agg_valid_bytes[k][g] = valid ? 1 : 0;
+        }
+    }
+    if (!f.hashed) {
+        // undo Finish(): 127 packed bits
+        const uint64_t lo = klo | (khi << 63), hi = khi >> 1;
+        int pos = 0;
+        for (int k = 0; k < f.nkeys; ++k) {
+            const int type = f.keys[k].type;
+            const int nbits = 8 * TypeWidth(type);
+            uint64_t bits;
+            if (pos < 64) {
+                bits = lo >> pos;
+                if (pos > 0 && pos + nbits > 64) bits |= hi << (64 - pos);
+            } else {
+                bits = hi >> (pos - 64);
+            }
+            bits &= WidthMask(nbits);
+            pos += nbits;
+            StoreTyped(f.key_vals[k], TypeWidth(type), g, bits);
+            if (f.keys[k].nullable) {
+                const uint64_t isNull = pos < 64 ? (lo >> pos) & 1ull : (hi >> (pos - 64)) & 1ull;
+                pos += 1;
+                if (f.key_valid_bytes[k] != nullptr) f.key_valid_bytes[k][g] = isNull ? 0 : 1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArgs) {
     const KeyedFinalizeArgs& f = KernArgsAs<KeyedFinalizeArgs>();
     __shared__ uint32_t wordCount[kTileRows / 64];
@@ -423,71 +485,190 @@ __global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArg
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < kRowsPerThread; ++u) {
-        const uint64_t klo = klos[u];
-        const uint64_t i = tile * kTileRows + u * kBlock + threadIdx.x;
-        uint32_t before = 0;
-        for (int w = 0; w < u * (kBlock / 64) + wave; ++w) before += wordCount[w];
-        if (klo == kEmpty) continue;
-        const int64_t g = tileFirst + before + __popcll(taken[u] & ((1ull << lane) - 1ull));
-        const uint32_t seen = f.t_seen[i];
-        if (f.group_rep_row != nullptr) f.group_rep_row[g] = f.t_rep_row[i];
-        for (int k = 0; k < f.naggs; ++k) {
-            const int kind = f.aggs[k].kind;
-            uint64_t v = f.t_acc[size_t(f.agg_src[k]) * f.capacity + i];
-            bool valid = true;
-            if (f.agg_row_index[k]) {
-                valid = v != ~0ull;  // smallest row with a non-null argument, none -> null
-                if (valid) v &= kRowIndexMask;  // (the order of the single-byte-key path sits above the row index)
-            } else {
-                if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
-                    v = F64FromOrdered(v);
-                    // the group's first non-null argument was a NaN: the reference's state never leaves it
-                    if (f.agg_nan_src[k] >= 0) {
-                        const uint64_t first = f.t_acc[size_t(f.agg_nan_src[k]) * f.capacity + i];
-                        if (first != ~0ull && (first & 1ull)) v = 0x7FF8000000000000ull;
-                    }
-                    // a zero result: the first zero that arrived stays, `<` / `>` do not tell the two zeros apart
-                    if (f.agg_zero_src[k] >= 0 && (v << 1) == 0) {
-                        const uint64_t first = f.t_acc[size_t(f.agg_zero_src[k]) * f.capacity + i];
-                        if (first != ~0ull) v = (first & 1ull) << 63;
-                    }
-                }
-                if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> f.agg_src[k]) & 1u;
-                if (!valid) v = 0;
-                v = PayloadToStored(v, f.agg_out_type[k]);
-            }
-            if (f.agg_vals[k] != nullptr) {
-                StoreTyped(f.agg_vals[k], f.agg_row_index[k] ? 8 : TypeWidth(f.agg_out_type[k]), g, v);
-                if (f.agg_valid_bytes[k] != nullptr) f.agg_valid_bytes[k][g] = valid ? 1 : 0;
-            }
+            const uint64_t klo = klos[u];
+            const uint64_t i = tile * kTileRows + u * kBlock + threadIdx.x;
+            uint32_t before = 0;
+            for (int w = 0; w < u * (kBlock / 64) + wave; ++w) before += wordCount[w];
+            if (klo == kEmpty) continue;
+            const int64_t g = tileFirst + before + __popcll(taken[u] & ((1ull << lane) - 1ull));
+            const uint64_t khi = (!f.hashed && f.two_words) ? f.t_key_hi[i] : 0ull;
+            const uint64_t rep = f.group_rep_row != nullptr ? f.t_rep_row[i] : 0ull;
+            EmitGroup(f, g, klo, khi, f.t_seen[i], rep, [&](int j) { return f.t_acc[size_t(j) * f.capacity + i]; });
         }
-        if (!f.hashed) {
-            // undo Finish(): 127 packed bits
-            const uint64_t khi = f.two_words ? f.t_key_hi[i] : 0ull;
-            const uint64_t lo = klo | (khi << 63), hi = khi >> 1;
-            int pos = 0;
-            for (int k = 0; k < f.nkeys; ++k) {
-                const int type = f.keys[k].type;
-                const int nbits = 8 * TypeWidth(type);
-                uint64_t bits;
-                if (pos < 64) {
-                    bits = lo >> pos;
-                    if (pos > 0 && pos + nbits > 64) bits |= hi << (64 - pos);
-                } else {
-                    bits = hi >> (pos - 64);
-                }
-                bits &= WidthMask(nbits);
-                pos += nbits;
-                StoreTyped(f.key_vals[k], TypeWidth(type), g, bits);
-                if (f.keys[k].nullable) {
-                    const uint64_t isNull = pos < 64 ? (lo >> pos) & 1ull : (hi >> (pos - 64)) & 1ull;
-                    pos += 1;
-                    if (f.key_valid_bytes[k] != nullptr) f.key_valid_bytes[k][g] = isNull ? 0 : 1;
-                }
-            }
-        }
-        }  // slots of this thread
         __syncthreads();  // wordCount is rewritten for the next tile
+    }
+}
+
+// Position of a key inside the LDS table of its region.  The region itself is chosen by other bits of the same 32-bit
+// fold (DigitOf), so this takes them through another multiplier.
+__device__ __forceinline__ uint32_t RegionLdsStart(uint32_t fold, int shift) { return (fold * 0xC2B2AE35u) >> shift; }
+
+// One region of the grouping finished by one workgroup, without a table in HBM: the region's groups are built in an LDS
+// table -- first what the scan's workgroups left in their region of the scan's small level-2 table (their level-1 tables,
+// merged there as they ended), then the region's records -- and leave straight into the output columns, at positions
+// the workgroup claims from one counter (the order of the groups in the output is as unspecified as the reference's
+// hash-table order).  A region whose groups outnumber the LDS slots raises SCAN_TABLE_FULL (the host repeats the step with
+// more regions); when the output columns are too short nothing is written, the counter still ends as the number of
+// groups, and the host runs this pass again with longer ones.
+__global__ __launch_bounds__(kBlock) void RegionEmitKernel(const RegionEmitArgs) {
+    const RegionEmitArgs& a = KernArgsAs<RegionEmitArgs>();
+    const KeyedSink& s = a.s;
+    const KeyedFinalizeArgs& f = a.f;
+    extern __shared__ uint64_t lRegion[];
+    const int R = a.region_slots, Rs = a.small_slots;
+    const int ldsShift = __builtin_clz(uint32_t(R)) + 1;  // 32 - log2(R)
+    const bool two = s.two_words != 0, hashed = s.hashed != 0;
+    uint64_t* lLo = lRegion;
+    uint64_t* lHi = lLo + R;
+    uint64_t* lRep = lHi + (two ? R : 0);
+    uint64_t* lAcc = lRep + (hashed ? R : 0);
+    uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(s.naggs) * R);
+    __shared__ uint32_t lWordStart[64 + 1];  // groups in the 64-slot words before each word of the table; [nwords]: all
+    __shared__ unsigned long long lBase;
+    __shared__ uint32_t lStop;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwords = R / 64;
+    uint32_t err = 0;
+    for (int region = blockIdx.x; region < a.nregions; region += gridDim.x) {
+        const uint32_t first = a.region_start[region], last = a.region_start[region + 1];
+        const uint64_t small0 = uint64_t(region) * uint64_t(Rs);
+        bool any = first != last;
+        for (int i = threadIdx.x; i < Rs && !any; i += kBlock) any = s.t_key_lo[small0 + i] != kEmpty;
+        // (also keeps the previous region's emit pass and this region's set-up apart)
+        if (!__syncthreads_or(any ? 1 : 0)) continue;
+        // a region that ran full somewhere: the host repeats the step with more regions, the rest is wasted work
+        if (threadIdx.x == 0) lStop = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SCAN_TABLE_FULL;
+        __syncthreads();
+        if (lStop != 0) break;  // (one value for the whole workgroup: the next store to it is barriers away)
+        for (int i = threadIdx.x; i < R; i += kBlock) {
+            lLo[i] = kEmpty;
+            if (two) lHi[i] = kUnpublished;
+            if (hashed) lRep[i] = ~0ull;
+            lSeen[i] = 0;
+            for (int k = 0; k < s.naggs; ++k) lAcc[size_t(k) * R + i] = TableIdentity(s.aggs[k].kind);
+        }
+        __syncthreads();
+        // what the scan's workgroups merged into this region of their table
+        for (int i = threadIdx.x; i < Rs; i += kBlock) {
+            const uint64_t lo = s.t_key_lo[small0 + i];
+            if (lo == kEmpty || err != 0) continue;
+            const uint64_t hi = two ? s.t_key_hi[small0 + i] : 0ull;
+            const uint32_t start = RegionLdsStart(Fold32(lo, hi), ldsShift);
+            int64_t g;
+            if (hashed && (hi >> 63) != 0) {
+                const uint64_t row = s.t_rep_row[small0 + i];
+                g = TableUpsertVerified(lLo, lHi, lRep, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, row, uint32_t(R),
+                                        [&](uint64_t rep) { return SameKeyRows(a.cols, s, row, rep); });
+            } else {
+                g = TableUpsert(lLo, lHi, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, two, uint32_t(R));
+                if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(lRep + g), static_cast<unsigned long long>(s.t_rep_row[small0 + i]));
+            }
+            if (g < 0) {
+                err |= SCAN_TABLE_FULL;
+                continue;
+            }
+            for (int k = 0; k < s.naggs; ++k) {
+                const int kind = s.aggs[k].kind;
+                const uint64_t v = s.t_acc[size_t(k) * s.acc_stride + small0 + i];
+                if (v != TableIdentity(kind)) AccUpdate(kind, lAcc + size_t(k) * R + g, v);
+            }
+            const uint32_t seen = s.t_seen[small0 + i];
+            if (seen != 0) atomicOr(lSeen + g, seen);
+        }
+        // the region's records
+        for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += 4 * kBlock) {
+            uint64_t los[4], his[4];
+            uint32_t masks[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i = i0 + j * kBlock < last ? i0 + j * kBlock : i0;
+                los[j] = a.rec.lo[i];
+                his[j] = 0;
+                masks[j] = ~0u;
+            }
+            if (two && !s.rec_raw64) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) his[j] = a.rec.hi[i0 + j * kBlock < last ? i0 + j * kBlock : i0];
+            }
+            if (s.rec_raw64) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) RawKeyWords(los[j], los[j], his[j]);
+            }
+            if (a.rec.mask != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) masks[j] = a.rec.mask[i0 + j * kBlock < last ? i0 + j * kBlock : i0];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i = i0 + j * kBlock;
+                if (i >= last || err != 0) continue;
+                const uint64_t lo = los[j], hi = his[j];
+                const uint32_t mask = masks[j];
+                const uint32_t start = RegionLdsStart(Fold32(lo, hi), ldsShift);
+                int64_t g;
+                if (hashed && (hi >> 63) != 0) {
+                    const uint64_t row = a.rec.row[i];
+                    g = TableUpsertVerified(lLo, lHi, lRep, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, row, uint32_t(R),
+                                            [&](uint64_t rep) { return SameKeyRows(a.cols, s, row, rep); });
+                } else {
+                    g = TableUpsert(lLo, lHi, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, two, uint32_t(R));
+                    if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(lRep + g), static_cast<unsigned long long>(a.rec.row[i]));
+                }
+                if (g < 0) {
+                    err |= SCAN_TABLE_FULL;
+                    continue;
+                }
+                uint32_t seen = 0;
+                int v = 0;
+                for (int k = 0; k < s.naggs; ++k) {
+                    const int kind = s.aggs[k].kind;
+                    const int slotV = v;
+                    if (kind != AGG_COUNT) ++v;
+                    if (!((mask >> k) & 1u)) continue;
+                    if (s.aggs[k].check_valid) seen |= 1u << k;
+                    AccUpdate(kind, lAcc + size_t(k) * R + g, kind == AGG_COUNT ? 1ull : a.rec.val[size_t(slotV) * size_t(a.stride) + i]);
+                }
+                if (seen != 0 && (lSeen[g] & seen) != seen) atomicOr(lSeen + g, seen);
+            }
+        }
+        if (__syncthreads_or(err != 0 ? 1 : 0)) {
+            if (threadIdx.x == 0) atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
+            break;
+        }
+        // The groups leave in slot order.  Word w of the table = slots 64 w .. 64 w + 63, counted by the wave that will emit
+        // them (thread t takes the slots t, t + 256, ..: word 4 j + wave in its trip j).
+        for (int j = 0; j * kBlock < R; ++j) {
+            const int i = j * kBlock + threadIdx.x;
+            const uint64_t taken = __ballot(i < R && lLo[i] != kEmpty);
+            if (lane == 0 && i < R) lWordStart[(i >> 6) + 1] = uint32_t(__popcll(taken));
+        }
+        __syncthreads();
+        if (wave == 0) {  // (64 words at most: one lane each)
+            uint32_t c = lane < nwords ? lWordStart[lane + 1] : 0u;
+            uint32_t inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (lane < nwords) lWordStart[lane + 1] = inc;
+            if (lane == 0) lWordStart[0] = 0;
+            const uint32_t total = __shfl(inc, 63, 64);
+            if (lane == 0) lBase = total != 0 ? atomicAdd(a.out_count, static_cast<unsigned long long>(total)) : 0ull;
+        }
+        __syncthreads();
+        const uint64_t base = lBase;
+        const uint32_t total = lWordStart[nwords];
+        if (base + total <= f.capacity) {
+            for (int j = 0; j * kBlock < R; ++j) {
+                const int i = j * kBlock + threadIdx.x;
+                const uint64_t klo = i < R ? lLo[i] : kEmpty;
+                const uint64_t taken = __ballot(klo != kEmpty);
+                if (klo == kEmpty) continue;
+                const int64_t g = int64_t(base) + lWordStart[i >> 6] + __popcll(taken & ((1ull << lane) - 1ull));
+                EmitGroup(f, g, klo, two ? lHi[i] : 0ull, lSeen[i], hashed ? lRep[i] : 0ull, [&](int k) { return lAcc[size_t(k) * R + i]; });
+            }
+        }
     }
 }
 
@@ -644,6 +825,20 @@ size_t RegionApplyLdsBytes(const KeyedSink& s, int regionSlots) {
 hipError_t LaunchRegionApply(const RegionApplyArgs& a, hipStream_t st) {
     const int grid = a.nregions < kMaxGrid * 16 ? a.nregions : kMaxGrid * 16;
     hipLaunchKernelGGL(RegionApplyKernel, dim3(uint32_t(grid)), dim3(kBlock), RegionApplyLdsBytes(a.s, a.region_slots), st, a);
+    return hipGetLastError();
+}
+
+size_t RegionEmitLdsBytes(const KeyedSink& s, int regionSlots) { return RegionApplyLdsBytes(s, regionSlots); }
+
+hipError_t ConfigureRegionKernels(int maxLdsBytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&RegionEmitKernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&RegionApplyKernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    return e;
+}
+
+hipError_t LaunchRegionEmit(const RegionEmitArgs& a, hipStream_t st) {
+    const int grid = a.nregions < kMaxGrid * 16 ? a.nregions : kMaxGrid * 16;
+    hipLaunchKernelGGL(RegionEmitKernel, dim3(uint32_t(grid)), dim3(kBlock), RegionEmitLdsBytes(a.s, a.region_slots), st, a);
     return hipGetLastError();
 }
 

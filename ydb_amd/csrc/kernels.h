@@ -237,6 +237,28 @@ struct RegionApplyArgs {
 // LDS bytes the apply pass needs for regions of `region_slots` slots.
 size_t RegionApplyLdsBytes(const KeyedSink& s, int region_slots);
 hipError_t LaunchRegionApply(const RegionApplyArgs& a, hipStream_t st);
+// The same records aggregated region by region in LDS and emitted straight into the output columns: no table of the
+// whole grouping in HBM.  `s` carries the scan's own level-2 table, which in this mode holds only what the scan's
+// workgroups merged into it as they ended: nregions regions of small_slots slots, chosen by the same key bits as the
+// records' regions.
+struct RegionEmitArgs {
+    KeyedSink s;
+    const DevColumn* cols;        // hashed keys: rows are compared by their key values
+    RecordSet rec;                // the records in region order
+    int64_t stride;
+    int32_t nvals;
+    int32_t region_slots;         // slots of the LDS table a region's groups are built in: a power of two, 64 .. 4096
+    int32_t small_slots;          // slots per region of the scan's table (a power of two)
+    int32_t nregions;
+    const uint32_t* region_start; // [nregions + 1]
+    uint32_t* status;
+    KeyedFinalizeArgs f;          // the output columns; f.capacity: the rows they hold (tile_offsets and t_* unused)
+    unsigned long long* out_count; // zero before the launch; afterwards the number of groups, whether they fitted or not
+};
+static_assert(sizeof(RegionEmitArgs) <= 4096, "kernel arguments are limited to 4 KB");
+size_t RegionEmitLdsBytes(const KeyedSink& s, int region_slots);
+hipError_t ConfigureRegionKernels(int maxLdsBytes);
+hipError_t LaunchRegionEmit(const RegionEmitArgs& a, hipStream_t st);
 // tile_counts[t] = occupied slots among slots [t * kTileRows, (t + 1) * kTileRows); capacity is a multiple of kTileRows
 hipError_t LaunchKeyedTileCount(const uint64_t* t_key_lo, uint64_t capacity, uint32_t* tile_counts, hipStream_t st);
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st);

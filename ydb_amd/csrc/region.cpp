@@ -27,21 +27,19 @@ int Log2Of(uint64_t x) {
 }
 }  // namespace
 
-// `sink`: the sink the scan ran with (table, record arrays); `cap`: slots of the table; the regions have
-// min(cap, regionSlots) slots.  Errors of the apply pass arrive in the status word, like the scan's.
-Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& args, int64_t rows, int nvals, bool needMask,
-                                      int regionSlots, uint64_t cap) {
+// The records a scan left, sorted by region.  `sink`: the sink the scan ran with (record arrays; its table_mask and
+// `regionShift` say which bits of a key's table position are its region number); `regions`: how many there are.
+Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nvals, bool needMask, int regionShift, uint64_t regions,
+                                     SortedRecords& out) {
     const bool twoWords = sink.two_words != 0, hashed = sink.hashed != 0;
     const size_t n = size_t(rows);
-    const uint64_t R = std::min<uint64_t>(cap, uint64_t(regionSlots));
-    const uint64_t regions = cap / R;
     const int regionBits = Log2Of(regions);
     // one round of the sort for up to 256 regions, else two of about as many bits each (the second of 6 bits at least)
     const int bitsB = regionBits <= 8 ? 0 : std::max(6, regionBits / 2);  // (fewer digits a round: longer runs per tile in the scatter)
     const int bitsA = regionBits - bitsB;
     if (std::getenv("SSA_DEBUG_PLAN")) {
-        std::fprintf(stderr, "regions: table %llu slots, %llu regions of %llu, sort rounds of %d and %d bits\n", (unsigned long long)cap,
-                     (unsigned long long)regions, (unsigned long long)R, bitsA, bitsB);
+        std::fprintf(stderr, "regions: %llu regions (table mask %llx, shift %d), sort rounds of %d and %d bits\n", (unsigned long long)regions,
+                     (unsigned long long)sink.table_mask, regionShift, bitsA, bitsB);
     }
 
     const bool raw64 = sink.rec_raw64 != 0;  // (64-bit keys in one word: no hi arrays)
@@ -65,7 +63,7 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
     ra.present = raw64 ? sink.rec_present : nullptr;
     ra.skip_free = 1;
     ra.table_mask = sink.table_mask;
-    ra.region_shift = Log2Of(R);
+    ra.region_shift = regionShift;
     ra.digit_shift = bitsB;
     ra.ndigits = std::max(64, 1 << bitsA);
     ra.nseg = 1;
@@ -81,9 +79,9 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
     SSA_HIP(LaunchRadixOffsets(ra, StreamHandle));
     SSA_HIP(LaunchRadixScatter(ra, StreamHandle));
 
-    RecordSet sorted = part;
-    const uint32_t* regionStart = ra.out_start;
-    BufferPtr countsB, startB;
+    out.set = part;
+    out.region_start = ra.out_start;
+    out.keep = {partLo, partHi, partVal, partMask, partRow, recRow, segA, countsA, startA};
     if (bitsB > 0) {
         RadixArgs rb = ra;
         rb.src = part;
@@ -95,18 +93,36 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
         rb.nseg = 1 << bitsA;
         rb.chunks = std::max(1, std::min(16, 768 / rb.nseg));
         rb.seg_start = ra.out_start;
-        countsB = Buffer::Alloc(size_t(rb.nseg) * rb.chunks * rb.ndigits * 4);
-        startB = Buffer::Alloc((size_t(rb.nseg) * rb.ndigits + 1) * 4 + 64);
+        BufferPtr countsB = Buffer::Alloc(size_t(rb.nseg) * rb.chunks * rb.ndigits * 4);
+        BufferPtr startB = Buffer::Alloc((size_t(rb.nseg) * rb.ndigits + 1) * 4 + 64);
         if (!countsB || !startB) return Status::Hip("out of device memory");
         rb.counts = static_cast<uint32_t*>(countsB->Ptr);
         rb.out_start = static_cast<uint32_t*>(startB->Ptr);
         SSA_HIP(LaunchRadixCount(rb, StreamHandle));
         SSA_HIP(LaunchRadixOffsets(rb, StreamHandle));
         SSA_HIP(LaunchRadixScatter(rb, StreamHandle));
-        sorted = back;
-        regionStart = rb.out_start;
+        out.set = back;
+        out.region_start = rb.out_start;
+        out.keep.push_back(countsB);
+        out.keep.push_back(startB);
     }
+    // (the whole stack of whole[] is read by the copy above: the caller synchronises the stream before it returns)
+    return Status::OK();
+}
 
+// `cap`: slots of the table in HBM; its regions have min(cap, regionSlots) slots.  Errors of the apply pass arrive in the
+// status word, like the scan's.
+Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& args, int64_t rows, int nvals, bool needMask,
+                                      int regionSlots, uint64_t cap) {
+    const bool hashed = sink.hashed != 0;
+    const uint64_t R = std::min<uint64_t>(cap, uint64_t(regionSlots));
+    const uint64_t regions = cap / R;
+    SortedRecords sorted;
+    const Status st = SortDeferredRecords(sink, rows, nvals, needMask, Log2Of(R), regions, sorted);
+    if (!st.ok()) {
+        (void)hipStreamSynchronize(StreamHandle);
+        return st;
+    }
     RegionApplyArgs aa{};
     aa.s = sink;
     BufferPtr devCols;
@@ -116,16 +132,52 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
         SSA_HIP(hipMemcpyAsync(devCols->Ptr, args.cols, sizeof(args.cols), hipMemcpyHostToDevice, StreamHandle));
         aa.cols = static_cast<const DevColumn*>(devCols->Ptr);
     }
-    aa.rec = sorted;
+    aa.rec = sorted.set;
     aa.stride = rows;
     aa.nvals = nvals;
     aa.region_slots = int32_t(R);
     aa.nregions = int32_t(regions);
-    aa.region_start = regionStart;
+    aa.region_start = sorted.region_start;
     aa.status = static_cast<uint32_t*>(StatusWord->Ptr);
     SSA_HIP(LaunchRegionApply(aa, StreamHandle));
     // (the buffers of this function are freed when it returns: the stream has to be past their last use)
     SSA_HIP(hipStreamSynchronize(StreamHandle));
+    return Status::OK();
+}
+
+// The sorted records aggregated region by region in LDS and written straight into the output columns `fa` describes
+// (RegionEmitKernel).  `sink`: the scan's sink, whose table holds `regions` regions of `smallSlots` slots; `ldsSlots`: slots of
+// the LDS table of a region.  *groups: the number of groups -- more than fa.capacity when the columns were too short (nothing
+// was written then, and the call can be repeated with longer columns).  Ends with the stream synchronised.
+Status Executor::EmitDeferredRecords(const KeyedSink& sink, const ScanArgs& args, const SortedRecords& sorted, int64_t rows, int nvals,
+                                     int ldsSlots, int smallSlots, uint64_t regions, const KeyedFinalizeArgs& fa, int64_t* groups) {
+    RegionEmitArgs ea{};
+    ea.s = sink;
+    BufferPtr devCols;
+    if (sink.hashed) {
+        devCols = Buffer::Alloc(sizeof(args.cols));
+        if (!devCols) return Status::Hip("out of device memory");
+        SSA_HIP(hipMemcpyAsync(devCols->Ptr, args.cols, sizeof(args.cols), hipMemcpyHostToDevice, StreamHandle));
+        ea.cols = static_cast<const DevColumn*>(devCols->Ptr);
+    }
+    BufferPtr counter = Buffer::Alloc(256);
+    if (!counter) return Status::Hip("out of device memory");
+    SSA_HIP(hipMemsetAsync(counter->Ptr, 0, 8, StreamHandle));
+    ea.rec = sorted.set;
+    ea.stride = rows;
+    ea.nvals = nvals;
+    ea.region_slots = ldsSlots;
+    ea.small_slots = smallSlots;
+    ea.nregions = int32_t(regions);
+    ea.region_start = sorted.region_start;
+    ea.status = static_cast<uint32_t*>(StatusWord->Ptr);
+    ea.f = fa;
+    ea.out_count = static_cast<unsigned long long*>(counter->Ptr);
+    SSA_HIP(LaunchRegionEmit(ea, StreamHandle));
+    int64_t* at = HostWords ? reinterpret_cast<int64_t*>(HostWords + 8) : groups;
+    SSA_HIP(hipMemcpyAsync(at, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    SSA_HIP(hipStreamSynchronize(StreamHandle));
+    *groups = *at;
     return Status::OK();
 }
 
