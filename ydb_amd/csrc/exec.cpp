@@ -1998,7 +1998,13 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
         // (probing inside LDS is cheap: the table may be up to three quarters full, and everything that walks over it is
         // the faster for it)
-        if (deferWanted && hint.Groups > 0) cap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(uint64_t(hint.Groups) + uint64_t(hint.Groups) / 3), 1024), maxCap);
+        if (deferWanted && hint.Groups > 0) {
+            // (a table in LDS costs no traffic: the pass that emits from LDS gets tables a fifth to three eighths full, where most
+            // keys sit in the first slot looked at)
+            const bool sparse = !hashed && !(std::getenv("SSA_KEYED_EMIT") && std::atoi(std::getenv("SSA_KEYED_EMIT")) == 0);
+            const uint64_t want = sparse ? uint64_t(hint.Groups) * 8 / 3 : uint64_t(hint.Groups) + uint64_t(hint.Groups) / 3;
+            cap = std::min<uint64_t>(std::max<uint64_t>(NextPow2(want), 1024), sparse ? maxCap * 2 : maxCap);
+        }
     }
     BufferPtr recLo, recHi, recVal, recMask;
     // slots of a region: what one workgroup holds in 48 KB of LDS (SSA_KEYED_REGION / SSA_KEYED_REGION_KB: experiments and tests)
@@ -2006,9 +2012,22 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     size_t regionLds = 48 * 1024;
     if (const char* env = std::getenv("SSA_KEYED_REGION_KB")) regionLds = size_t(std::max(8, std::min(128, std::atoi(env)))) * 1024;
     while (regionSlots > 256 && size_t(regionSlots) * (8 + (twoWords ? 8 : 0) + (hashed ? 8 : 0) + 8 * size_t(naggs) + 4) > regionLds) regionSlots >>= 1;
+    // (the pass that emits from LDS keeps 64-bit keys as one word)
+    int emitSlots = 4096;
+    {
+        const bool rawKey = !hashed && keyBits == 64;
+        bool anyCheck = false;
+        for (const AggSpec& a : phys) anyCheck = anyCheck || a.check_valid != 0;
+        const size_t slotBytes = hashed ? size_t(8 + 8 + 8 + 8 * naggs + 4) : size_t(8 + (twoWords && !rawKey ? 8 : 0) + 8 * naggs + (anyCheck ? 4 : 0) + 2);
+        // (exact keys, tables of 80 KB: the pass is bound by its instructions, not by the workgroups a CU holds, and the work
+        // a region costs whatever its records -- set-up, counting and listing its groups -- is paid half as often)
+        const size_t emitLds = std::getenv("SSA_KEYED_REGION_KB") ? regionLds : (hashed ? regionLds : size_t(80 * 1024));
+        while (emitSlots > 256 && size_t(emitSlots + 1) * slotBytes > emitLds) emitSlots >>= 1;
+    }
     if (const char* env = std::getenv("SSA_KEYED_REGION")) {
         const int r = std::atoi(env);
         if (r >= 64 && r <= regionSlots && (r & (r - 1)) == 0) regionSlots = r;
+        if (r >= 64 && r <= emitSlots && (r & (r - 1)) == 0) emitSlots = r;
     }
     const int specCompactTiles = ssink.compact_n;  // (the generic kernel never takes that way)
     sink.compact_n = 0;
@@ -2046,7 +2065,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     uint64_t totalCap = 0;
     // A scan that leaves records: its groups are built region by region in LDS and emitted from there (RegionEmitKernel),
     // unless SSA_KEYED_EMIT=0 asks for the table in HBM brought up to date region by region (RegionApplyKernel).
-    const bool emitWanted = !(std::getenv("SSA_KEYED_EMIT") && std::atoi(std::getenv("SSA_KEYED_EMIT")) == 0);
+    bool emitWanted = !(std::getenv("SSA_KEYED_EMIT") && std::atoi(std::getenv("SSA_KEYED_EMIT")) == 0);
     bool emitNow = false, emitted = false;
     int ldsSlots = 0, smallSlots = 0;
     uint64_t regionCount = 0;
@@ -2168,7 +2187,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 if (std::getenv("SSA_PHASE_TIMING")) defines += "#define SSA_PHASE_TIMING 1\n";  // diagnostics
                 ScanRowsPerThread = specRows;
                 // (more than 2^16 regions would take a third round of the sort: such tables are updated row by row)
-                if (deferWanted && cap / std::min<uint64_t>(cap, uint64_t(regionSlots)) <= 65536) {
+                if (deferWanted && cap / std::min<uint64_t>(cap, uint64_t(emitWanted ? emitSlots : regionSlots)) <= 65536) {
                     image.defer = 1;
                     spec = SpecializedKernel("keyed_scan.h", hotMode == 1 ? "ssa_spec_keyed" : "ssa_spec_keyed_plain", defines + "#define SSA_SPEC_DEFER 1\n",
                                              sargs, &image, sizeof(image), totalRows, specCfg);
@@ -2190,7 +2209,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         emitNow = deferNow && emitWanted;
         uint64_t tableCap = cap;
         if (emitNow) {
-            ldsSlots = int(std::min<uint64_t>(cap, uint64_t(regionSlots)));
+            ldsSlots = int(std::min<uint64_t>(cap, uint64_t(emitSlots)));
             regionCount = cap / uint64_t(ldsSlots);
             const uint64_t entries = uint64_t(std::max(specCfg.grid, 1)) * uint64_t(std::max(L, 1));  // what the workgroups' own tables hold
             smallSlots = int(std::min<uint64_t>(uint64_t(ldsSlots), std::max<uint64_t>(16, NextPow2((4 * entries + regionCount - 1) / regionCount))));
@@ -2299,27 +2318,23 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
         if (!tableFull && deferNow && emitNow) {
             SortedRecords sorted;
-            Status st = SortDeferredRecords(ssink, in.Rows, nvals, needMask, (63 - __builtin_clzll(uint64_t(smallSlots))), regionCount, sorted);
-            // Room for the groups of the step's last scan and an eighth more; a scan that finds more is told so by the count
-            // the pass leaves and runs the pass (not the scan, not the sort) again.
-            int64_t outCap = std::max<int64_t>(hint.Groups + hint.Groups / 8 + 4096, int64_t(1) << 16);
-            outCap = std::min<int64_t>(outCap, in.Rows + int64_t(tableCap));
+            RegionGroups regionGroups;
             int64_t found = 0;
-            for (int attempt = 0; st.ok() && attempt < 3; ++attempt) {
-                st = prepareOutputs(outCap);
-                if (!st.ok()) break;
-                fa.capacity = uint64_t(outCap);
-                st = EmitDeferredRecords(ssink, sargs, sorted, in.Rows, nvals, ldsSlots, smallSlots, regionCount, fa, &found);
-                if (!st.ok()) break;
-                st = CheckScanStatus(&tableFull, nullptr);
-                if (!st.ok() || tableFull || found <= outCap) break;
-                outCap = found;
+            int64_t* foundAt = HostWords ? reinterpret_cast<int64_t*>(HostWords + 8) : &found;  // (pinned: no staging copy)
+            Status st = SortDeferredRecords(ssink, in.Rows, nvals, needMask, 63 - __builtin_clzll(uint64_t(smallSlots)), regionCount, sorted);
+            if (st.ok()) st = AggregateDeferredRecords(ssink, sargs, sorted, in.Rows, nvals, ldsSlots, smallSlots, regionCount, regionGroups, foundAt);
+            if (st.ok()) st = CheckScanStatus(&tableFull, nullptr);  // (synchronises the stream: the count has arrived)
+            if (st.ok() && !tableFull) {
+                found = *foundAt;
+                st = prepareOutputs(found);
+                fa.capacity = uint64_t(found);
+                if (st.ok() && found > 0) st = EmitRegionGroups(regionGroups, fa);
             }
-            if (!st.ok()) {
-                (void)hipStreamSynchronize(StreamHandle);  // (the buffers of the sort are freed on the way out)
-                return st;
-            }
-            if (!tableFull && found > outCap) return Status::Invalid("internal: the groups of a region pass changed between two runs");
+            // (the buffers of the sort and of the region pass are freed on the way out of this block: the stream has to be
+            // past their last use)
+            const hipError_t syncErr = hipStreamSynchronize(StreamHandle);
+            if (!st.ok()) return st;
+            SSA_HIP(syncErr);
             gKeyedStepsDeferred.fetch_add(1, std::memory_order_relaxed);
             if (!tableFull) {
                 emitted = true;
@@ -2338,6 +2353,11 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             if (std::getenv("SSA_DEBUG_PLAN")) std::fprintf(stderr, "keyed: by region %.3f ms, row by row %.3f ms -> %d\n", hint.MsDeferOn, hint.MsDeferOff, hint.DeferChoice);
         }
         if (!tableFull) break;
+        if (cap >= maxCap && emitNow) {  // (regions that ran full although the table is as large as it gets: the table in HBM, then)
+            emitWanted = false;
+            cap = maxCap;
+            continue;
+        }
         if (cap >= maxCap) return Status::Invalid("internal: group-by table overflow");
         cap = std::min<uint64_t>(cap * 16, maxCap);
     }

@@ -271,8 +271,14 @@ private:
                                SortedRecords& out);
     Status ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& args, int64_t rows, int nvals, bool needMask, int regionSlots,
                                 uint64_t cap);
-    Status EmitDeferredRecords(const KeyedSink& sink, const ScanArgs& args, const SortedRecords& sorted, int64_t rows, int nvals,
-                               int ldsSlots, int smallSlots, uint64_t regions, const KeyedFinalizeArgs& fa, int64_t* groups);
+    // The groups of a region pass in its temporary table, and what the kernel that moves them to the output needs.
+    struct RegionGroups {
+        RegionEmitArgs args{};
+        std::vector<BufferPtr> keep;
+    };
+    Status AggregateDeferredRecords(const KeyedSink& sink, const ScanArgs& args, const SortedRecords& sorted, int64_t rows, int nvals,
+                                    int ldsSlots, int smallSlots, uint64_t regions, RegionGroups& out, int64_t* groupsAt);
+    Status EmitRegionGroups(RegionGroups& groups, const KeyedFinalizeArgs& fa);
     Status DescribeSlices(const StepPlan& plan, ManySlices& many, ScanArgs& args, int64_t tileRows, uint64_t cap, LaunchCfg& cfg,
                           BufferPtr& descs, BufferPtr& map);
     Status RunSegments(const std::vector<CopySegment>& segments);

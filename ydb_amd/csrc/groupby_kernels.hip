@@ -35,8 +35,7 @@ __global__ __launch_bounds__(kBlock) void KeyedTableInitKernel(const KeyedTableI
 // ---- deferred level-2 updates ------------------------------------------------------------------------
 // Digit of a record in one round of the sort: bits of the number of the region its probe sequence starts in.
 __device__ __forceinline__ uint32_t DigitOf(const RadixArgs& a, uint64_t lo, uint64_t hi) {
-    const uint32_t h = Fold32(lo, hi);
-    const uint64_t start = (uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24) & a.table_mask;
+    const uint64_t start = TablePos(lo, hi) & a.table_mask;
     return uint32_t(start >> a.region_shift >> a.digit_shift) & uint32_t(a.ndigits - 1);
 }
 
@@ -343,8 +342,7 @@ __global__ __launch_bounds__(kBlock) void RegionApplyKernel(const RegionApplyArg
             if (i >= last || err != 0) continue;
             const uint64_t lo = los[j], hi = his[j];
             const uint32_t mask = masks[j];
-            const uint32_t h = Fold32(lo, hi);
-            const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
+            const uint64_t start = TablePos(lo, hi);
             int64_t g;
             if (hashed && (hi >> 63) != 0) {
                 const uint64_t row = a.rec.row[i];
@@ -407,62 +405,68 @@ __global__ __launch_bounds__(kBlock) void KeyedTileCountKernel(const uint64_t* t
 // One group's row of the output: aggregate results (type conversions, nulls, the order-dependent MIN / MAX rules) and,
 // for keys that are packed exactly, the key columns decoded from the table's key words.  accAt(j): accumulator j of the group.
 template <class AccAt>
+__device__ __forceinline__ void EmitAggregate(const KeyedFinalizeArgs& f, int k, int64_t g, uint32_t seen, AccAt accAt) {
+    const int kind = f.aggs[k].kind;
+    uint64_t v = accAt(f.agg_src[k]);
+    bool valid = true;
+    if (f.agg_row_index[k]) {
+        valid = v != ~0ull;  // smallest row with a non-null argument, none -> null
+        if (valid) v &= kRowIndexMask;  // (the order of the single-byte-key path sits above the row index)
+    } else {
+        if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
+            v = F64FromOrdered(v);
+            // the group's first non-null argument was a NaN: the reference's state never leaves it
+            if (f.agg_nan_src[k] >= 0) {
+                const uint64_t first = accAt(f.agg_nan_src[k]);
+                if (first != ~0ull && (first & 1ull)) v = 0x7FF8000000000000ull;
+            }
+            // a zero result: the first zero that arrived stays, `<` / `>` do not tell the two zeros apart
+            if (f.agg_zero_src[k] >= 0 && (v << 1) == 0) {
+                const uint64_t first = accAt(f.agg_zero_src[k]);
+                if (first != ~0ull) v = (first & 1ull) << 63;
+            }
+        }
+        if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> f.agg_src[k]) & 1u;
+        if (!valid) v = 0;
+        v = PayloadToStored(v, f.agg_out_type[k]);
+    }
+    if (f.agg_vals[k] != nullptr) {
+        StoreTyped(f.agg_vals[k], f.agg_row_index[k] ? 8 : TypeWidth(f.agg_out_type[k]), g, v);
+        if (f.agg_valid_bytes[k] != nullptr) f.agg_valid_bytes[k][g] = valid ? 1 : 0;
+    }
+}
+
+// Key k of a group from the 127 packed bits (lo, hi: Finish() undone), which start at bit `pos`; returns the next key's.
+__device__ __forceinline__ int EmitKey(const KeyedFinalizeArgs& f, int k, int pos, int64_t g, uint64_t lo, uint64_t hi) {
+    const int type = f.keys[k].type;
+    const int nbits = 8 * TypeWidth(type);
+    uint64_t bits;
+    if (pos < 64) {
+        bits = lo >> pos;
+        if (pos > 0 && pos + nbits > 64) bits |= hi << (64 - pos);
+    } else {
+        bits = hi >> (pos - 64);
+    }
+    bits &= WidthMask(nbits);
+    pos += nbits;
+    StoreTyped(f.key_vals[k], TypeWidth(type), g, bits);
+    if (f.keys[k].nullable) {
+        const uint64_t isNull = pos < 64 ? (lo >> pos) & 1ull : (hi >> (pos - 64)) & 1ull;
+        pos += 1;
+        if (f.key_valid_bytes[k] != nullptr) f.key_valid_bytes[k][g] = isNull ? 0 : 1;
+    }
+    return pos;
+}
+
+template <class AccAt>
 __device__ __forceinline__ void EmitGroup(const KeyedFinalizeArgs& f, int64_t g, uint64_t klo, uint64_t khi, uint32_t seen, uint64_t rep,
                                           AccAt accAt) {
     if (f.group_rep_row != nullptr) f.group_rep_row[g] = rep;
-    for (int k = 0; k < f.naggs; ++k) {
-        const int kind = f.aggs[k].kind;
-        uint64_t v = accAt(f.agg_src[k]);
-        bool valid = true;
-        if (f.agg_row_index[k]) {
-            valid = v != ~0ull;  // smallest row with a non-null argument, none -> null
-            if (valid) v &= kRowIndexMask;  // (the order of the single-byte-key path sits above the row index)
-        } else {
-            if (kind == AGG_MIN_F || kind == AGG_MAX_F) {
-                v = F64FromOrdered(v);
-                // the group's first non-null argument was a NaN: the reference's state never leaves it
-                if (f.agg_nan_src[k] >= 0) {
-                    const uint64_t first = accAt(f.agg_nan_src[k]);
-                    if (first != ~0ull && (first & 1ull)) v = 0x7FF8000000000000ull;
-                }
-                // a zero result: the first zero that arrived stays, `<` / `>` do not tell the two zeros apart
-                if (f.agg_zero_src[k] >= 0 && (v << 1) == 0) {
-                    const uint64_t first = accAt(f.agg_zero_src[k]);
-                    if (first != ~0ull) v = (first & 1ull) << 63;
-                }
-            }
-            if (kind != AGG_COUNT && f.aggs[k].check_valid) valid = (seen >> f.agg_src[k]) & 1u;
-            if (!valid) v = 0;
-            v = PayloadToStored(v, f.agg_out_type[k]);
-        }
-        if (f.agg_vals[k] != nullptr) {
-            StoreTyped(f.agg_vals[k], f.agg_row_index[k] ? 8 : TypeWidth(f.agg_out_type[k]), g, v);
-            if (f.agg_valid_bytes[k] != nullptr) f.agg_valid_bytes[k][g] = valid ? 1 : 0;
-        }
-    }
+    for (int k = 0; k < f.naggs; ++k) EmitAggregate(f, k, g, seen, accAt);
     if (!f.hashed) {
-        // undo Finish(): 127 packed bits
         const uint64_t lo = klo | (khi << 63), hi = khi >> 1;
         int pos = 0;
-        for (int k = 0; k < f.nkeys; ++k) {
-            const int type = f.keys[k].type;
-            const int nbits = 8 * TypeWidth(type);
-            uint64_t bits;
-            if (pos < 64) {
-                bits = lo >> pos;
-                if (pos > 0 && pos + nbits > 64) bits |= hi << (64 - pos);
-            } else {
-                bits = hi >> (pos - 64);
-            }
-            bits &= WidthMask(nbits);
-            pos += nbits;
-            StoreTyped(f.key_vals[k], TypeWidth(type), g, bits);
-            if (f.keys[k].nullable) {
-                const uint64_t isNull = pos < 64 ? (lo >> pos) & 1ull : (hi >> (pos - 64)) & 1ull;
-                pos += 1;
-                if (f.key_valid_bytes[k] != nullptr) f.key_valid_bytes[k][g] = isNull ? 0 : 1;
-            }
-        }
+        for (int k = 0; k < f.nkeys; ++k) pos = EmitKey(f, k, pos, g, lo, hi);
     }
 }
 
@@ -524,7 +528,6 @@ __global__ __launch_bounds__(kBlock) void RegionEmitKernel(const RegionEmitArgs)
     uint64_t* lAcc = lRep + (hashed ? R : 0);
     uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(s.naggs) * R);
     __shared__ uint32_t lWordStart[64 + 1];  // groups in the 64-slot words before each word of the table; [nwords]: all
-    __shared__ unsigned long long lBase;
     __shared__ uint32_t lStop;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwords = R / 64;
@@ -653,21 +656,358 @@ __global__ __launch_bounds__(kBlock) void RegionEmitKernel(const RegionEmitArgs)
             }
             if (lane < nwords) lWordStart[lane + 1] = inc;
             if (lane == 0) lWordStart[0] = 0;
-            const uint32_t total = __shfl(inc, 63, 64);
-            if (lane == 0) lBase = total != 0 ? atomicAdd(a.out_count, static_cast<unsigned long long>(total)) : 0ull;
         }
         __syncthreads();
-        const uint64_t base = lBase;
         const uint32_t total = lWordStart[nwords];
-        if (base + total <= f.capacity) {
-            for (int j = 0; j * kBlock < R; ++j) {
-                const int i = j * kBlock + threadIdx.x;
-                const uint64_t klo = i < R ? lLo[i] : kEmpty;
-                const uint64_t taken = __ballot(klo != kEmpty);
-                if (klo == kEmpty) continue;
-                const int64_t g = int64_t(base) + lWordStart[i >> 6] + __popcll(taken & ((1ull << lane) - 1ull));
-                EmitGroup(f, g, klo, two ? lHi[i] : 0ull, lSeen[i], hashed ? lRep[i] : 0ull, [&](int k) { return lAcc[size_t(k) * R + i]; });
+        if (threadIdx.x == 0) a.region_groups[region] = total;
+        const uint64_t row0 = uint64_t(region) * uint64_t(R);
+        for (int j = 0; j * kBlock < R; ++j) {
+            const int i = j * kBlock + threadIdx.x;
+            const uint64_t klo = i < R ? lLo[i] : kEmpty;
+            const uint64_t taken = __ballot(klo != kEmpty);
+            if (klo == kEmpty) continue;
+            const uint64_t at = row0 + lWordStart[i >> 6] + __popcll(taken & ((1ull << lane) - 1ull));
+            a.tmp_lo[at] = klo;
+            if (two) a.tmp_hi[at] = lHi[i];
+            if (hashed) a.tmp_rep[at] = lRep[i];
+            a.tmp_seen[at] = lSeen[i];
+            for (int k = 0; k < s.naggs; ++k) a.tmp_acc[size_t(k) * a.tmp_stride + at] = lAcc[size_t(k) * R + i];
+        }
+    }
+}
+
+// The same pass for keys that are packed exactly (nothing to verify in memory), built around what it is bound by: the
+// instructions of the probes.  A lane takes kEmitC records at a time, hashes them in straight-line code, and looks at the
+// first slot of each with plain reads, all of them in flight together: at the load the host sizes these tables for, most
+// records find their key there.  The rest -- keys not yet in the table, collisions -- walk on in a loop that takes one
+// step for every record still looking, claims free slots by compare-and-swap, and skips the records that are done.
+// Double hashing: inside LDS a probe sequence gains nothing from being contiguous, and strides that differ from key to
+// key keep the sequences short.  First slot and stride come from the bits of the key's table position above those that
+// chose the region.  The accumulators are then updated from registers, the next records are on their way from HBM
+// meanwhile, and nothing in the loop over the records waits for another wave.  Keys of exactly 64 bits
+// (KeyedSink.rec_raw64) live in the table as the one word their records carry; the one value that equals the free
+// marker has a slot of its own behind the table.
+constexpr int kEmitC = 4;                  // records per lane and trip
+constexpr int kEmitWave = kEmitC * 64;
+// kRaw: 64-bit keys carried as one word; kTwo: the table keeps a hi word; kCountOnly: one aggregate, a count of rows (no
+// operands, no masks, no seen flags).  (What the launch knows is compiled in: the pass is bound by its instructions.)
+template <bool kRaw, bool kTwo, bool kCountOnly>
+__global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmitArgs) {
+    const RegionEmitArgs& a = KernArgsAs<RegionEmitArgs>();
+    const KeyedSink& s = a.s;
+    extern __shared__ uint64_t lRegion[];
+    const int R = a.region_slots, Rs = a.small_slots;
+    const uint32_t slotMask = uint32_t(R - 1);
+    const int posShift = 64 - __builtin_clzll(s.table_mask);  // bits of a table position that choose slot and region in the scan's table
+    constexpr bool raw = kRaw, two = kTwo;
+    const int naggs = kCountOnly ? 1 : s.naggs;
+    const int R1 = R + 1;  // (slot R: the raw key ~0)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool anyCheck = false;
+    if (!kCountOnly) {
+        for (int k = 0; k < naggs; ++k) anyCheck = anyCheck || s.aggs[k].check_valid != 0;
+    }
+    uint64_t* lLo = lRegion;
+    uint64_t* lHi = lLo + R1;
+    uint64_t* lAcc = lHi + (two ? R : 0);
+    uint32_t* lSeen = reinterpret_cast<uint32_t*>(lAcc + size_t(naggs) * R1);
+    uint16_t* lList = reinterpret_cast<uint16_t*>(lSeen + (anyCheck ? R1 : 0));  // the slots in use, in slot order
+    __shared__ uint32_t lWordStart[64 + 1];  // groups in the 64-slot words before each word of the table; [nwords]: all
+    const int nwords = R / 64;
+    const bool needMask = !kCountOnly && a.rec.mask != nullptr;
+    uint32_t err = 0;
+#ifdef SSA_REGION_TIMING
+    uint64_t tphase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast = __builtin_readcyclecounter();
+#define SSA_RT(i) do { const uint64_t now_ = __builtin_readcyclecounter(); tphase[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define SSA_RT(i) do {} while (0)
+#endif
+
+    // first slot and stride of a key's walk
+    auto startOf = [&](uint64_t lo, uint64_t hi, uint32_t& slot, uint32_t& step) {
+        const uint64_t pos = TablePos(lo, hi) >> posShift;
+        slot = uint32_t(pos) & slotMask;
+        step = (uint32_t(pos >> 10) | 1u) & slotMask;
+    };
+    // one step of a walk: the key's slot, or -1 (go on: `slot` has moved unless the slot's owner is between its two stores)
+    auto visit = [&](uint64_t lo, uint64_t hi, uint32_t& slot, uint32_t step) -> int {
+        uint64_t seen = __hip_atomic_load(lLo + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen == kEmpty) {
+            seen = atomicCAS(reinterpret_cast<unsigned long long*>(lLo + slot), static_cast<unsigned long long>(kEmpty), static_cast<unsigned long long>(lo));
+            if (seen == kEmpty) {
+                if (two) __hip_atomic_store(lHi + slot, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return int(slot);
             }
+        }
+        if (seen == lo) {
+            if (!two) return int(slot);
+            const uint64_t ch = __hip_atomic_load(lHi + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ch == hi) return int(slot);
+            if (ch == kUnpublished) return -1;  // the same slot again
+        }
+        slot = (slot + step) & slotMask;
+        return -1;
+    };
+    // the records [i0, i0 + kEmitWave) of this wave, as far as they exist, from HBM into registers
+    auto loadRecords = [&](uint32_t i0, uint32_t last, uint64_t (&lo)[kEmitC], uint64_t (&hi)[kEmitC]) {
+#pragma unroll
+        for (int c = 0; c < kEmitC; ++c) {
+            const uint32_t i = i0 + c * 64 + lane;
+            lo[c] = i < last ? a.rec.lo[i] : 0ull;
+            hi[c] = 0;
+        }
+        if (two) {
+#pragma unroll
+            for (int c = 0; c < kEmitC; ++c) {
+                const uint32_t i = i0 + c * 64 + lane;
+                hi[c] = i < last ? a.rec.hi[i] : 0ull;
+            }
+        }
+    };
+
+    for (int region = blockIdx.x; region < a.nregions; region += gridDim.x) {
+        const uint32_t first = a.region_start[region], last = a.region_start[region + 1];
+        const uint64_t small0 = uint64_t(region) * uint64_t(Rs);
+        // on their way while the table is set up: the first slots of the scan's table, the wave's first records
+        const uint64_t seed0 = int(threadIdx.x) < Rs ? s.t_key_lo[small0 + threadIdx.x] : kEmpty;
+        uint64_t nlo[kEmitC], nhi[kEmitC];
+        loadRecords(first + wave * kEmitWave, last, nlo, nhi);
+        SSA_RT(0);
+        // (also keeps the previous region's last pass over the table and this region's set-up apart)
+        if (!__syncthreads_or((first != last || seed0 != kEmpty || Rs > kBlock) ? 1 : 0)) continue;
+        SSA_RT(1);
+        for (int i = threadIdx.x; i < R1; i += kBlock) {
+            lLo[i] = kEmpty;
+            if (two && i < R) lHi[i] = kUnpublished;
+            if (anyCheck) lSeen[i] = 0;
+            if (kCountOnly) lAcc[i] = 0;
+            else for (int k = 0; k < naggs; ++k) lAcc[size_t(k) * R1 + i] = TableIdentity(s.aggs[k].kind);
+        }
+        __syncthreads();
+        SSA_RT(2);
+        // what the scan's workgroups merged into this region of their table
+        for (int i = threadIdx.x; i < Rs && !(s.pad2_ & 4); i += kBlock) {
+            const uint64_t slo = i == int(threadIdx.x) ? seed0 : s.t_key_lo[small0 + i];
+            if (slo == kEmpty || err != 0) continue;
+            const uint64_t shi = s.two_words ? s.t_key_hi[small0 + i] : 0ull;
+            const uint64_t lo = raw ? (slo | (shi << 63)) : slo, hi = raw ? 0ull : shi;
+            int g = -1;
+            if (raw && lo == kEmpty) {
+                g = R;
+                lLo[R] = 0;
+            } else {
+                uint32_t slot, step;
+                startOf(slo, shi, slot, step);
+                for (uint32_t tries = 0; g < 0 && tries < 3u * uint32_t(R) + 64u; ++tries) g = visit(lo, hi, slot, step);
+            }
+            if (g < 0) {
+                err |= SCAN_TABLE_FULL;
+                continue;
+            }
+            for (int k = 0; k < naggs; ++k) {
+                const int kind = s.aggs[k].kind;
+                const uint64_t v = s.t_acc[size_t(k) * s.acc_stride + small0 + i];
+                if (v != TableIdentity(kind)) AccUpdate(kind, lAcc + size_t(k) * R1 + g, v);
+            }
+            if (anyCheck) {
+                const uint32_t seen = s.t_seen[small0 + i];
+                if (seen != 0) atomicOr(lSeen + g, seen);
+            }
+        }
+        SSA_RT(3);
+        // the region's records, kEmitWave per wave at a time
+        for (uint32_t w0 = first + wave * kEmitWave; w0 < last && !(s.pad2_ & 1); w0 += (kBlock / 64) * kEmitWave) {
+            uint64_t lo[kEmitC], hi[kEmitC];
+            uint32_t slot[kEmitC], step[kEmitC];
+            uint32_t live = 0, pending = 0;
+#pragma unroll
+            for (int c = 0; c < kEmitC; ++c) {
+                lo[c] = nlo[c];
+                hi[c] = nhi[c];
+            }
+            if (w0 + (kBlock / 64) * kEmitWave < last) loadRecords(w0 + (kBlock / 64) * kEmitWave, last, nlo, nhi);
+            uint64_t seen[kEmitC];
+#pragma unroll
+            for (int c = 0; c < kEmitC; ++c) {
+                // (table positions are those of the key words the scan's tables hold: TablePosRaw says what they are for a raw word)
+                const uint64_t pos = (raw ? TablePosRaw(lo[c]) : TablePos(lo[c], hi[c])) >> posShift;
+                slot[c] = uint32_t(pos) & slotMask;
+                step[c] = (uint32_t(pos >> 10) | 1u) & slotMask;
+                seen[c] = lLo[slot[c]];
+            }
+#pragma unroll
+            for (int c = 0; c < kEmitC; ++c) {
+                if (w0 + c * 64 + lane >= last) continue;
+                live |= 1u << c;
+                if (raw && lo[c] == kEmpty) {
+                    slot[c] = uint32_t(R);
+                    lLo[R] = 0;
+                } else if (two || seen[c] != lo[c]) {
+                    pending |= 1u << c;
+                }
+            }
+            if (err != 0) live = pending = 0;
+            // a first slot that read as free is claimed at once (one-word keys: nothing else to store); what is then
+            // still pending are collisions and lost races
+            if (!two) {
+#pragma unroll
+                for (int c = 0; c < kEmitC; ++c) {
+                    if (((pending >> c) & 1u) && seen[c] == kEmpty) {
+                        const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(lLo + slot[c]), static_cast<unsigned long long>(kEmpty),
+                                                        static_cast<unsigned long long>(lo[c]));
+                        seen[c] = prev == kEmpty ? lo[c] : prev;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < kEmitC; ++c) {
+                    if (!((pending >> c) & 1u)) continue;
+                    if (seen[c] == lo[c]) pending &= ~(1u << c); else slot[c] = (slot[c] + step[c]) & slotMask;
+                }
+            }
+            uint32_t tries = 0;
+            while (__any(pending != 0)) {
+#pragma unroll
+                for (int c = 0; c < kEmitC; ++c) {
+                    if (!((pending >> c) & 1u)) continue;
+                    if (visit(lo[c], hi[c], slot[c], step[c]) >= 0) pending &= ~(1u << c);
+                }
+                if (++tries > 3u * uint32_t(R) + 64u) {  // (an odd stride visits every slot: the table is full)
+                    if (pending != 0) err |= SCAN_TABLE_FULL;
+                    live = pending = 0;
+                }
+            }
+            if (kCountOnly) {
+#pragma unroll
+                for (int c = 0; c < kEmitC; ++c) {
+                    if ((live >> c) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(lAcc + slot[c]), 1ull);
+                }
+                continue;
+            }
+            // the accumulators, one aggregate after the other (what describes an aggregate is the same for every record)
+            uint32_t masks[kEmitC];
+#pragma unroll
+            for (int c = 0; c < kEmitC; ++c) masks[c] = ((live >> c) & 1u) ? ~0u : 0u;
+            if (needMask) {
+#pragma unroll
+                for (int c = 0; c < kEmitC; ++c) {
+                    if ((live >> c) & 1u) masks[c] = a.rec.mask[w0 + uint32_t(c * 64 + lane)];
+                }
+            }
+            int valSlot = 0;
+            for (int k = 0; k < naggs; ++k) {
+                const int kind = s.aggs[k].kind;
+                uint64_t* acc = lAcc + size_t(k) * R1;
+                if (kind == AGG_COUNT) {
+#pragma unroll
+                    for (int c = 0; c < kEmitC; ++c) {
+                        if ((masks[c] >> k) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(acc + slot[c]), 1ull);
+                    }
+                } else {
+                    const uint64_t* vals = a.rec.val + size_t(valSlot) * size_t(a.stride);
+                    ++valSlot;
+                    uint64_t v[kEmitC];
+#pragma unroll
+                    for (int c = 0; c < kEmitC; ++c) v[c] = ((masks[c] >> k) & 1u) ? vals[w0 + uint32_t(c * 64 + lane)] : 0ull;
+#pragma unroll
+                    for (int c = 0; c < kEmitC; ++c) {
+                        if ((masks[c] >> k) & 1u) AccUpdate(kind, acc + slot[c], v[c]);
+                    }
+                }
+                if (s.aggs[k].check_valid) {
+#pragma unroll
+                    for (int c = 0; c < kEmitC; ++c) {
+                        if (((masks[c] >> k) & 1u) && !((lSeen[slot[c]] >> k) & 1u)) atomicOr(lSeen + slot[c], 1u << k);
+                    }
+                }
+            }
+        }
+        SSA_RT(4);
+        if (__syncthreads_or(err != 0 ? 1 : 0)) {
+            if (threadIdx.x == 0) atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
+            break;
+        }
+        SSA_RT(5);
+        if (s.pad2_ & 2) continue;
+        // The groups leave in slot order.  Word w of the table = slots 64 w .. 64 w + 63.
+        for (int j = 0; j * kBlock < R; ++j) {
+            const int i = j * kBlock + threadIdx.x;
+            const uint64_t taken = __ballot(i < R && lLo[i] != kEmpty);
+            if (lane == 0 && i < R) lWordStart[(i >> 6) + 1] = uint32_t(__popcll(taken));
+        }
+        __syncthreads();
+        if (wave == 0) {  // (64 words at most: one lane each)
+            uint32_t c = lane < nwords ? lWordStart[lane + 1] : 0u;
+            uint32_t inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (lane < nwords) lWordStart[lane + 1] = inc;
+            if (lane == 0) lWordStart[0] = 0;
+        }
+        __syncthreads();
+        SSA_RT(6);
+        const uint32_t inTable = lWordStart[nwords];
+        const bool extra = lLo[R] != kEmpty;
+        const uint32_t ngroups = inTable + (extra ? 1u : 0u);
+        if (ngroups > uint32_t(R)) {  // (a full table and the key behind it: one row more than the region has in the temporary table)
+            if (threadIdx.x == 0) atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
+            break;
+        }
+        if (threadIdx.x == 0) a.region_groups[region] = ngroups;
+        // the slots in use, listed, then array after array over the list: every lane has a group, and neighbouring lanes
+        // write neighbouring rows
+        for (int j = 0; j * kBlock < R; ++j) {
+            const int i = j * kBlock + threadIdx.x;
+            const bool there = i < R && lLo[i] != kEmpty;
+            const uint64_t taken = __ballot(there);
+            if (there) lList[lWordStart[i >> 6] + __popcll(taken & ((1ull << lane) - 1ull))] = uint16_t(i);
+        }
+        if (threadIdx.x == 0 && extra) lList[inTable] = uint16_t(R);
+        __syncthreads();
+        const uint64_t row0 = uint64_t(region) * uint64_t(R);
+        for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kBlock) {
+            const int i = lList[idx];
+            uint64_t elo = lLo[i < R ? i : 0], ehi = two ? lHi[i < R ? i : 0] : 0ull;
+            if (raw) RawKeyWords(i == R ? kEmpty : elo, elo, ehi);
+            a.tmp_lo[row0 + idx] = elo;
+            if (kRaw || kTwo) a.tmp_hi[row0 + idx] = ehi;
+            a.tmp_seen[row0 + idx] = anyCheck ? lSeen[i] : 0u;
+        }
+        for (int k = 0; k < naggs; ++k) {
+            for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kBlock) a.tmp_acc[size_t(k) * a.tmp_stride + row0 + idx] = lAcc[size_t(k) * R1 + lList[idx]];
+        }
+        SSA_RT(7);
+    }
+#ifdef SSA_REGION_TIMING
+    if (threadIdx.x == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.status) + 16;
+        for (int i = 0; i < 8; ++i) atomicAdd(dbg + i, static_cast<unsigned long long>(tphase[i]));
+    }
+#endif
+#undef SSA_RT
+}
+
+// The groups of all regions, which the region pass left as rows [region * R, region * R + groups of the region) of the
+// temporary table, to their places in the output columns: region after region, so the order of the result is the same
+// from run to run.  offsets: the exclusive scan of the regions' group counts.  Rows beyond the output's capacity are not
+// written (the host looks at the total and runs this kernel again with longer columns).
+__global__ __launch_bounds__(kBlock) void RegionCompactEmitKernel(const RegionEmitArgs) {
+    const RegionEmitArgs& a = KernArgsAs<RegionEmitArgs>();
+    const KeyedFinalizeArgs& f = a.f;
+    const int R = a.region_slots;
+    for (int region = blockIdx.x; region < a.nregions; region += gridDim.x) {
+        const uint32_t n = a.region_groups[region];
+        const int64_t base = a.region_offsets[region];
+        if (uint64_t(base) + n > f.capacity) continue;
+        const uint64_t row0 = uint64_t(region) * uint64_t(R);
+        for (uint32_t idx = threadIdx.x; idx < n; idx += kBlock) {
+            const uint64_t at = row0 + idx;
+            const uint64_t khi = (!f.hashed && f.two_words) ? a.tmp_hi[at] : 0ull;
+            const uint64_t rep = f.group_rep_row != nullptr ? a.tmp_rep[at] : 0ull;
+            EmitGroup(f, base + idx, a.tmp_lo[at], khi, a.tmp_seen[at], rep, [&](int j) { return a.tmp_acc[size_t(j) * a.tmp_stride + at]; });
         }
     }
 }
@@ -828,17 +1168,50 @@ hipError_t LaunchRegionApply(const RegionApplyArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-size_t RegionEmitLdsBytes(const KeyedSink& s, int regionSlots) { return RegionApplyLdsBytes(s, regionSlots); }
+size_t RegionEmitLdsBytes(const KeyedSink& s, int regionSlots) {
+    if (s.hashed) return RegionApplyLdsBytes(s, regionSlots);
+    const bool two = s.two_words != 0 && s.rec_raw64 == 0;
+    bool anyCheck = false;
+    for (int k = 0; k < s.naggs; ++k) anyCheck = anyCheck || s.aggs[k].check_valid != 0;
+    const size_t r1 = size_t(regionSlots) + 1;
+    return r1 * (8 + 8 * size_t(s.naggs)) + (two ? size_t(regionSlots) * 8 : 0) + (anyCheck ? r1 * 4 : 0) + r1 * 2 + 16;
+}
+
+namespace {
+bool CountOnlySink(const KeyedSink& s) { return s.naggs == 1 && s.aggs[0].kind == AGG_COUNT && s.aggs[0].check_valid == 0; }
+
+using RegionKernel = void (*)(const RegionEmitArgs);
+RegionKernel ExactRegionKernel(bool raw, bool two, bool countOnly) {
+    if (raw) return countOnly ? RegionEmitExactKernel<true, false, true> : RegionEmitExactKernel<true, false, false>;
+    if (two) return countOnly ? RegionEmitExactKernel<false, true, true> : RegionEmitExactKernel<false, true, false>;
+    return countOnly ? RegionEmitExactKernel<false, false, true> : RegionEmitExactKernel<false, false, false>;
+}
+}  // namespace
 
 hipError_t ConfigureRegionKernels(int maxLdsBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&RegionEmitKernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    for (int v = 0; v < 6 && e == hipSuccess; ++v) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ExactRegionKernel(v / 2 == 0, v / 2 == 1, v % 2 != 0)), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    }
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&RegionApplyKernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
     return e;
 }
 
 hipError_t LaunchRegionEmit(const RegionEmitArgs& a, hipStream_t st) {
     const int grid = a.nregions < kMaxGrid * 16 ? a.nregions : kMaxGrid * 16;
-    hipLaunchKernelGGL(RegionEmitKernel, dim3(uint32_t(grid)), dim3(kBlock), RegionEmitLdsBytes(a.s, a.region_slots), st, a);
+    if (a.s.hashed) {
+        hipLaunchKernelGGL(RegionEmitKernel, dim3(uint32_t(grid)), dim3(kBlock), RegionEmitLdsBytes(a.s, a.region_slots), st, a);
+    } else {
+        const bool raw = a.s.rec_raw64 != 0, two = a.s.two_words != 0 && !raw;
+        const bool countOnly = CountOnlySink(a.s) && a.rec.mask == nullptr;
+        hipLaunchKernelGGL(ExactRegionKernel(raw, two, countOnly), dim3(uint32_t(grid)), dim3(kBlock), RegionEmitLdsBytes(a.s, a.region_slots), st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t LaunchRegionCompactEmit(const RegionEmitArgs& a, hipStream_t st) {
+    const int grid = a.nregions < kMaxGrid * 16 ? a.nregions : kMaxGrid * 16;
+    hipLaunchKernelGGL(RegionCompactEmitKernel, dim3(uint32_t(grid)), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
 

@@ -237,10 +237,12 @@ struct RegionApplyArgs {
 // LDS bytes the apply pass needs for regions of `region_slots` slots.
 size_t RegionApplyLdsBytes(const KeyedSink& s, int region_slots);
 hipError_t LaunchRegionApply(const RegionApplyArgs& a, hipStream_t st);
-// The same records aggregated region by region in LDS and emitted straight into the output columns: no table of the
-// whole grouping in HBM.  `s` carries the scan's own level-2 table, which in this mode holds only what the scan's
-// workgroups merged into it as they ended: nregions regions of small_slots slots, chosen by the same key bits as the
-// records' regions.
+// The same records aggregated region by region in LDS, with no table of the whole grouping in HBM.  `s` carries the
+// scan's own level-2 table, which in this mode holds only what the scan's workgroups merged into it as they ended:
+// nregions regions of small_slots slots, chosen by the same key bits as the records' regions.  The pass leaves the groups
+// of region r as rows [r * region_slots, + region_groups[r]) of a temporary table (tmp_*: key words as the tables hold
+// them, accumulators, seen flags, representative rows); LaunchRegionCompactEmit then writes them to the output columns
+// at region_offsets[r] (the exclusive scan of region_groups), formatted like KeyedEmitKernel's.
 struct RegionEmitArgs {
     KeyedSink s;
     const DevColumn* cols;        // hashed keys: rows are compared by their key values
@@ -252,13 +254,21 @@ struct RegionEmitArgs {
     int32_t nregions;
     const uint32_t* region_start; // [nregions + 1]
     uint32_t* status;
-    KeyedFinalizeArgs f;          // the output columns; f.capacity: the rows they hold (tile_offsets and t_* unused)
-    unsigned long long* out_count; // zero before the launch; afterwards the number of groups, whether they fitted or not
+    uint32_t* region_groups;      // [nregions]
+    const int64_t* region_offsets; // [nregions + 1] (the compacting kernel)
+    uint64_t* tmp_lo;             // [nregions * region_slots]
+    uint64_t* tmp_hi;             // two-word keys
+    uint64_t* tmp_rep;            // hashed keys
+    uint64_t* tmp_acc;            // [naggs][tmp_stride]
+    uint32_t* tmp_seen;
+    uint64_t tmp_stride;
+    KeyedFinalizeArgs f;          // the compacting kernel: the output columns; f.capacity: the rows they hold (tile_offsets and t_* unused)
 };
 static_assert(sizeof(RegionEmitArgs) <= 4096, "kernel arguments are limited to 4 KB");
 size_t RegionEmitLdsBytes(const KeyedSink& s, int region_slots);
 hipError_t ConfigureRegionKernels(int maxLdsBytes);
 hipError_t LaunchRegionEmit(const RegionEmitArgs& a, hipStream_t st);
+hipError_t LaunchRegionCompactEmit(const RegionEmitArgs& a, hipStream_t st);
 // tile_counts[t] = occupied slots among slots [t * kTileRows, (t + 1) * kTileRows); capacity is a multiple of kTileRows
 hipError_t LaunchKeyedTileCount(const uint64_t* t_key_lo, uint64_t capacity, uint32_t* tile_counts, hipStream_t st);
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st);

@@ -58,6 +58,16 @@ __device__ __forceinline__ uint32_t Fold32(uint64_t lo, uint64_t hi) {
     return x;
 }
 
+// Position of a key in the table in HBM (40 bits; the table's mask cuts it down), and with it the region of the table a
+// deferred update of the key belongs to.  One 64-bit multiply (Fibonacci hashing: the top bits of the product depend on
+// every bit of the key): this is computed for every record in every pass of the sort and again in the region pass.
+// The key words are those the tables hold (KeyBuilder::Finish); for a 64-bit key carried as one raw word the first line
+// is that word again, so that TablePosRaw(raw) is the same position.
+__device__ __forceinline__ uint64_t TablePosRaw(uint64_t raw) { return (raw * 0x9E3779B97F4A7C15ull) >> 24; }
+__device__ __forceinline__ uint64_t TablePos(uint64_t lo, uint64_t hi) {
+    return TablePosRaw((lo | (hi << 63)) ^ ((hi >> 1) * 0xC2B2AE3D27D4EB4Full));
+}
+
 // Order-preserving map double -> uint64 (so float min/max become integer atomics) and back.
 __device__ __forceinline__ uint64_t OrderedFromF64(uint64_t bits) {
     return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
@@ -623,7 +633,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
                 }
                 bool placed = true;
                 if (sl < 0) {
-                    const int64_t g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, uint64_t(h32) * 0x9E3779B97F4A7C15ull >> 24, klo, khi, twoWords, 4096u, abortWord);
+                    const int64_t g = TableUpsert(tKeyLo, tKeyHi, tableMask, regionMask, TablePos(klo, khi), klo, khi, twoWords, 4096u, abortWord);
                     if (g < 0) {
                         if (abortWord != nullptr && !(m.err & SCAN_TABLE_FULL)) atomicOr(a.status, uint32_t(SCAN_TABLE_FULL));
                         m.err |= SCAN_TABLE_FULL;
@@ -915,7 +925,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
                     if (twoWords && !s.rec_raw64) rs.rec_hi[row] = khi;  // (the lo word: at the end of the tile, for every row)
                     sl = kDeferredSlot;
                 } else if (sl < 0) {
-                    const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
+                    const uint64_t start = TablePos(klo, khi);
                     int64_t g;
                     if (byHash) {
                         g = TableUpsertVerified(tKeyLo, tKeyHi, tRepRow, tableMask, regionMask, start, klo, khi, row, 4096u, sameRows, abortWord);
@@ -1153,7 +1163,7 @@ __device__ __forceinline__ void ScanKeyedBody() {
         const uint64_t hi = twoWords ? lHi[i] : 0ull;
         const uint32_t d = lDense[i];
         const uint32_t h = Fold32(lo, twoWords ? hi : 0ull);
-        const uint64_t start = uint64_t(h) * 0x9E3779B97F4A7C15ull >> 24;
+        const uint64_t start = TablePos(lo, twoWords ? hi : 0ull);
         int64_t g;
         if (hashed && (hi >> 63) != 0) {
             const uint64_t row = lRep[i];

@@ -145,24 +145,32 @@ Status Executor::ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& arg
     return Status::OK();
 }
 
-// The sorted records aggregated region by region in LDS and written straight into the output columns `fa` describes
-// (RegionEmitKernel).  `sink`: the scan's sink, whose table holds `regions` regions of `smallSlots` slots; `ldsSlots`: slots of
-// the LDS table of a region.  *groups: the number of groups -- more than fa.capacity when the columns were too short (nothing
-// was written then, and the call can be repeated with longer columns).  Ends with the stream synchronised.
-Status Executor::EmitDeferredRecords(const KeyedSink& sink, const ScanArgs& args, const SortedRecords& sorted, int64_t rows, int nvals,
-                                     int ldsSlots, int smallSlots, uint64_t regions, const KeyedFinalizeArgs& fa, int64_t* groups) {
-    RegionEmitArgs ea{};
+// The sorted records aggregated region by region in LDS (RegionEmitKernel / RegionEmitExactKernel); the groups of the
+// regions are left in a temporary table, counted and their places in the output scanned.  `sink`: the scan's sink, whose
+// table holds `regions` regions of `smallSlots` slots; `ldsSlots`: slots of the LDS table of a region.  The number of
+// groups is on its way into *groupsAt (pinned host memory, or read after the next synchronisation of the stream).
+Status Executor::AggregateDeferredRecords(const KeyedSink& sink, const ScanArgs& args, const SortedRecords& sorted, int64_t rows, int nvals,
+                                          int ldsSlots, int smallSlots, uint64_t regions, RegionGroups& out, int64_t* groupsAt) {
+    RegionEmitArgs& ea = out.args;
+    ea = RegionEmitArgs{};
     ea.s = sink;
-    BufferPtr devCols;
-    if (sink.hashed) {
-        devCols = Buffer::Alloc(sizeof(args.cols));
+    if (const char* env = std::getenv("SSA_REGION_DEBUG")) ea.s.pad2_ = std::atoi(env);  // experiments: parts of the pass left out
+    const bool twoWords = sink.two_words != 0, hashed = sink.hashed != 0;
+    if (hashed) {
+        BufferPtr devCols = Buffer::Alloc(sizeof(args.cols));
         if (!devCols) return Status::Hip("out of device memory");
         SSA_HIP(hipMemcpyAsync(devCols->Ptr, args.cols, sizeof(args.cols), hipMemcpyHostToDevice, StreamHandle));
         ea.cols = static_cast<const DevColumn*>(devCols->Ptr);
+        out.keep.push_back(devCols);
     }
-    BufferPtr counter = Buffer::Alloc(256);
-    if (!counter) return Status::Hip("out of device memory");
-    SSA_HIP(hipMemsetAsync(counter->Ptr, 0, 8, StreamHandle));
+    const size_t slots = size_t(regions) * size_t(ldsSlots);
+    BufferPtr tmpLo = Buffer::Alloc(slots * 8), tmpHi = Buffer::Alloc(twoWords ? slots * 8 : 64), tmpRep = Buffer::Alloc(hashed ? slots * 8 : 64);
+    BufferPtr tmpAcc = Buffer::Alloc(size_t(sink.naggs) * slots * 8 + 64), tmpSeen = Buffer::Alloc(slots * 4);
+    BufferPtr counts = Buffer::Alloc(size_t(regions) * 4 + 64);
+    BufferPtr offsets = Buffer::Alloc((size_t(regions) + 1 + (size_t(regions) + 4095) / 4096 + 2) * 8 + 64), total = Buffer::Alloc(256);
+    if (!tmpLo || !tmpHi || !tmpRep || !tmpAcc || !tmpSeen || !counts || !offsets || !total) return Status::Hip("out of device memory");
+    out.keep.insert(out.keep.end(), {tmpLo, tmpHi, tmpRep, tmpAcc, tmpSeen, counts, offsets, total});
+    SSA_HIP(hipMemsetAsync(counts->Ptr, 0, size_t(regions) * 4, StreamHandle));  // (a region without records leaves no count)
     ea.rec = sorted.set;
     ea.stride = rows;
     ea.nvals = nvals;
@@ -171,13 +179,32 @@ Status Executor::EmitDeferredRecords(const KeyedSink& sink, const ScanArgs& args
     ea.nregions = int32_t(regions);
     ea.region_start = sorted.region_start;
     ea.status = static_cast<uint32_t*>(StatusWord->Ptr);
-    ea.f = fa;
-    ea.out_count = static_cast<unsigned long long*>(counter->Ptr);
+    ea.region_groups = static_cast<uint32_t*>(counts->Ptr);
+    ea.region_offsets = static_cast<const int64_t*>(offsets->Ptr);
+    ea.tmp_lo = static_cast<uint64_t*>(tmpLo->Ptr);
+    ea.tmp_hi = static_cast<uint64_t*>(tmpHi->Ptr);
+    ea.tmp_rep = static_cast<uint64_t*>(tmpRep->Ptr);
+    ea.tmp_acc = static_cast<uint64_t*>(tmpAcc->Ptr);
+    ea.tmp_seen = static_cast<uint32_t*>(tmpSeen->Ptr);
+    ea.tmp_stride = slots;
     SSA_HIP(LaunchRegionEmit(ea, StreamHandle));
-    int64_t* at = HostWords ? reinterpret_cast<int64_t*>(HostWords + 8) : groups;
-    SSA_HIP(hipMemcpyAsync(at, counter->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
-    SSA_HIP(hipStreamSynchronize(StreamHandle));
-    *groups = *at;
+    SSA_HIP(LaunchTileScan(ea.region_groups, int64_t(regions), static_cast<int64_t*>(offsets->Ptr), static_cast<int64_t*>(total->Ptr), StreamHandle));
+    SSA_HIP(hipMemcpyAsync(groupsAt, total->Ptr, 8, hipMemcpyDeviceToHost, StreamHandle));
+    if (std::getenv("SSA_REGION_TIMING")) {  // diagnostics build only (-DSSA_REGION_TIMING): ticks per phase, summed over workgroups
+        unsigned long long t[8];
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        SSA_HIP(hipMemcpy(t, static_cast<char*>(StatusWord->Ptr) + 128, 64, hipMemcpyDeviceToHost));
+        SSA_HIP(hipMemset(static_cast<char*>(StatusWord->Ptr) + 128, 0, 64));
+        std::fprintf(stderr, "region pass ticks: first loads %llu, vote %llu, set-up %llu, seeds %llu, records %llu, vote %llu, count %llu, rows out %llu\n", t[0], t[1],
+                     t[2], t[3], t[4], t[5], t[6], t[7]);
+    }
+    return Status::OK();
+}
+
+// The groups the region pass left, to the output columns `fa` describes (room for all of them).
+Status Executor::EmitRegionGroups(RegionGroups& groups, const KeyedFinalizeArgs& fa) {
+    groups.args.f = fa;
+    SSA_HIP(LaunchRegionCompactEmit(groups.args, StreamHandle));
     return Status::OK();
 }
 
