@@ -161,11 +161,14 @@ __global__ __launch_bounds__(1024) void RadixStartScanKernel(const RadixArgs) {
 
 // The records to their places.  A tile of the chunk is first ordered by digit inside LDS (indices only), then written
 // out in that order: neighbouring lanes then write neighbouring records of one (segment, digit), whole lines at a time.
+// kRaw: 64-bit keys in one word (RadixArgs.raw64) -- the ordered tile keeps no key words in LDS (they are read once more,
+// from the cache, where they are written out), which lets twice the workgroups share a CU.
+template <bool kRaw>
 __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
     const RadixArgs& a = KernArgsAs<RadixArgs>();
     __shared__ uint32_t lCursor[256], lCount[256], lBase[256 + 1];
     __shared__ uint32_t lWave[kBlock / 64];
-    __shared__ uint64_t lSortedLo[kRadixTile];
+    __shared__ uint64_t lSortedLo[kRaw ? 1 : kRadixTile];
     __shared__ uint16_t lOrder[kRadixTile];
     __shared__ uint8_t lDigit[kRadixTile];
     const int seg = blockIdx.x / a.chunks;
@@ -178,7 +181,8 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
     __syncthreads();
     uint32_t begin, end;
     RadixChunk(a, begin, end);
-    const bool two = a.two_words != 0, raw = a.raw64 != 0;
+    const bool two = a.two_words != 0;
+    constexpr bool raw = kRaw;
     for (uint32_t r0 = begin; r0 < end; r0 += kRadixTile) {
         // (loads without conditions, so that all of them are in flight together: a row past the end reads the last one)
         uint64_t lo[kRadixPerThread], hi[kRadixPerThread];
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         for (int u = 0; u < kRadixPerThread; ++u) {
             if (digit[u] == 0xFFFFFFFFu) continue;
             const uint32_t at = lBase[digit[u]] + rank[u];
-            lSortedLo[at] = lo[u];
+            if (!raw) lSortedLo[at] = lo[u];
             lOrder[at] = uint16_t(u * kBlock + threadIdx.x);
             lDigit[at] = uint8_t(digit[u]);
         }
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
             const uint32_t at = lCursor[d] + (p - lBase[d]);
             const uint32_t r = r0 + lOrder[p];
             // (64-bit keys in one word: the word as it came, read once more -- from the cache)
-            a.dst.lo[at] = raw ? a.src.lo[r] : lSortedLo[p];
+            a.dst.lo[at] = raw ? a.src.lo[r] : lSortedLo[raw ? 0 : p];
             if (!more) continue;
             if (two && !raw) a.dst.hi[at] = a.src.hi[r];
             if (a.dst.mask != nullptr) a.dst.mask[at] = a.src.mask[r];
@@ -1154,7 +1158,11 @@ hipError_t LaunchRadixOffsets(const RadixArgs& a, hipStream_t st) {
 }
 
 hipError_t LaunchRadixScatter(const RadixArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(RadixScatterKernel, dim3(uint32_t(a.nseg * a.chunks)), dim3(kBlock), 0, st, a);
+    if (a.raw64) {
+        hipLaunchKernelGGL(RadixScatterKernel<true>, dim3(uint32_t(a.nseg * a.chunks)), dim3(kBlock), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(RadixScatterKernel<false>, dim3(uint32_t(a.nseg * a.chunks)), dim3(kBlock), 0, st, a);
+    }
     return hipGetLastError();
 }
 

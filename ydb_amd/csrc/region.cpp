@@ -67,7 +67,10 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
     ra.digit_shift = bitsB;
     ra.ndigits = std::max(64, 1 << bitsA);
     ra.nseg = 1;
-    ra.chunks = int(std::min<int64_t>(768, std::max<int64_t>(1, (rows + 16383) / 16384)));  // (three workgroups of the scatter fit a CU)
+    // (three workgroups a CU; more of them -- raw keys leave room for six -- measured slower: shorter chunks, shorter runs)
+    int64_t workgroups = 768;
+    if (const char* env = std::getenv("SSA_RADIX_WORKGROUPS")) workgroups = std::max(64, std::atoi(env));  // experiments
+    ra.chunks = int(std::min<int64_t>(workgroups, std::max<int64_t>(1, (rows + 16383) / 16384)));
     BufferPtr segA = Buffer::Alloc(64), countsA = Buffer::Alloc(size_t(ra.chunks) * ra.ndigits * 4), startA = Buffer::Alloc(size_t(ra.ndigits + 1) * 4 + 64);
     if (!segA || !countsA || !startA) return Status::Hip("out of device memory");
     const uint32_t whole[2] = {0u, uint32_t(rows)};
@@ -91,7 +94,7 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
         rb.digit_shift = 0;
         rb.ndigits = 1 << bitsB;
         rb.nseg = 1 << bitsA;
-        rb.chunks = std::max(1, std::min(16, 768 / rb.nseg));
+        rb.chunks = std::max(1, std::min(16, int(workgroups) / rb.nseg));
         rb.seg_start = ra.out_start;
         BufferPtr countsB = Buffer::Alloc(size_t(rb.nseg) * rb.chunks * rb.ndigits * 4);
         BufferPtr startB = Buffer::Alloc((size_t(rb.nseg) * rb.ndigits + 1) * 4 + 64);
