@@ -239,6 +239,13 @@ int ssa_sharding_hash(ssa_program_t* program, const ssa_batch_t* batch, const ch
 int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
                        uint32_t shards_count, ssa_batch_t** out, uint32_t* out_shard_rows, char** err);
 
+/* The same split without the balancing of the lists: part = |hash| % parts_count and nothing else, so that rows with equal
+ * keys are in the same part whichever batch they come from.  No counterpart in the reference (its balanced lists are
+ * what a KQP compute task reads, and equal keys may end in different ones); this is the partitioning step of the
+ * exchange between GPUs, where every rank must send a group's partial aggregates to the one rank that merges it. */
+int ssa_batch_partition_by_key(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
+                               uint32_t parts_count, ssa_batch_t** out, uint32_t* out_part_rows, char** err);
+
 /* ---- TColumnFilter: filters kept in HBM and their algebra ---------------------------------------------------------- */
 
 /* NArrow::TColumnFilter (ydb/core/formats/arrow/arrow_filter.h:20-211) with its bits in device memory.  The reference

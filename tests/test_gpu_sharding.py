@@ -118,6 +118,34 @@ def test_split_by_hashed_keys_and_skewed_data_triggers_the_size_correction(n, sh
     assert max(sizes) <= max(n // shards + 1, min(sizes))  # the correction ran
 
 
+@pytest.mark.parametrize("parts", [2, 8])
+def test_partition_by_key_alone_keeps_equal_keys_together(parts):
+    """The partitioning of the exchange between GPUs: no balancing, so two batches (two ranks' partial tables) send a key
+    they share to the same part however skewed their rows are -- and the part is the one the oracle's hash names."""
+    from oracle import sharding_oracle as so
+    rng = np.random.default_rng(40 + parts)
+    pc = _container([(1, "region"), (2, "day"), (3, "x")])
+    where = {}
+    for n, hot in ((5000, 0.7), (3001, 0.0), (777, 0.95)):
+        region = [("north" if rng.random() < hot else r) for r in _strings(rng, n, 6)]
+        day = rng.integers(0, 5, n).astype(np.int16)
+        batch = {"region": region, "day": day, "x": rng.integers(0, 1 << 40, n).astype(np.int64)}
+        out, sizes = pc.PartitionByKey(pc.Import(batch), ["region", "day"], parts)
+        got = pc.Export(out)
+        assert sum(sizes) == n
+        h = so.hash_rows(_columns(batch, ["region", "day"]), n, so.COMPUTE_SHARDING_SEED).view(np.int64)
+        expect = {(r, int(d)): int(abs(int(hh)) % parts) for r, d, hh in zip(region, day, h)}
+        at = 0
+        for part, size in enumerate(sizes):
+            for r, d in zip(got["region"].values[at:at + size], np.asarray(got["day"].values)[at:at + size]):
+                key = (r.decode() if isinstance(r, bytes) else r, int(d))
+                assert expect[key] == part
+                assert where.setdefault(key, part) == part
+            at += size
+        # rows of a part keep their input order, every row is there once
+        assert sorted(np.asarray(got["x"].values).tolist()) == sorted(batch["x"].tolist())
+
+
 def test_unsharded_cases_return_the_batch_unchanged():
     rng = np.random.default_rng(5)
     n = 1000

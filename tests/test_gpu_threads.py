@@ -146,6 +146,10 @@ def test_batches_of_a_shard_never_wait_for_a_build(tmp_path):
     assert a["build_ms"] > 50 and any(f.endswith(".co") for f in os.listdir(d)), (a, os.listdir(d))
     b = _child("disk2", {"SSA_JIT_CACHE_DIR": d, "SSA_JIT": "1"})
     assert b["built"] >= 1 and b["build_ms"] == 0 and b["launches"] > 0, b
+    # ... but only what a library of the same build left there: the key of a code object holds a digest of the kernel
+    # sources, the compiler's options and the runtime's version (SSA_JIT_KEY_SALT stands in for another build)
+    c = _child("disk3", {"SSA_JIT_CACHE_DIR": d, "SSA_JIT": "1", "SSA_JIT_KEY_SALT": "another build"})
+    assert c["built"] >= 1 and c["build_ms"] > 50 and c["launches"] > 0, c
 
 
 def test_a_failed_allocation_does_not_poison_the_next_launch():

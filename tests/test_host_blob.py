@@ -75,3 +75,27 @@ def test_damaged_blobs_are_errors():
         outcomes["ok" if text is not None else "error"] += 1
         assert text is not None or err
     assert outcomes["error"] > 100
+
+
+def test_a_row_count_beyond_32_bits_is_refused():
+    """A batch that announces 2^61 rows: the sizes of its buffers, as products of that count, would wrap to a few bytes."""
+    import struct
+
+    import pyarrow as pa
+    rows = 12345
+    batch = pa.record_batch({"i64": pa.array(np.arange(rows, dtype=np.int64)), "s": pa.array(["x"] * rows)})
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, batch.schema) as w:
+        w.write_batch(batch)
+    blob = sink.getvalue().to_pybytes()
+    text, err = describe(blob)
+    assert text is not None and f"rows={rows} " in text, err
+    # the RecordBatch message's length and its field nodes' lengths: every 64-bit 12345 ahead of the body
+    body = blob.index(np.arange(8, dtype=np.int64).tobytes())
+    head = blob[:body]
+    needle = struct.pack("<q", rows)
+    assert head.count(needle) >= 3
+    for huge in (1 << 61, (1 << 62) + 5, (1 << 31)):
+        damaged = head.replace(needle, struct.pack("<q", huge)) + blob[body:]
+        text, err = describe(damaged)
+        assert text is None and "row count" in err, (text, err)

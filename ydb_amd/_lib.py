@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_program_apply_many", "ssa_apply_many_stats", "ssa_keyed_stats", "ssa_keyed_compact_stats",
     "ssa_batch_pack_layout", "ssa_batch_pack_data", "ssa_batch_unpack", "ssa_batch_concat", "ssa_batch_slice", "ssa_batch_rename",
     "ssa_batch_column_name", "ssa_merge_sorted", "ssa_batch_export", "ssa_batch_rows",
-    "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
+    "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_batch_partition_by_key", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
     "ssa_gen_lineitem",
     "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
     "ssa_filter_combine_sequential_and", "ssa_filter_info", "ssa_filter_runs", "ssa_filter_bits", "ssa_filter_filtered_count",
@@ -142,6 +142,8 @@ def load() -> ctypes.CDLL:
     lib.ssa_sharding_hash.restype = i32
     lib.ssa_sharding_split.argtypes = [vp, vp, P(ctypes.c_char_p), sz, ctypes.c_uint32, P(vp), vp, P(vp)]
     lib.ssa_sharding_split.restype = i32
+    lib.ssa_batch_partition_by_key.argtypes = [vp, vp, P(ctypes.c_char_p), sz, ctypes.c_uint32, P(vp), vp, P(vp)]
+    lib.ssa_batch_partition_by_key.restype = i32
     lib.ssa_specialization_stats.argtypes = [P(i64), P(ctypes.c_double), P(i64)]
     lib.ssa_specialization_stats.restype = None
     lib.ssa_gen_lineitem.argtypes = [P(LineitemColumns), i64, i64, ctypes.c_uint64, i32]

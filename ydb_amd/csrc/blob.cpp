@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,18 @@ struct PendingBuffer {
 
 Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<FieldDesc>& schema,
                              std::vector<BatchPtr>& out) {
+    const Status st = ImportBlobsQueued(blobs, schema, out);
+    // An error may leave copies queued on this executor's stream: out of the caller's blobs, and into buffers that go back
+    // to the pool all executors share when this call's vectors die.  Nothing is handed back before the stream is past them.
+    if (!st.ok()) {
+        (void)hipStreamSynchronize(StreamHandle);
+        (void)hipGetLastError();
+    }
+    return st;
+}
+
+Status Executor::ImportBlobsQueued(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<FieldDesc>& schema,
+                                   std::vector<BatchPtr>& out) {
     (void)hipSetDevice(Device);
     out.clear();
     const size_t nb = blobs.size();
@@ -65,6 +78,14 @@ Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>
     for (size_t i = 0; i < nb; ++i) {
         if (!blobs[i].first && blobs[i].second) return Status::Invalid("null blob");
         SSA_RETURN_NOT_OK(ParseIpcBlob(blobs[i].first, blobs[i].second, schema, parsed[i]));
+        // Row counts come from the blob's metadata, unchecked so far: the buffer sizes below are products of them, and a count
+        // near 2^61 would wrap those products to a few bytes (Arrow's Validate() refuses such a batch; so does every kernel
+        // here that counts rows in 32 bits).
+        constexpr int64_t kMaxRows = INT32_MAX;
+        bool rowsOk = parsed[i].Rows >= 0 && parsed[i].Rows <= kMaxRows;
+        for (const IpcColumn& c : parsed[i].Columns) rowsOk = rowsOk && c.Length >= 0 && c.Length <= kMaxRows && c.NullCount <= c.Length;
+        for (const IpcDictionary& d : parsed[i].Dicts) rowsOk = rowsOk && d.Rows >= 0 && d.Rows <= kMaxRows;
+        if (!rowsOk) return Status::Invalid("a row count of the blob is negative or beyond 2^31 - 1");
         bool zstd = parsed[i].Codec == IPC_ZSTD;
         for (const IpcDictionary& d : parsed[i].Dicts) zstd = zstd || d.Codec == IPC_ZSTD;
         if (zstd) return Status::Unsupported("ZSTD body compression of an IPC blob (LZ4_FRAME and uncompressed bodies are decoded)");

@@ -591,8 +591,24 @@ int ssa_sharding_hash(ssa_program_t* program, const ssa_batch_t* batch, const ch
     return SSA_OK;
 }
 
+namespace {
+int ShardingSplitEntry(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys, uint32_t shards_count,
+                       bool balance, ssa_batch_t** out, uint32_t* out_shard_rows, char** err);
+}
+
 int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
                        uint32_t shards_count, ssa_batch_t** out, uint32_t* out_shard_rows, char** err) {
+    return ShardingSplitEntry(program, batch, key_columns, n_keys, shards_count, /*balance=*/true, out, out_shard_rows, err);
+}
+
+int ssa_batch_partition_by_key(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys,
+                               uint32_t parts_count, ssa_batch_t** out, uint32_t* out_part_rows, char** err) {
+    return ShardingSplitEntry(program, batch, key_columns, n_keys, parts_count, /*balance=*/false, out, out_part_rows, err);
+}
+
+namespace {
+int ShardingSplitEntry(ssa_program_t* program, const ssa_batch_t* batch, const char* const* key_columns, size_t n_keys, uint32_t shards_count,
+                       bool balance, ssa_batch_t** out, uint32_t* out_shard_rows, char** err) {
     if (err) *err = nullptr;
     std::lock_guard<std::mutex> g(program->Lock);
     {
@@ -605,12 +621,13 @@ int ssa_sharding_split(ssa_program_t* program, const ssa_batch_t* batch, const c
     std::vector<uint32_t> rows;
     BatchPtr plain;
     Status st = program->Exec->DecodedBatch(batch->Batch, plain);
-    if (st.ok()) st = program->Exec->ShardingSplit(*plain, names, shards_count, result, rows);
+    if (st.ok()) st = program->Exec->ShardingSplit(*plain, names, shards_count, result, rows, balance);
     if (!st.ok()) return Fail(st, err);
     if (out_shard_rows) std::memcpy(out_shard_rows, rows.data(), rows.size() * sizeof(uint32_t));
     *out = new ssa_batch{result};
     return SSA_OK;
 }
+}  // namespace
 
 // ---- TColumnFilter ----------------------------------------------------------------------------------------
 

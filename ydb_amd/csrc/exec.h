@@ -177,6 +177,8 @@ public:
     // `schema`) -> HBM-resident batches, one per blob; all compressed buffers are decoded by one kernel launch.
     Status ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<FieldDesc>& schema,
                        std::vector<BatchPtr>& out);
+    Status ImportBlobsQueued(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<FieldDesc>& schema,
+                             std::vector<BatchPtr>& out);  // (ImportBlobs without the wait on an error's way out)
 
     // TProgram::ApplyTo: every step in order.
     Status ApplyProgram(const TProgram& program, const BatchPtr& in, BatchPtr& out);
@@ -192,7 +194,7 @@ public:
     // shard), shardRows[s] of them in shard s.  A batch that the reference leaves unsharded comes back unchanged with all
     // rows counted in shard 0.
     Status ShardingSplit(const Batch& in, const std::vector<std::string>& keyNames, uint32_t shards, BatchPtr& out,
-                         std::vector<uint32_t>& shardRows);
+                         std::vector<uint32_t>& shardRows, bool balance = true);
 
     // -- TColumnFilter ------------------------------------------------------------------------------------
     // TColumnFilter(std::vector<bool>) given as runs: run j has `runs[j]` rows of value firstValue ^ (j & 1).

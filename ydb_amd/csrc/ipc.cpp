@@ -1,5 +1,6 @@
 #include "ipc.h"
 
+#include <climits>
 #include <cstring>
 
 namespace ssa {
@@ -237,6 +238,7 @@ Status ParseIpcBlob(const uint8_t* blob, size_t size, const std::vector<FieldDes
                 if (fb.Scalar<int8_t>(compression, 1, 0) != 0) return Status::Unsupported("IPC body compression method other than BUFFER");
                 if (d.Codec != IPC_LZ4_FRAME && d.Codec != IPC_ZSTD) return Status::Unsupported("unknown IPC body compression codec");
             }
+            if (fb.Ok() && d.Rows > INT32_MAX) return Status::Invalid("a row count of the blob is beyond 2^31 - 1");
             if (!fb.Ok() || d.Rows < 0 || nnodes != 1 || nbuffers != 3) return Status::Unsupported("a dictionary that is not one column of strings");
             d.NullCount = fb.Read<int64_t>(nodes + 8);
             if (fb.Read<int64_t>(nodes) != d.Rows || d.NullCount < 0 || d.NullCount > d.Rows) return Status::Invalid("damaged DictionaryBatch field node");
@@ -274,6 +276,8 @@ Status ParseIpcBlob(const uint8_t* blob, size_t size, const std::vector<FieldDes
             if (out.Codec != IPC_LZ4_FRAME && out.Codec != IPC_ZSTD) return Status::Unsupported("unknown IPC body compression codec");
         }
         if (!fb.Ok() || out.Rows < 0) return Status::Invalid("damaged RecordBatch metadata");
+        // (buffer sizes are products of this count: near 2^61 they would wrap to a few bytes; no batch here has 2^31 rows)
+        if (out.Rows > INT32_MAX) return Status::Invalid("a row count of the blob is beyond 2^31 - 1");
         if (nnodes != fields.size()) return Status::Invalid("the RecordBatch has " + std::to_string(nnodes) + " columns, the schema " + std::to_string(fields.size()));
         out.BodyOffset = bodyPos;
         out.BodyLength = bodyLength;

@@ -73,6 +73,10 @@ struct Rtc {
     }
 };
 
+// Options of every run-time compilation (the target is added per device).
+const char* const kCompileOptions[] = {"-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm", "-ffp-contract=off",
+                                       "-mllvm", "-pragma-unroll-threshold=1048576"};
+
 uint64_t Fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
     const unsigned char* b = static_cast<const unsigned char*>(p);
     for (size_t i = 0; i < n; ++i) {
@@ -137,6 +141,35 @@ struct State {
 State& St() {
     static State s;
     return s;
+}
+
+// What a built kernel depends on besides its own key: the kernel sources embedded in this library (their argument
+// structs are the launch ABI), the compiler's options and the runtime's version.  Part of every cache key, so that a code
+// object a differently built library left in SSA_JIT_CACHE_DIR is never loaded.  (SSA_JIT_KEY_SALT: tests.)
+const std::string& BuildFingerprint() {
+    static const std::string fp = [] {
+        uint64_t a = 1469598103934665603ull, b = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < kEmbeddedCount; ++i) {
+            a = Fnv(kEmbeddedNames[i], std::strlen(kEmbeddedNames[i]) + 1, a);
+            a = Fnv(kEmbeddedSources[i], std::strlen(kEmbeddedSources[i]) + 1, a);
+            b = Fnv(kEmbeddedSources[i], std::strlen(kEmbeddedSources[i]) + 1, b);
+        }
+        std::string s = "sources:";
+        char hex[40];
+        std::snprintf(hex, sizeof(hex), "%016llx%016llx", static_cast<unsigned long long>(a), static_cast<unsigned long long>(b));
+        s += hex;
+        s += " options:";
+        for (const char* o : kCompileOptions) {
+            s += o;
+            s += ' ';
+        }
+        int runtime = 0;
+        if (hipRuntimeGetVersion(&runtime) != hipSuccess) (void)hipGetLastError();
+        s += "runtime:" + std::to_string(runtime);
+        if (const char* salt = std::getenv("SSA_JIT_KEY_SALT")) s += std::string(" salt:") + salt;
+        return s;
+    }();
+    return fp;
 }
 
 constexpr size_t kMaxBuiltKernels = 256;        // READY entries kept (each holds a code object and a module per device)
@@ -230,9 +263,9 @@ bool Compile(const Job& job, std::vector<char>& code, std::string& why) {
     // built kernel two instructions of the step program sit next to each other, and the reference rounds after
     // each of them (a * b + c differed in the last bit on a quarter of the rows).  Where a fused operation is
     // wanted (the register-held groups) the source asks for it by name.
-    const char* opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-inline-asm", "-ffp-contract=off",
-                          "-mllvm", "-pragma-unroll-threshold=1048576"};
-    const hiprtcResult rc = st.R.CompileProgram(prog, int(sizeof(opts) / sizeof(opts[0])), opts);
+    std::vector<const char*> opts = {archOpt.c_str()};
+    for (const char* o : kCompileOptions) opts.push_back(o);
+    const hiprtcResult rc = st.R.CompileProgram(prog, int(opts.size()), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         (void)st.R.GetProgramLogSize(prog, &n);
@@ -371,11 +404,12 @@ bool KernelJit::Get(int device, const char* mainHeader, const char* entry, const
             arch = prop.gcnArchName;
         }
         std::string key;
-        key.reserve(imageBytes + defines.size() + 96);
+        key.reserve(imageBytes + defines.size() + 256);
         key.append(mainHeader).push_back('\0');
         key.append(entry).push_back('\0');
         key.append(defines).push_back('\0');
         key.append(arch).push_back('\0');
+        key.append(BuildFingerprint()).push_back('\0');
         key.append(static_cast<const char*>(image), imageBytes);
         Entry& e = st.Entries[key];
         e.LastUse = Clock::now();

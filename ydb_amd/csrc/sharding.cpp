@@ -103,8 +103,10 @@ void PlanSizeCorrection(const std::vector<uint64_t>& sizes, std::vector<uint32_t
     }
 }
 
+// `balance`: the reference's size correction.  Without it a row's shard depends on its key alone, which is what an exchange
+// between GPUs needs (equal keys of all senders end in one place); with it the last rows of long lists move elsewhere.
 Status Executor::ShardingSplit(const Batch& in, const std::vector<std::string>& keyNames, uint32_t shards, BatchPtr& out,
-                               std::vector<uint32_t>& shardRows) {
+                               std::vector<uint32_t>& shardRows, bool balance) {
     (void)hipSetDevice(Device);
     if (shards == 0) return Status::Invalid("shards count is zero");
     if (shards > kMaxShards) return Status::Unsupported("more than 512 shards");
@@ -170,7 +172,11 @@ Status Executor::ShardingSplit(const Batch& in, const std::vector<std::string>& 
     std::vector<uint32_t> keep;
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> segments;
     std::vector<uint64_t> finalSizes;
-    PlanSizeCorrection(sizes, keep, segments, finalSizes);
+    if (balance) {
+        PlanSizeCorrection(sizes, keep, segments, finalSizes);
+    } else {
+        finalSizes = sizes;
+    }
     bool corrected = false;
     for (const auto& s : segments) corrected = corrected || !s.empty();
 

@@ -267,6 +267,16 @@ class ProgramContainer:
         self._check(rc, err)
         return DeviceBatch(self._lib, out.value), [int(x) for x in sizes[:shards]]
 
+    def PartitionByKey(self, batch: DeviceBatch, keys: Sequence[str], parts: int) -> Tuple[DeviceBatch, List[int]]:
+        """The batch with its rows grouped part after part by the hash of their keys alone (no balancing of the parts:
+        equal keys are in the same part whichever batch they come from), and the number of rows of every part."""
+        sizes = np.zeros(max(1, parts), dtype=np.uint32)
+        out, err = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = self._lib.ssa_batch_partition_by_key(self._h, batch._h, self._names(keys), len(keys), parts, ctypes.byref(out),
+                                                  sizes.ctypes.data, ctypes.byref(err))
+        self._check(rc, err)
+        return DeviceBatch(self._lib, out.value), [int(x) for x in sizes[:parts]]
+
     def EnableProfile(self, enabled: bool = True):
         self._lib.ssa_profile_enable(self._h, 1 if enabled else 0)
 

@@ -420,7 +420,8 @@ class ShardedScan:
             mark("all-gather")
             parts = [pc.Unpack(h, recv.data_ptr() + r * width, db, keep=recv) for r, (h, db) in enumerate(heads)]
         else:
-            split, counts = pc.ShardingSplit(partial, key_names, world)
+            # (by the key hash alone: the reference's split also balances its lists, which sends equal keys to different places)
+            split, counts = pc.PartitionByKey(partial, key_names, world)
             mark("partition by key hash")
             pieces, at = [], 0
             for r in range(world):
