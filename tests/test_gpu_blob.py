@@ -210,3 +210,59 @@ def test_program_over_a_blob_with_dictionary_columns():
     host = {"ds": strings("ds", True), "flag": strings("flag", True), "db": strings("db", False), "v": exp_cols["v.values"]}
     exp = ssa_oracle.Oracle(resolver, p).apply(host)
     compare_batches(got, exp, key_names=["flag", "db"])
+
+
+def long_match_blob(period, match=100_000):
+    """(blob, expected bytes): an IPC stream with one uint8 column whose data buffer is an LZ4 frame with one 256 KB block
+    (Arrow writes 64 KB ones; the format allows up to 4 MB) -- the pattern as literals, one match `period` bytes back that
+    repeats it for `match` bytes, and the closing literals."""
+    import struct
+
+    import pyarrow as pa
+    import xxhash
+    pattern = bytes((17 * i + 5) % 251 for i in range(period))
+    for extra in range(5, 14):  # (until the buffer Arrow writes is not a multiple of eight bytes long: see below)
+        tail = bytes(range(1, extra + 1))
+        expected = (pattern * (match // period + 2))[:period + match] + tail
+        lit = len(pattern)
+        block = bytearray([(min(lit, 15) << 4) | 15])
+        if lit >= 15:
+            block += b"\xff" * ((lit - 15) // 255) + bytes([(lit - 15) % 255])
+        block += pattern + struct.pack("<H", period)
+        rest = match - 4 - 15
+        block += b"\xff" * (rest // 255) + bytes([rest % 255])
+        block += bytes([len(tail) << 4]) + tail
+        descriptor = bytes([0x60, 0x50])  # version 1, independent blocks, no checksums; blocks of up to 256 KB
+        frame = struct.pack("<I", 0x184D2204) + descriptor + bytes([(xxhash.xxh32(descriptor, seed=0).intdigest() >> 8) & 0xFF])
+        frame += struct.pack("<I", len(block)) + bytes(block) + struct.pack("<I", 0)
+        # a stream written by Arrow for a column of the same length; the frame of its one data buffer is replaced, and with it
+        # the two lengths in the metadata that describe it: the buffer's and the (padded) body's
+        n = len(expected)
+        batch = pa.record_batch({"u8": pa.array(np.frombuffer(expected, dtype=np.uint8))})
+        sink = pa.BufferOutputStream()
+        with pa.ipc.new_stream(sink, batch.schema, options=pa.ipc.IpcWriteOptions(compression="lz4")) as w:
+            w.write_batch(batch)
+        blob = sink.getvalue().to_pybytes()
+        at = blob.index(struct.pack("<I", 0x184D2204))
+        assert struct.unpack_from("<q", blob, at - 8)[0] == n
+        eos = blob.rindex(struct.pack("<iI", -1, 0))
+        head, body = blob[:at - 8], eos - (at - 8)
+        lengths = [c for c in range(body - 7, body) if head.count(struct.pack("<q", c)) == 1]
+        if head.count(struct.pack("<q", body)) != 1 or len(lengths) != 1:
+            continue
+        new_buffer = 8 + len(frame)
+        padded = (new_buffer + 7) // 8 * 8
+        head = head.replace(struct.pack("<q", lengths[0]), struct.pack("<q", new_buffer)).replace(struct.pack("<q", body), struct.pack("<q", padded))
+        return head + struct.pack("<q", n) + frame + b"\0" * (padded - new_buffer) + blob[eos:], expected
+    raise AssertionError("no stream whose two lengths can be told apart")
+
+
+@pytest.mark.parametrize("split", ["1", "0"], ids=["parse_and_copy_apart", "one_wave_does_both"])
+@pytest.mark.parametrize("period", [3, 7, 64])
+def test_a_match_longer_than_64_kb_that_repeats_a_short_pattern(split, period, monkeypatch):
+    """Longer than the 64 KB of output the decode kernels keep in LDS: the match's later bytes come from its own output."""
+    monkeypatch.setenv("SSA_LZ4_SPLIT", split)
+    crafted, expected = long_match_blob(period)
+    pc = container([("u8", None)])
+    got = pc.Export(pc.ImportBlob(crafted))
+    assert bytes(np.asarray(got["u8"].values).astype(np.uint8)) == expected

@@ -131,3 +131,14 @@ def test_lz4_restatement_equals_the_reference_library():
         n = ref.LZ4F_compressFrame(buf, cap, data, len(data), None)
         assert n < (1 << 40)
         assert ipc_oracle.lz4_frame_decode(buf.raw[:n], len(data)) == data
+
+
+@pytest.mark.parametrize("period", [3, 7, 64])
+def test_a_frame_with_a_256_kb_block_and_a_match_longer_than_64_kb(period):
+    """The blob tests/test_gpu_blob.py crafts for the decode kernels, read by the oracle (and, where it was built, by the
+    reference's own LZ4): the crafted stream is a valid one."""
+    from oracle import ipc_oracle
+    from test_gpu_blob import long_match_blob
+    blob, expected = long_match_blob(period)
+    got = ipc_oracle.read_blob(blob)
+    assert bytes(np.asarray(got["u8"]["values"]).astype(np.uint8)) == expected

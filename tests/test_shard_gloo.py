@@ -175,3 +175,16 @@ def test_commands_after_the_aggregation_run_on_the_merged_groups():
     merged = ssa_oracle.Oracle(mr, mp_).apply(shard.partial_batch(parts, prog, tpch.LINEITEM_RESOLVER))
     assert list(merged.keys()) == list(exp.keys())
     compare_batches(merged, exp, key_names=["l_shipdate"], float_sum_names=["142"])
+
+
+def test_a_program_with_two_aggregations_is_refused():
+    """The first aggregation's groups span the shards; a second one over per-shard partial groups would be merged into
+    something else than the second aggregation of the whole table."""
+    from ydb_amd import shard
+    from ydb_amd.ssa_pb import AGG, Aggregate, Program
+    p = (Program().group_by([Aggregate(10, AGG.COUNT, [])], keys=[1, 2])
+         .group_by([Aggregate(11, AGG.SUM, [10])], keys=[1]))
+    with pytest.raises(ValueError, match="more than one GroupBy"):
+        shard.split_at_last_group_by(p)
+    with pytest.raises(ValueError, match="more than one GroupBy"):
+        shard.merge_program(p, [(1, "a"), (2, "b")])

@@ -265,11 +265,14 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
                     }
                 }
             } else {
-                // the match overlaps its own output: a pattern of `off` bytes repeated
+                // the match overlaps its own output: a pattern of `off` bytes repeated.  Its first bytes come from the
+                // pattern itself; later ones from the match's own output a whole number of periods back, written by an
+                // earlier piece (a match longer than the ring has overwritten the pattern's own place by then)
+                const uint32_t periods = ((64u + off - 1u) / off) * off;
                 for (uint32_t base = 0; base < ml; base += 64) {
                     const uint32_t i = base + lane;
                     if (i < ml) {
-                        const uint8_t x = ring[(op - off + (i % off)) & (kRing - 1)];
+                        const uint8_t x = i < periods ? ring[(op - off + (i % off)) & (kRing - 1)] : ring[(op + i - periods) & (kRing - 1)];
                         ring[(op + i) & (kRing - 1)] = x;
                         dst[op + i] = x;
                     }

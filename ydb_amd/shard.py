@@ -62,9 +62,14 @@ def split_at_last_group_by(program: Program) -> Tuple[Program, List[object]]:
     """(the program up to and including its last GroupBy, the commands after it).  Shards run the first part; what
     follows an aggregation (a HAVING filter, avg = sum / count, the final projection) only makes sense on merged
     groups and runs after the merge."""
-    idx = max((i for i, cmd in enumerate(program.commands) if isinstance(cmd, GroupBy)), default=None)
-    if idx is None:
+    found = [i for i, cmd in enumerate(program.commands) if isinstance(cmd, GroupBy)]
+    if not found:
         raise ValueError("program has no GroupBy: shards are concatenated, not merged")
+    if len(found) > 1:
+        # (the groups of the first aggregation span the shards: a second one over per-shard partial groups, merged
+        # afterwards, is not the second aggregation of the whole table)
+        raise ValueError("program has more than one GroupBy: only the last aggregation of a program can be merged across shards")
+    idx = found[-1]
     return Program(commands=list(program.commands[:idx + 1]), version=program.version, kernels=program.kernels), list(program.commands[idx + 1:])
 
 
