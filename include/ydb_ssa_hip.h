@@ -1,8 +1,10 @@
 /*
  * C ABI of the MI355X executor for YDB column-shard SSA programs (libydb_ssa_hip.so).
  *
- * Every entry point replaces one interface of the reference's CPU path; the cited file:line
- * is the reference code a host shim would stop calling.  Plain pointers and sizes only: batches
+ * An entry point either replaces one interface of the reference's CPU path -- the cited file:line is the reference
+ * code a host shim would stop calling -- or says in its comment that it has no counterpart there and what it is for
+ * (set-up and shutdown, counters and profiles for operators and tests, the exchange between GPUs, the entry point that
+ * allocates nothing).  Plain pointers and sizes only: batches
  * cross the boundary through the Arrow C Data Interface (struct ArrowArray / ArrowSchema as in
  * contrib/libs/apache/arrow/cpp/src/arrow/c/abi.h), programs as the serialized protobuf a
  * ColumnShard receives.  All functions are thread-safe unless stated otherwise; none aborts.
@@ -337,23 +339,6 @@ void ssa_profile_read(ssa_program_t* program, double* scan_ms, int64_t* launches
 void ssa_specialization_stats(int64_t* kernels_built, double* build_ms, int64_t* launches);
 
 /* ---- synthetic TPC-H lineitem generated in HBM (benchmark / parity input) ----------------------------------- */
-
-/* Fills caller-provided device arrays with rows [row0, row0 + nrows) of the deterministic synthetic lineitem
- * (counter-based splitmix64 of `seed`, column id and row number).  Any pointer may be NULL to skip that column. */
-struct ssa_lineitem_columns {
-    int32_t* l_shipdate;      /* days since epoch */
-    double* l_quantity;
-    double* l_extendedprice;
-    double* l_discount;
-    double* l_tax;
-    int32_t* rf_offsets;      /* l_returnflag utf8: nrows + 1 offsets */
-    uint8_t* rf_chars;
-    int32_t* ls_offsets;      /* l_linestatus utf8 */
-    uint8_t* ls_chars;
-    int8_t* rf_code;          /* dictionary codes: 0 = "A", 1 = "N", 2 = "R" */
-    int8_t* ls_code;          /* 0 = "F", 1 = "O" */
-};
-int ssa_gen_lineitem(const struct ssa_lineitem_columns* cols, int64_t row0, int64_t nrows, uint64_t seed, int device);
 
 #ifdef __cplusplus
 }

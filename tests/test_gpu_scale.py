@@ -169,3 +169,20 @@ def test_full_shard_sizes(rows):
     for name in ("134", "135", "137", "138"):   # counts are exact
         assert sorted(int(v) for v in merged[name].values) == sorted(int(v) for v in whole1[name].values)
     assert abs((q6_halves[0] + q6_halves[1]) - whole6) <= 1e-12 * abs(whole6)
+
+
+def test_q6_at_sf1_matches_the_oracle():
+    """TPC-H Q6 over an SF1 lineitem (6 001 215 rows, the size the reference's own CPU-runnable configuration names):
+    the whole table in one batch on the device, the oracle over the same rows on the host."""
+    from oracle import ssa_oracle
+    from ydb_amd import tpch
+    n = 6_001_215
+    got = _scan(tpch.q6_program(), tpch.Q6_COLUMNS, tpch.DeviceLineitem(n, utf8_flags=False, code_flags=False))
+    host = tpch.lineitem_host(0, n)
+    exp = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, tpch.q6_program()).apply({c: host[c] for c in tpch.Q6_COLUMNS})
+    assert list(got.keys()) == list(exp.keys()) == ["130"]
+    assert got["130"].type == exp["130"].type
+    g, e = got["130"].to_pylist(), exp["130"].to_pylist()
+    assert len(g) == len(e) == 1
+    # (the reference sums pairwise, the GPU tile by tile: both within a few ulps of the exact sum of ~1.1e5 terms)
+    assert abs(g[0] - e[0]) <= 1e-12 * abs(e[0]), (g, e)

@@ -14,8 +14,8 @@ from ydb_amd.ssa_pb import AGG, F, YQL, Aggregate, Column, Program, olap_program
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ydb_ssa_hip.h")).read()
+def declared_symbols(header="ydb_ssa_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     return sorted(set(re.findall(r"\b(ssa_[a-z0-9_]+)\s*\(", text)))
@@ -29,6 +29,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTED_SYMBOLS) == names
     assert lib.ssa_version().decode().startswith("ydb-ssa-hip")
+    # the benchmark-support library and its header
+    bench = _lib.load_bench()
+    assert declared_symbols("ydb_ssa_bench.h") == sorted(_lib.BENCH_EXPORTED_SYMBOLS)
+    for n in _lib.BENCH_EXPORTED_SYMBOLS:
+        assert hasattr(bench, n), n
+        assert not hasattr(lib, n), n  # (the executor's library carries no benchmark code)
 
 
 def container(program, resolver=tpch.LINEITEM_RESOLVER):

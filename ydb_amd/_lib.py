@@ -47,14 +47,31 @@ EXPORTED_SYMBOLS = [
     "ssa_batch_pack_layout", "ssa_batch_pack_data", "ssa_batch_unpack", "ssa_batch_concat", "ssa_batch_slice", "ssa_batch_rename",
     "ssa_batch_column_name", "ssa_merge_sorted", "ssa_batch_export", "ssa_batch_rows",
     "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_batch_partition_by_key", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
-    "ssa_gen_lineitem",
     "ssa_filter_simple", "ssa_filter_from_runs", "ssa_filter_from_program", "ssa_filter_predicate", "ssa_filter_and", "ssa_filter_or",
     "ssa_filter_combine_sequential_and", "ssa_filter_info", "ssa_filter_runs", "ssa_filter_bits", "ssa_filter_filtered_count",
     "ssa_filter_apply", "ssa_filter_destroy", "ssa_filter_from_program_noalloc",
     "ssa_batch_from_blob", "ssa_batches_from_blobs", "ssa_blob_describe",
 ]
 
+# ... and include/ydb_ssa_bench.h (libydb_ssa_bench.so: benchmark and test support, not part of the executor)
+BENCH_LIB_PATH = os.path.join(_HERE, "lib", "libydb_ssa_bench.so")
+BENCH_EXPORTED_SYMBOLS = ["ssa_gen_lineitem"]
+
 _lib = None
+_bench = None
+
+
+def load_bench() -> ctypes.CDLL:
+    """The benchmark-support library (synthetic lineitem generated in HBM)."""
+    global _bench
+    if _bench is None:
+        load()  # (torch's HIP runtime first, as below)
+        if not os.path.exists(BENCH_LIB_PATH):
+            raise ImportError(f"{BENCH_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        _bench = ctypes.CDLL(BENCH_LIB_PATH)
+        _bench.ssa_gen_lineitem.argtypes = [ctypes.POINTER(LineitemColumns), ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int]
+        _bench.ssa_gen_lineitem.restype = ctypes.c_int
+    return _bench
 
 
 def load() -> ctypes.CDLL:
@@ -146,8 +163,6 @@ def load() -> ctypes.CDLL:
     lib.ssa_batch_partition_by_key.restype = i32
     lib.ssa_specialization_stats.argtypes = [P(i64), P(ctypes.c_double), P(i64)]
     lib.ssa_specialization_stats.restype = None
-    lib.ssa_gen_lineitem.argtypes = [P(LineitemColumns), i64, i64, ctypes.c_uint64, i32]
-    lib.ssa_gen_lineitem.restype = i32
     lib.ssa_filter_simple.argtypes = [i32, P(vp)]
     lib.ssa_filter_simple.restype = i32
     lib.ssa_filter_from_runs.argtypes = [vp, i32, vp, sz, P(vp), P(vp)]

@@ -814,23 +814,4 @@ void ssa_profile_read(ssa_program_t* program, double* scan_ms, int64_t* launches
     p.ScanBytes = 0;
 }
 
-int ssa_gen_lineitem(const ssa_lineitem_columns* cols, int64_t row0, int64_t nrows, uint64_t seed, int device) {
-    if (hipSetDevice(device) != hipSuccess) return SSA_HIP_ERROR;
-    LineitemColumns c{};
-    c.l_shipdate = cols->l_shipdate;
-    c.l_quantity = cols->l_quantity;
-    c.l_extendedprice = cols->l_extendedprice;
-    c.l_discount = cols->l_discount;
-    c.l_tax = cols->l_tax;
-    c.rf_offsets = cols->rf_offsets;
-    c.rf_chars = cols->rf_chars;
-    c.ls_offsets = cols->ls_offsets;
-    c.ls_chars = cols->ls_chars;
-    c.rf_code = cols->rf_code;
-    c.ls_code = cols->ls_code;
-    if (LaunchGenLineitem(c, row0, nrows, seed, nullptr) != hipSuccess) return SSA_HIP_ERROR;
-    if (hipDeviceSynchronize() != hipSuccess) return SSA_HIP_ERROR;
-    return SSA_OK;
-}
-
 }  // extern "C"

@@ -149,7 +149,7 @@ class DeviceLineitem:
                      "ls_offsets", "ls_chars", "rf_code", "ls_code"):
             setattr(cols, name, self.t[name].data_ptr() if name in self.t else None)
         torch.cuda.synchronize(dev)
-        rc = lib.ssa_gen_lineitem(ctypes.byref(cols), row0, nrows, seed, device)
+        rc = _lib.load_bench().ssa_gen_lineitem(ctypes.byref(cols), row0, nrows, seed, device)
         if rc != 0:
             raise RuntimeError(f"ssa_gen_lineitem failed: {rc}")
 
