@@ -113,9 +113,11 @@ def test_small_scans_and_ssa_jit_0_stay_on_the_generic_kernels(monkeypatch):
     from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
     rng = np.random.default_rng(8)
     batch = P.lineitem_like(rng, 5000)
-    # a program no other test uses: a kernel that exists already is used whatever the size of the scan
+    # a program of a shape no other test uses (a kernel that exists already is used whatever the size of the scan, and a
+    # kernel is built for a program's shape: other literals would not make it another program)
     p = (Program().assign_const(100, "Int32", 10464).assign_func(110, F.CMP_LESS_EQUAL, [1, 100]).filter(110)
-         .group_by([Aggregate(130, AGG.SUM, [3]), Aggregate(131, AGG.COUNT, [])]))
+         .assign_func(111, F.CMP_GREATER, [1, 100]).assign_func(112, F.CMP_NOT_EQUAL, [110, 111]).filter(112)
+         .group_by([Aggregate(130, AGG.SUM, [3]), Aggregate(131, AGG.COUNT, []), Aggregate(132, AGG.MAX, [3]), Aggregate(133, AGG.COUNT, [3])]))
     for mode in (None, "0"):
         if mode is None:
             monkeypatch.delenv("SSA_JIT", raising=False)
@@ -226,3 +228,66 @@ def test_a_multiply_and_an_add_are_rounded_separately(jit, monkeypatch):
          .project([101, 102, 104, 106]))
     got, exp = P.both(res, p, batch)
     compare_batches(got, exp)
+
+
+def test_a_query_that_comes_back_with_other_literals_runs_the_kernel_built_for_its_shape(monkeypatch):
+    """Q6 with twenty sets of substitution parameters: the constants of a program are data of a launch, not part of the
+    kernel built for it (they are data in the reference too: ydb/core/tx/program/program.cpp:253-295), so one kernel is
+    built and every result equals the oracle's for its own literals."""
+    from oracle import ssa_oracle
+    from ydb_amd import tpch
+    from ydb_amd.program import ProgramContainer
+    monkeypatch.setenv("SSA_JIT", "1")
+    n = 300_000
+    host = tpch.lineitem_host(0, n)
+    batch = {c: host[c] for c in tpch.Q6_COLUMNS}
+    rng = np.random.default_rng(77)
+    built0, _, launches0 = _stats()
+    results = set()
+    for i in range(20):
+        lo = int(8036 + rng.integers(0, 2000))
+        args = dict(date_lo=lo, date_hi=lo + int(rng.integers(30, 400)), discount=float(rng.integers(2, 10)) / 100.0,
+                    quantity=float(rng.integers(10, 50)))
+        prog = tpch.q6_program(**args)
+        pc = ProgramContainer()
+        ok, err = pc.Init(tpch.LINEITEM_RESOLVER, prog)
+        assert ok, err
+        got = pc.ApplyProgram(batch)
+        exp = ssa_oracle.Oracle(tpch.LINEITEM_RESOLVER, prog).apply(batch)
+        g, e = got["130"].to_pylist()[0], exp["130"].to_pylist()[0]
+        assert (g is None) == (e is None), (args, g, e)
+        if e is not None:
+            assert abs(g - e) <= 1e-12 * abs(e), (args, g, e)
+        results.add(e)
+    built1, _, launches1 = _stats()
+    assert len(results) > 10  # (the literals did change the answer)
+    assert launches1 - launches0 >= 20
+    assert built1 - built0 <= 1, "a kernel was built per literal"
+
+
+def test_patterns_of_one_length_share_a_kernel(monkeypatch):
+    """The bytes of a LIKE pattern are data of the launch as well; its length shapes the code."""
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    from ydb_amd.ssa_pb import AGG, F, Aggregate, Program
+    monkeypatch.setenv("SSA_JIT", "1")
+    rng = np.random.default_rng(78)
+    words = ["google", "yandex", "amazon", "github", "reddit", "zzzzzz"]
+    urls = ["http://%s.%s/%d" % (words[int(rng.integers(0, 5))], "com" if rng.random() < 0.5 else "org", int(rng.integers(0, 1000))) for _ in range(50_000)]
+    batch = {"url": urls}
+    res = [(1, "url")]
+    built0, _, _ = _stats()
+    counts = []
+    for w in words:
+        prog = (Program(version=5).assign_const(10, "Bytes", w.encode()).assign_func(11, F.STR_MATCH, [1, 10]).filter(11)
+                .group_by([Aggregate(20, AGG.COUNT, [])]).project([20]))
+        pc = ProgramContainer()
+        ok, err = pc.Init(res, prog)
+        assert ok, err
+        got = pc.ApplyProgram(batch)
+        exp = ssa_oracle.Oracle(res, prog).apply(batch)
+        assert got["20"].to_pylist() == exp["20"].to_pylist()
+        counts.append(got["20"].to_pylist()[0])
+    built1, _, _ = _stats()
+    assert counts[-1] == 0 and min(counts[:-1]) > 1000
+    assert built1 - built0 <= 1, "a kernel was built per pattern"

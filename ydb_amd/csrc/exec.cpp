@@ -957,6 +957,14 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
     for (int i = 0; i < kMaxLookupTables; ++i) a.tables[i] = LookupTable{nullptr, nullptr, 0};
     a.slices = nullptr;
     a.block_slice = nullptr;
+    // The values of the program's constants and the bytes of its patterns are data of a launch (Machine::ConstBits,
+    // Machine::Pattern): a kernel is built for the program's shape -- types, nulls, pattern lengths -- and a query that
+    // comes back with other literals finds it (constants and parameters are data in the reference too:
+    // ydb/core/tx/program/program.cpp:253-295, :338-356).
+    for (int i = 0; i < kMaxConsts; ++i) {
+        if (!IsStringLike(a.consts[i].type)) a.consts[i].bits = 0;
+    }
+    std::memset(a.pattern, 0, sizeof(a.pattern));
     std::memcpy(image.data(), &a, sizeof(a));
     std::memcpy(reinterpret_cast<char*>(image.data()) + sizeof(ScanArgs), sinkImage, sinkBytes);
     SpecKernel k;

@@ -321,7 +321,15 @@ struct Machine {
         return S().lds_end_off[c] < 0 ? 0xFFFFFFFFu : uint32_t(S().lds_end_off[c]) + uint32_t(waveBase / (64 * U)) * uint32_t(kEndSlotBytes);
     }
     __device__ __forceinline__ uint32_t RegOff(int r) const { return kStatic ? uint32_t(S().lds_reg_offs[r]) : ReadLane32(tRegOff, r); }
-    __device__ __forceinline__ uint64_t ConstBits(int k) const { return kStatic ? S().consts[k].bits : ReadLane64(tConstBits, k); }
+    // The value of a constant is data of the launch, not of the program a kernel is built for: a built kernel reads it from
+    // the kernel arguments (a scalar load the compiler hoists out of the tile loop), so that the same query with another
+    // literal runs the same kernel.  What shapes the code stays with the program: a constant's type, whether it is null,
+    // and, for a string, where its bytes are and how many (the bytes themselves are read through Pattern()).
+    __device__ __forceinline__ uint64_t ConstBits(int k) const {
+        if (!kStatic) return ReadLane64(tConstBits, k);
+        return IsStringLike(S().consts[k].type) ? S().consts[k].bits : a.consts[k].bits;
+    }
+    __device__ __forceinline__ const uint8_t* Pattern() const { return a.pattern; }
     __device__ __forceinline__ uint32_t ConstValid(int k) const { return kStatic ? uint32_t(S().consts[k].valid) : ReadLane32(tConstValid, k); }
     __device__ __forceinline__ int NumCode() const { return kStatic ? S().ncode : ncode; }
     __device__ __forceinline__ int NumCols() const { return kStatic ? S().ncols : ncols; }
@@ -1219,7 +1227,7 @@ struct Machine {
         }
         case OP_STRMATCH: {
             const uint64_t pat = ConstBits(fa);
-            const uint8_t* pp = S().pattern + uint32_t(pat >> 32);
+            const uint8_t* pp = Pattern() + uint32_t(pat >> 32);
             const int32_t pn = int32_t(uint32_t(pat));
             A.ok = ValidityOf(si) & (ConstValid(fa) ? AllMask<U>() : 0u);
 #ifdef SSA_SPEC
@@ -1247,7 +1255,7 @@ struct Machine {
             int32_t pn = 0;
             if (!rhsCol) {
                 const uint64_t pat = ConstBits(fa);
-                pp = S().pattern + uint32_t(pat >> 32);
+                pp = Pattern() + uint32_t(pat >> 32);
                 pn = int32_t(uint32_t(pat));
                 ok &= ConstValid(fa) ? AllMask<U>() : 0u;
             } else {

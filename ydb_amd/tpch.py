@@ -39,12 +39,15 @@ Q1_BYTES_PER_ROW_UTF8 = 4 + 4 * 8 + 2 * (4 + 1)  # + tax, two utf8 flags (offset
 Q1_BYTES_PER_ROW_CODES = 4 + 4 * 8 + 2 * 1       # flags as 1-byte dictionary codes
 
 
-def q6_program() -> Program:
+def q6_program(date_lo: int = None, date_hi: int = None, discount: float = 0.07, quantity: float = 25.0) -> Program:
     """select sum(l_extendedprice * l_discount) where shipdate in [d0, d0 + 1y) and discount between .06 and .08
-    and quantity < 25 -- five Filters in one step, one Assign, GroupBy{SUM}, Projection."""
+    and quantity < 25 -- five Filters in one step, one Assign, GroupBy{SUM}, Projection.  The arguments are the query's
+    substitution parameters (the defaults: the validation values of the TPC-H specification)."""
+    date_lo = Q6_DATE_LO if date_lo is None else date_lo
+    date_hi = Q6_DATE_HI if date_hi is None else date_hi
     p = Program(version=5)
-    p.assign_const(100, "Int32", Q6_DATE_LO).assign_const(101, "Int32", Q6_DATE_HI)
-    p.assign_const(102, "Double", 0.07 - 0.01).assign_const(103, "Double", 0.07 + 0.01).assign_const(104, "Double", 25.0)
+    p.assign_const(100, "Int32", date_lo).assign_const(101, "Int32", date_hi)
+    p.assign_const(102, "Double", discount - 0.01).assign_const(103, "Double", discount + 0.01).assign_const(104, "Double", quantity)
     p.assign_func(110, F.CMP_GREATER_EQUAL, [L_SHIPDATE, 100]).assign_func(111, F.CMP_LESS, [L_SHIPDATE, 101])
     p.assign_func(112, F.CMP_GREATER_EQUAL, [L_DISCOUNT, 102]).assign_func(113, F.CMP_LESS_EQUAL, [L_DISCOUNT, 103])
     p.assign_func(114, F.CMP_LESS, [L_QUANTITY, 104])
