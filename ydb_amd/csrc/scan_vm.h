@@ -330,6 +330,16 @@ struct Machine {
         return IsStringLike(S().consts[k].type) ? S().consts[k].bits : a.consts[k].bits;
     }
     __device__ __forceinline__ const uint8_t* Pattern() const { return a.pattern; }
+    // Eight bytes of the pattern buffer from byte `at` on, read as words of the kernel-argument segment (scalar loads; in a
+    // built kernel `at` is a constant).  `at` + 8 stays inside the buffer's 256 bytes plus the 8 of the field behind it.
+    __device__ __forceinline__ uint64_t PatternWord(uint32_t at) const {
+        typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+        ConstWords w = (ConstWords)(uintptr_t)(a.pattern);
+        const uint32_t i = at >> 2, sh = 8u * (at & 3u);
+        const uint64_t lo = uint64_t(w[i]) | (uint64_t(w[i + 1]) << 32);
+        const uint64_t hi = uint64_t(w[i + 2]);
+        return sh == 0 ? lo : (lo >> sh) | (hi << (64u - sh));
+    }
     __device__ __forceinline__ uint32_t ConstValid(int k) const { return kStatic ? uint32_t(S().consts[k].valid) : ReadLane32(tConstValid, k); }
     __device__ __forceinline__ int NumCode() const { return kStatic ? S().ncode : ncode; }
     __device__ __forceinline__ int NumCols() const { return kStatic ? S().ncols : ncols; }
@@ -648,12 +658,17 @@ struct Machine {
         if (e < b0 || e > limit) {  // offsets that do not describe this buffer (or its last, partial piece): the per-row path
             return false;
         }
-        // the pattern as two 64-bit words with their byte masks
-        uint64_t pw[2] = {0, 0};
-        for (int32_t i = 0; i < pn; ++i) {
-            const uint8_t ch = icase ? AsciiLower(pp[i]) : pp[i];
-            pw[i >> 3] |= uint64_t(ch) << (8 * (i & 7));
-        }
+        // the pattern as two 64-bit words (zero behind its bytes)
+        auto lower8 = [](uint64_t x) {  // ASCII upper-case bytes get bit 5
+            const uint64_t t = x & 0x7F7F7F7F7F7F7F7Full;
+            const uint64_t up = ((t + 0x3F3F3F3F3F3F3F3Full) & ~(t + 0x2525252525252525ull)) & ~x & 0x8080808080808080ull;
+            return x | (up >> 2);
+        };
+        const uint32_t pat0 = uint32_t(pp - Pattern());
+        uint64_t pw[2] = {PatternWord(pat0), pn > 8 ? PatternWord(pat0 + 8u) : 0ull};
+        if (pn < 8) pw[0] &= (1ull << (8 * pn)) - 1ull;
+        if (pn > 8 && pn < 16) pw[1] &= (1ull << (8 * (pn - 8))) - 1ull;
+        if (icase) pw[0] = lower8(pw[0]), pw[1] = lower8(pw[1]);
         const uint32_t p32 = uint32_t(pw[0]);
         const uint32_t m32 = pn >= 4 ? ~0u : ((1u << (8 * pn)) - 1u);
         auto lower4 = [](uint32_t x) {  // ASCII upper-case bytes get bit 5
@@ -672,7 +687,7 @@ struct Machine {
         uint4 cur = piece(first);
         uint4 nxt = piece(first + 1024u);
         for (uint32_t base = first; base < e; base += 1024u) {
-            const uint4 ahead = piece(base + 2048u);  // two pieces are in flight while `cur` is searched
+            const uint4 ahead = piece(base + 2048u);  // two pieces are in flight while `cur` is searched (four measured no faster)
             uint32_t d[8];
             d[0] = cur.x, d[1] = cur.y, d[2] = cur.z, d[3] = cur.w;
             // the 16 bytes behind mine: the next lane's, for the last lane the first lane's of the next piece
