@@ -173,7 +173,9 @@ def main():
     ap.add_argument("--rows", type=int, default=0,
                     help="rows per GPU (default: TPC-H SF100 lineitem; SF1000 / 8 for mixed; ClickBench hits for cb_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="N = 1, workload q1: do not time Q6, Q1-codes and Q1-dictionary as well")
+    ap.add_argument("--no-also", action="store_true", help="N = 1, workload q1: do not time Q6, Q1-codes, Q1-dictionary and the ClickBench programs as well")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank scans a table of --rows rows (default SF100); strong: the table of --rows rows is split over the ranks")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses cuda:0 and the exchange runs over gloo (checks the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -209,6 +211,11 @@ def main():
     clickbench_run = args.workload.startswith("cb_")
     also = ["q6", "q1_codes", "q1_dict"] if (args.workload == "q1" and world == 1 and not args.no_also) else []
     rows = args.rows or (SF1000_SHARD_ROWS if mixed else tpch.SF100_ROWS)
+    total_table_rows = rows
+    if args.scaling == "strong" and not clickbench_run:
+        # the table is the same whatever the number of GPUs: rank r scans rows [r * rows, (r + 1) * rows) of it (the last
+        # rank's range is cut to the table's end)
+        rows = (total_table_rows + world - 1) // world
     resolver = tpch.LINEITEM_RESOLVER
     table = "SF1000 / 8 lineitem shard" if mixed else "SF100-sized lineitem shard"
     stream = []  # (workload key, program, batch, bytes per row, name)
@@ -227,7 +234,10 @@ def main():
         stream.append((args.workload, prog, li.batch(cols), bpr, "ClickBench " + args.workload[3:]))
     else:
         keys = ["q1", "q6"] if mixed else [args.workload]
-        li = tpch.DeviceLineitem(rows, device=local_rank, row0=rank * rows,
+        my_rows = rows
+        if args.scaling == "strong":
+            my_rows = max(0, min(rows, total_table_rows - rank * rows))
+        li = tpch.DeviceLineitem(my_rows, device=local_rank, row0=rank * rows,
                                  utf8_flags=("q1" in keys), code_flags=bool({"q1_codes", "q1_dict"} & set(keys + also)))
         for k in keys:
             prog, cols, bpr, name = tpch_workload(k)
@@ -245,17 +255,28 @@ def main():
 
     third_way = [0]  # keyed scans of the last timed region that took the rows behind the filter one by one
 
-    def timed(scans_, batches, steps, warmup):
+    def timed(scans_, batches, steps, warmup, settle=None, keep=None):
         """`warmup` untimed steps, then exactly `steps` timed ones; one step runs every program of the stream once."""
+        settle = (3 if clickbench_run else 2) if settle is None else settle
+        keep = on_device if keep is None else keep
         results = [None] * len(scans_)
         # The executor builds the step program's kernel at the first large scan and settles how it runs it
         # (register-held groups on or off) on the second; groupings of a million groups take a third such pass (records
         # sorted by table region, or row-by-row updates), and so do groupings behind a filter (the rows that passed taken
         # one by one).  Those passes run here, untimed, like the generation of the table -- each is a second of hiprtc on
         # the host with the GPU idle -- and the warm-up steps asked for come after them.
-        for _ in range((3 if clickbench_run else 2) + warmup):
+        for _ in range(settle + warmup):
             for i, s in enumerate(scans_):
-                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device, lazy=True)
+                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=keep, lazy=True)
+        # (a table of fewer than 2^25 rows has its kernel built by a worker thread while the scans go on with the kernels
+        # the library was built with: the timed steps wait for it, a few seconds at most)
+        waited = time.perf_counter()
+        while time.perf_counter() - waited < 8.0:
+            launches_before = scans_[0].local.SpecializationStats()[2]  # (process-wide: launches of kernels built at run time)
+            results[0] = scans_[0].run(batches[0], gather_device=gather_dev, keep_on_device=keep, lazy=True)
+            if scans_[0].local.SpecializationStats()[2] > launches_before or os.environ.get("SSA_JIT") == "0":
+                break
+            time.sleep(0.05)
         for s in scans_:
             s.local.EnableProfile(True)
             s.local.ReadProfile()
@@ -269,7 +290,7 @@ def main():
         marks = [t0]
         for _ in range(steps):
             for i, s in enumerate(scans_):
-                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=on_device, lazy=True)
+                results[i] = s.run(batches[i], gather_device=gather_dev, keep_on_device=keep, lazy=True)
             marks.append(time.perf_counter())
         barrier()
         elapsed = time.perf_counter() - t0
@@ -333,6 +354,44 @@ def main():
                                  "roofline": roofline_of("q1_slices", prog, kernel_ms, launches, algo_bytes, pc.SpecializationStats()[2])}
         del res, slices
 
+    if also:
+        # The ClickBench half of the target on the same GPU: the scan-aggregates over 1 G rows (10 x hits: at two bytes a row
+        # the hits-sized table is a 50 us launch), the substring search over 25 M URLs (one batch is bounded by int32
+        # offsets), the high-cardinality group-by over a hits-sized table.  Synthetic `hits` generated on the device.
+        from ydb_amd import clickbench
+        del li
+        gc.collect()
+        torch.cuda.empty_cache()
+        for k, cb_rows in (("cb_q1", 1_000_000_000), ("cb_adv", 1_000_000_000), ("cb_q20", 25_000_000), ("cb_userid", clickbench.HITS_ROWS)):
+            cols, bpr = clickbench.COLUMNS[k]
+            hits = clickbench.DeviceHits(cb_rows, device=local_rank, columns=cols)
+            if k == "cb_q20":
+                bpr = 4 + hits.url_bytes / cb_rows
+            prog = clickbench.programs()[k]
+            s = ShardedScan(prog, clickbench.HITS_RESOLVER, device=local_rank)
+            before = one_by_one_scans()
+            e, prof, res = timed([s], [hits.batch(cols)], args.steps, args.warmup, settle=(6 if k == "cb_adv" else 3), keep=(k == "cb_userid"))  # (cb_adv: three ways to run its kernel are timed first)
+            kernel_ms, launches, algo_bytes = prof[0]
+            entry = {"workload": f"ClickBench {k[3:]}, synthetic hits of {cb_rows} rows resident in HBM", "value": cb_rows * args.steps / e,
+                     "unit": "rows/s", "ms_per_step": 1e3 * e / args.steps, "algorithmic_bytes_per_row": bpr,
+                     "groups": res[0].rows if k == "cb_userid" else len(next(iter(res[0].values())).valid)}
+            if k == "cb_userid":
+                # scan, two rounds of the sort, the region pass, the move to the output: several kernels, priced as a step
+                # against the bytes of the key column
+                entry["roofline"] = {"bound": "hbm", "achieved": cb_rows * bpr / (e / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": cb_rows * bpr / (e / args.steps) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                     "kernel": "the whole step: ssa_spec_keyed_plain, RadixCount/Scatter x2, RegionEmitExactKernel, RegionCompactEmitKernel",
+                                     "algorithmic_bytes_per_launch": int(cb_rows * bpr)}
+            else:
+                entry["roofline"] = roofline_of(k, prog, kernel_ms, launches, algo_bytes, s.local.SpecializationStats()[2],
+                                                one_by_one_scans() - before >= args.steps)
+            if not args.no_cpu_baseline:
+                entry["cpu_baseline"] = cpu_baseline(k, seconds_target=6.0, all_cores_seconds=3.0)
+            also_out[k] = entry
+            del hits, s, res
+            gc.collect()
+            torch.cuda.empty_cache()
+
     result = results[0]
     groups = result.rows if on_device else (len(next(iter(result.values())).valid) if result else 0)
     if on_device and world > 1:  # the result is spread over the ranks
@@ -340,7 +399,7 @@ def main():
         dist.all_reduce(t)
         groups = int(t.item())
     if rank == 0:
-        total_rows = rows * world * args.steps * len(stream)
+        total_rows = (total_table_rows if (args.scaling == "strong" and not clickbench_run) else rows * world) * args.steps * len(stream)
         wl_key, prog, _, bpr, name = stream[0]
         kernel_ms, launches, algo_bytes = profiles[0]
         names = " then ".join(n for _, _, _, _, n in stream)
@@ -353,11 +412,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if not clickbench_run else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{names}, {table} per GPU ({rows} rows), whole shard as one HBM-resident batch" +
+            "config": {"workload": (f"{names}, {table} of {total_table_rows} rows split over {world} GPU(s) ({rows} rows each), every part one HBM-resident batch"
+                                    if (args.scaling == "strong" and not clickbench_run) else
+                                    f"{names}, {table} per GPU ({rows} rows), whole shard as one HBM-resident batch") +
                                    (" (one step = every program of the stream once; value counts the rows each program scanned)" if mixed else ""),
                        "rows_per_gpu": rows, "algorithmic_bytes_per_row": bpr if not mixed else sum(b for _, _, _, b, _ in stream),
                        "groups": groups,
