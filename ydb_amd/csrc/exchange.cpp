@@ -199,14 +199,7 @@ Status Executor::PackToHost(const Batch& in, std::vector<HostColumnView>& views,
         if (IsStringLike(c.Field.Type) && !c.Chars) return Status::OK();
     }
     (void)hipSetDevice(Device);
-    if (!HostStaging) {
-        void* pinned = nullptr;
-        if (hipHostMalloc(&pinned, kHostStagingBytes, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();  // (the copies buffer by buffer still work)
-            return Status::OK();
-        }
-        HostStaging = static_cast<uint8_t*>(pinned);
-    }
+    if (!EnsureHostStaging()) return Status::OK();  // (the copies buffer by buffer still work)
     std::vector<int32_t> bounds;
     SSA_RETURN_NOT_OK(StringBounds(in, bounds));
     std::vector<uint8_t> header;

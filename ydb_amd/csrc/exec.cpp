@@ -157,6 +157,35 @@ int Batch::FindColumn(const std::string& name) const {
     return count == 1 ? found : -1;
 }
 
+namespace {
+struct PhaseMark {
+    const char* name;
+    std::chrono::steady_clock::time_point at;
+};
+thread_local std::vector<PhaseMark> tPhaseMarks;
+}  // namespace
+
+bool HostPhases::On() {
+    static const bool on = std::getenv("SSA_HOST_PHASES") != nullptr;
+    return on;
+}
+
+void HostPhases::Mark(const char* name) {
+    if (On()) tPhaseMarks.push_back(PhaseMark{name, std::chrono::steady_clock::now()});
+}
+
+void HostPhases::Report(const char* what) {
+    if (!On() || tPhaseMarks.empty()) return;
+    std::string line = what;
+    for (size_t i = 1; i < tPhaseMarks.size(); ++i) {
+        char buf[96];
+        std::snprintf(buf, sizeof(buf), " %s %.1f", tPhaseMarks[i].name, std::chrono::duration<double, std::micro>(tPhaseMarks[i].at - tPhaseMarks[i - 1].at).count());
+        line += buf;
+    }
+    std::fprintf(stderr, "%s (us)\n", line.c_str());
+    tPhaseMarks.clear();
+}
+
 // ---------------------------------------------------------------------------------------------
 // executor basics
 // ---------------------------------------------------------------------------------------------
@@ -193,6 +222,17 @@ Executor::~Executor() {
     if (StreamHandle) (void)hipStreamDestroy(StreamHandle);
     if (HostWords) (void)hipHostFree(HostWords);
     if (HostStaging) (void)hipHostFree(HostStaging);
+}
+
+bool Executor::EnsureHostStaging() {
+    if (HostStaging) return true;
+    void* pinned = nullptr;
+    if (hipHostMalloc(&pinned, kHostStagingBytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    HostStaging = static_cast<uint8_t*>(pinned);
+    return true;
 }
 
 Status Executor::Sync() {
@@ -233,8 +273,6 @@ void Executor::ProfileCollect() {
 
 Status Executor::CheckScanStatus(bool* tableFull, bool* notUniform) {
     uint32_t st = 0;
-    if (tableFull) *tableFull = false;
-    if (notUniform) *notUniform = false;
     if (HostWords) {
         SSA_HIP(hipMemcpyAsync(HostWords, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
         SSA_HIP(hipStreamSynchronize(StreamHandle));
@@ -243,6 +281,13 @@ Status Executor::CheckScanStatus(bool* tableFull, bool* notUniform) {
         SSA_HIP(hipMemcpyAsync(&st, StatusWord->Ptr, sizeof(st), hipMemcpyDeviceToHost, StreamHandle));
         SSA_HIP(hipStreamSynchronize(StreamHandle));
     }
+    return DecodeScanStatus(st, tableFull, notUniform);
+}
+
+// What a scan's status word (already on the host) says; a status other than zero is cleared on the device.
+Status Executor::DecodeScanStatus(uint32_t st, bool* tableFull, bool* notUniform) {
+    if (tableFull) *tableFull = false;
+    if (notUniform) *notUniform = false;
     if (st == 0) return Status::OK();
     SSA_HIP(hipMemsetAsync(StatusWord->Ptr, 0, sizeof(st), StreamHandle));
     if ((st & SCAN_NOT_UNIFORM) && notUniform) {  // the scan's results are void: the caller runs the step another way
@@ -1002,6 +1047,12 @@ hipFunction_t Executor::SpecializedKernel(const char* header, const char* entry,
     if (const char* pc = std::getenv("SSA_SPEC_BLOCKS_PER_CU")) perCU = std::max(1, std::min(8, std::atoi(pc)));  // experiments
     cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), int64_t(256) * perCU));
     cfg.max_grid = 256 * perCU;
+    // A keyed scan of a shard-sized batch: a workgroup's set-up and the merge of its table into the step's are paid per
+    // workgroup, so every workgroup takes two tiles at least (a million rows of TPC-H Q1: 63 us an apply with 768
+    // workgroups of one or two tiles, 60 us with 512 of two).
+    if (std::strncmp(entry, "ssa_spec_keyed", 14) == 0 && ntiles > 256 && ntiles < 2 * int64_t(cfg.max_grid)) {
+        cfg.grid = int(std::max<int64_t>(256, std::min<int64_t>(cfg.grid, (ntiles + 1) / 2)));
+    }
     if (const char* g = std::getenv("SSA_SPEC_GRID")) cfg.grid = int(std::min<int64_t>(std::max<int64_t>(ntiles, 1), std::atoi(g)));  // experiments
     return k.Function;
 }
@@ -1241,12 +1292,15 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
             spec = SpecializedKernel("nokey_scan.h", "ssa_spec_nokey", defines, args, &sink, sizeof(sink), in.Rows, cfg);
         }
     }
-    BufferPtr partial = Buffer::Alloc(size_t(cfg.grid) * kMaxAggs * 8);
-    BufferPtr seen = Buffer::Alloc(size_t(cfg.grid) * 4);
-    BufferPtr outVals = Buffer::Alloc(kMaxAggs * 8 + kMaxAggs);
-    if (!partial || !seen || !outVals) return Status::Hip("out of device memory");
+    HostPhases::Mark("args+kernel");
+    // partials, seen bits and the result row in one block: [grid][kMaxAggs] words, [grid] words, 4 * kMaxOuts + 1 words
+    if (plan.Outs.size() > size_t(kMaxOuts)) return Status::Unsupported("more output columns than a key-less aggregation writes");
+    const size_t partialBytes = size_t(cfg.grid) * kMaxAggs * 8, seenBytes = (size_t(cfg.grid) * 4 + 15) & ~size_t(15);
+    BufferPtr partial = Buffer::Alloc(partialBytes + seenBytes);
+    BufferPtr result = Buffer::Alloc((4 * kMaxOuts + 1) * 8);
+    if (!partial || !result) return Status::Hip("out of device memory");
     sink.partial = static_cast<uint64_t*>(partial->Ptr);
-    sink.partial_seen = static_cast<uint32_t*>(seen->Ptr);
+    sink.partial_seen = reinterpret_cast<uint32_t*>(static_cast<char*>(partial->Ptr) + partialBytes);
     ProfileBegin();
     if (spec) {
         SSA_HIP(LaunchSpecialized(spec, args, &sink, sizeof(sink), cfg));
@@ -1255,66 +1309,73 @@ Status Executor::RunNoKey(const StepPlan& plan, const Batch& in, BatchPtr& out) 
         SSA_HIP(LaunchScanNoKey(args, sink, cfg));
     }
     ProfileEnd("ScanNoKeyKernel", algoBytes);
-    uint64_t* dv = static_cast<uint64_t*>(outVals->Ptr);
-    uint8_t* dvalid = reinterpret_cast<uint8_t*>(dv + kMaxAggs);
-    SSA_HIP(LaunchNoKeyFinalize(sink, cfg.grid, dv, dvalid, StreamHandle));
-    uint64_t hv[kMaxAggs + 2] = {0};
-    static_assert(16 * 4 + kMaxAggs * 9 <= kHostWords * 4, "the key-less results fit the pinned words behind the status and count");
-    void* hvAt = HostWords ? static_cast<void*>(HostWords + 16) : static_cast<void*>(hv);  // (pinned: no staging copy)
-    SSA_HIP(hipMemcpyAsync(hvAt, outVals->Ptr, kMaxAggs * 8 + kMaxAggs, hipMemcpyDeviceToHost, StreamHandle));
-    SSA_RETURN_NOT_OK(CheckScanStatus());
-    if (HostWords) std::memcpy(hv, hvAt, kMaxAggs * 8 + kMaxAggs);
-    const uint8_t* hvalid = reinterpret_cast<const uint8_t*>(hv + kMaxAggs);
 
-    // One output row; columns follow plan.Outs (aggregates in GroupBy order unless a projection reorders them).
-    out = std::make_shared<Batch>();
-    out->Rows = 1;
+    HostPhases::Mark("scan-launch");
+    // One output row; columns follow plan.Outs (aggregates in GroupBy order unless a projection reorders them).  The
+    // finalize launch writes the values where the output columns hold them; the host learns the scan's status and which
+    // results are null from two words.
+    NoKeyOutSpec outs[kMaxOuts];
+    int nouts = 0;
     for (const OutColumn& oc : plan.Outs) {
         const AggPlan& ap = plan.Aggs[size_t(oc.Index)];
-        uint64_t v = hv[oc.Index];
-        bool valid = hvalid[oc.Index] != 0;
+        NoKeyOutSpec os{};
+        os.agg = oc.Index;
+        os.mode = NOKEY_OUT_PLAIN;
+        if (ap.DecMid >= 0) {
+            os.mode = NOKEY_OUT_DECIMAL;
+            os.mid = ap.DecMid;
+            os.hi = ap.DecHi;
+        } else if (ap.SomeInputColumn >= 0) {  // the state is the smallest row index with a non-null argument
+            const Column& src = in.Cols[size_t(ap.SomeInputColumn)];
+            os.mode = NOKEY_OUT_ROW;
+            os.src = src.ValuesPtr();
+            os.width = TypeWidth(src.Field.Type);
+            if (os.width < 1 || os.width > 8) return Status::Unsupported("some() over values wider than 8 bytes");
+        } else if (oc.Type == T_F32) {
+            os.mode = NOKEY_OUT_F32;
+        }
+        outs[nouts++] = os;
+    }
+    uint64_t* dres = static_cast<uint64_t*>(result->Ptr);
+    uint32_t words[2] = {0, 0};
+    SSA_HIP(LaunchNoKeyFinalize(sink, cfg.grid, outs, nouts, dres, static_cast<const uint32_t*>(StatusWord->Ptr),
+                                reinterpret_cast<uint32_t*>(HostWords), StreamHandle));
+    HostPhases::Mark("finalize-launch");
+    if (HostWords) {
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        words[0] = uint32_t(HostWords[0]);
+        words[1] = uint32_t(HostWords[1]);
+    } else {
+        SSA_HIP(hipMemcpyAsync(words, dres + 4 * kMaxOuts, 8, hipMemcpyDeviceToHost, StreamHandle));
+        SSA_HIP(hipStreamSynchronize(StreamHandle));
+    }
+    HostPhases::Mark("sync");
+    SSA_RETURN_NOT_OK(DecodeScanStatus(words[0], nullptr, nullptr));
+
+    out = std::make_shared<Batch>();
+    out->Rows = 1;
+    int o = 0;
+    for (const OutColumn& oc : plan.Outs) {
+        const AggPlan& ap = plan.Aggs[size_t(oc.Index)];
         Column col;
         col.Field.Name = oc.Name;
         col.Field.Type = oc.Type;
-        col.Length = 1;
-        uint64_t stored = v;
-        uint64_t storedHi = 0;
         if (ap.DecMid >= 0) {
-            // 128-bit sum from the sums of its three parts
-            const unsigned __int128 total = (unsigned __int128)v + ((unsigned __int128)hv[ap.DecMid] << 32) +
-                                            ((unsigned __int128)hv[ap.DecHi] << 64);
-            stored = uint64_t(total);
-            storedHi = uint64_t(total >> 64);
             col.Field.Precision = ap.Precision;
             col.Field.Scale = ap.Scale;
-        } else if (ap.SomeInputColumn >= 0) {
-            // `v` is the smallest row index with a non-null argument: fetch that value.
-            stored = 0;
-            if (valid) {
-                const Column& src = in.Cols[size_t(ap.SomeInputColumn)];
-                const int w = TypeWidth(src.Field.Type);
-                SSA_HIP(hipMemcpy(&stored, static_cast<const char*>(src.ValuesPtr()) + v * w, size_t(w), hipMemcpyDeviceToHost));
-            }
-        } else if (oc.Type == T_F32) {
-            float f = float(BitsToF64(v));
-            uint32_t b;
-            std::memcpy(&b, &f, 4);
-            stored = b;
         }
-        if (!valid) stored = storedHi = 0;
-        col.Values = Buffer::Alloc(32);
-        if (!col.Values) return Status::Hip("out of device memory");
-        const uint64_t words[2] = {stored, storedHi};
-        SSA_HIP(hipMemcpy(col.Values->Ptr, words, 16, hipMemcpyHostToDevice));
-        if (!valid) {
-            col.Validity = Buffer::Alloc(32);
-            if (!col.Validity) return Status::Hip("out of device memory");
-            uint64_t zero = 0;
-            SSA_HIP(hipMemcpy(col.Validity->Ptr, &zero, 8, hipMemcpyHostToDevice));
+        col.Length = 1;
+        col.Values = result;
+        if (oc.Type == T_BOOL) col.ValBitOff = o * 256;
+        else col.ElemOffset = int64_t(o) * 32 / TypeWidth(oc.Type);
+        if (!((words[1] >> o) & 1u)) {
+            col.Validity = result;
+            col.ValidBitOff = (4 * o + 2) * 64;
             col.NullCount = 1;
             col.Field.Nullable = true;
         }
         out->Cols.push_back(std::move(col));
+        ++o;
     }
     return Status::OK();
 }
@@ -1510,6 +1571,71 @@ Status Executor::RunKeyed(const TProgramStep& step, const StepPlan& plan, const 
     return RunKeyedScan(step, plan, in, out, none, &notUniform);
 }
 
+// The offsets of n strings of `len` bytes each (0, len, 2 len ..): views of one ramp per length, made once and never
+// written again -- results of few groups get their offsets without a launch.
+Status Executor::OffsetRamp(int len, int64_t n, BufferPtr& out) {
+    constexpr int64_t kRampRows = 65536;
+    static_assert(kSmallEmitCounts + kSmallEmitTables <= kHostWords, "the counts of the small tables fit the pinned words");
+    if (n > kRampRows) {
+        out = Buffer::Alloc(size_t(n + 1) * 4 + 16);
+        if (!out) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchIotaI32(static_cast<int32_t*>(out->Ptr), n + 1, int32_t(len), StreamHandle));
+        return Status::OK();
+    }
+    BufferPtr& ramp = OffsetRamps[len];
+    if (!ramp) {
+        ramp = Buffer::Alloc(size_t(kRampRows + 1) * 4 + 16);
+        if (!ramp) return Status::Hip("out of device memory");
+        SSA_HIP(LaunchIotaI32(static_cast<int32_t*>(ramp->Ptr), kRampRows + 1, int32_t(len), StreamHandle));
+    }
+    out = ramp;
+    return Status::OK();
+}
+
+// The plan of `step` with string keys `renames` (key index, name) read from fixed-width columns of `shadow` instead;
+// kept per step, schema and key widths (planning is a twentieth of an apply of a shard-sized batch).
+Status Executor::FixedKeysPlan(const TProgramStep& step, const Batch& shadow, const std::vector<std::pair<size_t, std::string>>& renames,
+                               const std::vector<uint32_t>& lens, std::shared_ptr<const StepPlan>& kept) {
+    std::string signature;
+    const void* address = &step;
+    signature.append(reinterpret_cast<const char*>(&address), sizeof(address));
+    signature.push_back('F');
+    for (uint32_t len : lens) signature.push_back(char('0' + len));
+    bool stable = true;
+    for (const Column& c : shadow.Cols) {
+        if (c.Field.IsScalar) stable = false;
+        signature.append(c.Field.Name);
+        signature.push_back('\0');
+        const int32_t words[4] = {c.Field.Type, c.Field.Nullable ? 1 : 0, c.Field.Precision, c.Field.Scale};
+        signature.append(reinterpret_cast<const char*>(words), sizeof(words));
+    }
+    // (the steps of a program live as long as its executor; a rewritten copy does not)
+    stable = stable && StableStep;
+    if (stable) {
+        auto it = PlanCache.find(signature);
+        if (it != PlanCache.end()) {
+            kept = it->second;
+            return Status::OK();
+        }
+    }
+    TProgramStep fixedStep = step;
+    for (const auto& r : renames) {
+        const std::string original = step.GroupByKeys[r.first].ColumnName;
+        fixedStep.GroupByKeys[r.first].ColumnName = r.second;
+        for (auto& p : fixedStep.Projection) {
+            if (p.ColumnName == original) p.ColumnName = r.second;
+        }
+    }
+    auto fresh = std::make_shared<StepPlan>();
+    SSA_RETURN_NOT_OK(CompileStep(fixedStep, shadow.Schema(), CM_FULL, *fresh, /*serializedKeys=*/true));
+    kept = fresh;
+    if (stable) {
+        if (PlanCache.size() >= 64) PlanCache.clear();
+        PlanCache[signature] = kept;
+    }
+    return Status::OK();
+}
+
 Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out, bool& done) {
     done = false;
     struct Rewrite {
@@ -1548,8 +1674,10 @@ Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan,
         words.n = int32_t(probe.size());
         words.out = HostWords;
         SSA_HIP(LaunchProbeI32(words, StreamHandle));
+        HostPhases::Mark("probe-launch");
         SSA_HIP(hipStreamSynchronize(StreamHandle));
         for (size_t i = 0; i < probe.size(); ++i) probe[i] = HostWords[i];
+        HostPhases::Mark("probe-sync");
     } else {
         for (size_t i = 0; i < rewrites.size(); ++i) {
             SSA_HIP(hipMemcpyAsync(&probe[3 * i], words.addr[3 * i], 8, hipMemcpyDeviceToHost, StreamHandle));
@@ -1570,8 +1698,9 @@ Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan,
 
     // the batch with the chars buffers as extra fixed-width columns, the step with its keys renamed to them
     Batch shadow = in;
-    TProgramStep fixedStep = step;
     std::vector<OffsetCheck> checks;
+    std::vector<std::pair<size_t, std::string>> renames;
+    std::vector<uint32_t> lens;
     for (const Rewrite& r : rewrites) {
         const Column& src = in.Cols[size_t(r.Column)];
         Column col;
@@ -1580,16 +1709,14 @@ Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan,
         col.Length = in.Rows;
         col.Values = Buffer::Wrap(static_cast<char*>(src.Chars->Ptr) + r.First, size_t(in.Rows) * r.Len);
         shadow.Cols.push_back(col);
-        const std::string original = step.GroupByKeys[r.Key].ColumnName;
-        fixedStep.GroupByKeys[r.Key].ColumnName = r.Shadow;
-        for (auto& p : fixedStep.Projection) {
-            if (p.ColumnName == original) p.ColumnName = r.Shadow;
-        }
+        renames.emplace_back(r.Key, r.Shadow);
+        lens.push_back(r.Len);
         checks.push_back(OffsetCheck{static_cast<const int32_t*>(src.ValuesPtr()), r.First, r.Len});
     }
-    StepPlan fixedPlan;
-    if (!CompileStep(fixedStep, shadow.Schema(), CM_FULL, fixedPlan, /*serializedKeys=*/true).ok()) return Status::OK();
-    if (fixedPlan.Kind != StepPlan::AGG_KEYED) return Status::OK();
+    std::shared_ptr<const StepPlan> fixedKept;
+    if (!FixedKeysPlan(step, shadow, renames, lens, fixedKept).ok() || fixedKept->Kind != StepPlan::AGG_KEYED) return Status::OK();
+    const StepPlan& fixedPlan = *fixedKept;
+    HostPhases::Mark("fixed-plan");
     BatchPtr res;
     bool notUniform = false;
     SSA_RETURN_NOT_OK(RunKeyedScan(step, fixedPlan, shadow, res, checks, &notUniform));
@@ -1604,9 +1731,7 @@ Status Executor::RunKeyedUniform(const TProgramStep& step, const StepPlan& plan,
             str.Field = src.Field;
             str.Field.Nullable = false;
             str.Length = n;
-            str.Values = Buffer::Alloc(size_t(n + 1) * 4 + 16);
-            if (!str.Values) return Status::Hip("out of device memory");
-            SSA_HIP(LaunchIotaI32(static_cast<int32_t*>(str.Values->Ptr), n + 1, int32_t(r.Len), StreamHandle));
+            SSA_RETURN_NOT_OK(OffsetRamp(int(r.Len), n, str.Values));
             str.Chars = col.Values;
             if (!str.Chars) {
                 str.Chars = Buffer::Alloc(16);
@@ -1968,6 +2093,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         specRows = kRowsPerThread;
     }
 
+    HostPhases::Mark("describe");
     if (std::getenv("SSA_DEBUG_PLAN")) {
         std::fprintf(stderr, "keyed: naggs %d L %d R %d lds %u grid %d hashed %d two %d hot", naggs, L, R, cfg.lds_bytes, cfg.grid, int(hashed), int(twoWords));
         for (int k = 0; k < kHotAggs; ++k) std::fprintf(stderr, " %d@%d", sink.hot_kind[k], sink.hot_off[k]);
@@ -2167,6 +2293,14 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
         return Status::OK();
     };
+    // What the launch that counts and emits small tables does not do: gathers of input rows (string or wide keys, some()),
+    // decimal sums, null results (their validity is packed and counted by launches of its own).
+    bool smallEmitCan = HostWords != nullptr && !hashed && !std::getenv("SSA_NO_SMALL_EMIT");
+    for (const AggPlan& ap : plan.Aggs) {
+        if (ap.DecMid >= 0 || ap.SomeInputColumn >= 0 || (ap.Spec.kind != AGG_COUNT && ap.Spec.check_valid)) smallEmitCan = false;
+    }
+    for (const KeyPlan& kp : plan.Keys) smallEmitCan = smallEmitCan && !kp.Spec.nullable;
+    bool smallEmitted = false, smallNow = false;
     for (;;) {
         bool timedRun = timedWanted;
         bool deferNow = false;
@@ -2211,6 +2345,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 ScanRowsPerThread = kRowsPerThread;
             }
         }
+        HostPhases::Mark("kernel-lookup");
         // The table in HBM.  A scan that leaves records, to be aggregated region by region and emitted from LDS (emitNow),
         // touches it only when its workgroups end and merge their own tables into it: a small table then, cut into the
         // same regions as the records (`smallSlots` slots each).
@@ -2224,12 +2359,28 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             tableCap = regionCount * uint64_t(smallSlots);
         }
         totalCap = tableCap * nslices;  // every slice has a table of its own, one after the other
-        tLo = Buffer::Alloc(totalCap * 8);
-        tHi = Buffer::Alloc(twoWords ? totalCap * 8 : 64);
-        tAcc = Buffer::Alloc(size_t(naggs) * totalCap * 8);
-        tSeen = Buffer::Alloc(totalCap * 4);
-        tRep = Buffer::Alloc(hashed ? totalCap * 8 : 64);
-        if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
+        // Small tables that the launch behind the scan counts, emits and sets back to free (SmallTablesEmitKernel) stay
+        // with the step: its next scan finds them as a fresh table would be, without a launch to make them so.
+        const bool timedThisRun = timedWanted && (totalRows <= 0 || spec != nullptr);
+        smallNow = smallEmitCan && !timedThisRun && !deferNow && !deferTimed && tableCap <= uint64_t(kSmallTableSlots) && nslices <= size_t(kSmallEmitTables);
+        bool tableReady = false;
+        if (smallNow && hint.Small.Lo && hint.Small.TotalCap == totalCap && hint.Small.Naggs == naggs && hint.Small.TwoWords == twoWords) {
+            tLo = hint.Small.Lo;
+            tHi = hint.Small.Hi;
+            tAcc = hint.Small.Acc;
+            tSeen = hint.Small.Seen;
+            tRep = hint.Small.Rep;
+            tableReady = hint.Small.Clean;
+        } else {
+            tLo = Buffer::Alloc(totalCap * 8);
+            tHi = Buffer::Alloc(twoWords ? totalCap * 8 : 64);
+            tAcc = Buffer::Alloc(size_t(naggs) * totalCap * 8);
+            tSeen = Buffer::Alloc(totalCap * 4);
+            tRep = Buffer::Alloc(hashed ? totalCap * 8 : 64);
+            if (!tLo || !tHi || !tAcc || !tSeen || !tRep) return Status::Hip("out of device memory");
+            if (smallNow) hint.Small = KeyedHint::SmallTable{tLo, tHi, tAcc, tSeen, tRep, totalCap, naggs, twoWords, false};
+        }
+        if (smallNow) hint.Small.Clean = false;  // (until the launch that empties it again has been seen to end well)
         for (KeyedSink* k : {&sink, &ssink}) {
             k->table_mask = tableCap - 1;
             k->region_mask = tableCap - 1;
@@ -2241,11 +2392,12 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             k->t_seen = static_cast<uint32_t*>(tSeen->Ptr);
             k->t_rep_row = static_cast<uint64_t*>(tRep->Ptr);
         }
-        {
+        if (!tableReady) {
             KeyedSink all = sink;
             all.table_mask = totalCap - 1;  // (the capacity, not a mask, when there are several tables)
             SSA_HIP(LaunchKeyedTableInit(all, twoWords != 0, hashed, StreamHandle));
         }
+        HostPhases::Mark("table");
         if (totalRows > 0) {
             ssink.defer = deferNow ? 1 : 0;
             ssink.region_mask = emitNow ? uint64_t(smallSlots) - 1 : (deferNow ? std::min<uint64_t>(cap, uint64_t(regionSlots)) - 1 : cap - 1);
@@ -2270,6 +2422,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 ScanArgs& la = spec ? sargs : args;
                 LaunchCfg& lc = spec ? specCfg : cfg;
                 SSA_RETURN_NOT_OK(DescribeSlices(plan, *many, la, int64_t(kBlock) * (spec ? specRows : kRowsPerThread), cap, lc, sliceDescs, blockSlices));
+                HostPhases::Mark("slices");
             }
             ProfileBegin();
             if (deferTimed) {
@@ -2287,6 +2440,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             }
             ProfileEnd("ScanKeyedKernel", algoBytes);
         }
+        HostPhases::Mark("scan-launch");
         if (std::getenv("SSA_PHASE_TIMING")) {  // diagnostics build only (-DSSA_PHASE_TIMING): cycles per phase, summed over waves
             unsigned long long t[8];
             SSA_HIP(hipStreamSynchronize(StreamHandle));
@@ -2295,15 +2449,44 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             std::fprintf(stderr, "phases: stage %llu vm %llu keys %llu (exact packing %llu) upsert %llu hot %llu table %llu loop %llu\n", t[0], t[1],
                          t[2] + t[6], t[6], t[3], t[4], t[5], t[7]);
         }
-        // A small table is counted right behind the scan: status and group count then come back with one synchronisation
-        // instead of two (an apply of a shard-sized batch is made of little else).
-        counted = false;
-        if (!timedRun && !deferNow && !deferTimed && totalCap <= (uint64_t(1) << 16)) {
-            SSA_RETURN_NOT_OK(countGroups());
-            counted = true;
-        }
+        // Small tables are counted and emitted right behind the scan, every table to rows of its own of output columns as
+        // long as the tables: the scan's status and the group counts then come back with the one synchronisation that
+        // ends the step (an apply of a shard-sized batch is made of little else than launches and waits).  When the status
+        // is not zero the emitted rows are dropped.
         bool tableFull = false;
-        SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull, notUniform));
+        counted = false;
+        smallEmitted = false;
+        if (smallNow) {
+            SSA_RETURN_NOT_OK(prepareOutputs(int64_t(totalCap)));
+            SmallEmitArgs se{};
+            fa.capacity = totalCap;
+            fa.t_key_lo = sink.t_key_lo;
+            fa.t_key_hi = sink.t_key_hi;
+            fa.t_acc = sink.t_acc;
+            fa.t_seen = sink.t_seen;
+            fa.t_rep_row = sink.t_rep_row;
+            se.f = fa;
+            se.slice_cap = uint32_t(tableCap);
+            se.reset = 1;
+            se.nacc = naggs;
+            for (int k = 0; k < naggs; ++k) se.ident[k] = KeyedTableIdentity(phys[size_t(k)].kind);
+            se.status = static_cast<const uint32_t*>(StatusWord->Ptr);
+            se.host = reinterpret_cast<uint32_t*>(HostWords);
+            SSA_HIP(LaunchSmallTablesEmit(se, int(nslices), StreamHandle));
+            HostPhases::Mark("emit-launch");
+            SSA_HIP(hipStreamSynchronize(StreamHandle));
+            HostPhases::Mark("sync");
+            SSA_RETURN_NOT_OK(DecodeScanStatus(uint32_t(HostWords[0]), &tableFull, notUniform));
+            smallEmitted = !tableFull && !*notUniform;
+            hint.Small.Clean = HostWords[0] == 0;
+        } else {
+            // A table of up to 64 K slots is counted right behind the scan: status and group count come back together.
+            if (!timedRun && !deferNow && !deferTimed && totalCap <= (uint64_t(1) << 16)) {
+                SSA_RETURN_NOT_OK(countGroups());
+                counted = true;
+            }
+            SSA_RETURN_NOT_OK(CheckScanStatus(&tableFull, notUniform));
+        }
         if (*notUniform) return Status::OK();
         if (timedRun && !tableFull) {  // (the stream has been synchronised by the status check)
             float ms = 0;
@@ -2371,18 +2554,37 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     }
 
     cap = totalCap;  // (from here on the tables of all slices are one table: its slots in order are the slices in order)
-    if (!emitted) {
-        if (!counted) {
-            SSA_RETURN_NOT_OK(countGroups());
-            SSA_HIP(hipStreamSynchronize(StreamHandle));
+    int64_t maxGroups = 0;
+    if (smallEmitted) {
+        // table i's groups are rows [i * slots of a table, + its count) of the output
+        emitted = true;
+        const uint32_t* counts = reinterpret_cast<const uint32_t*>(HostWords) + kSmallEmitCounts;
+        for (size_t i = 0; i < nslices; ++i) maxGroups = std::max<int64_t>(maxGroups, counts[i]);
+        ngroups = many ? int64_t(totalCap) : int64_t(counts[0]);
+        if (many) {
+            many->GroupStart.assign(nslices + 1, 0);
+            many->GroupCount.assign(nslices, 0);
+            for (size_t i = 0; i < nslices; ++i) {
+                many->GroupStart[i] = int64_t(i) * int64_t(totalCap / nslices);
+                many->GroupCount[i] = counts[i];
+            }
+            many->GroupStart[nslices] = int64_t(totalCap);
         }
-        ngroups = *ngroupsAt;
-    }
-    int64_t maxGroups = ngroups;
-    if (many) {
-        many->GroupStart[nslices] = ngroups;
-        maxGroups = 0;
-        for (size_t i = 0; i < nslices; ++i) maxGroups = std::max(maxGroups, many->GroupStart[i + 1] - many->GroupStart[i]);
+    } else {
+        if (!emitted) {
+            if (!counted) {
+                SSA_RETURN_NOT_OK(countGroups());
+                SSA_HIP(hipStreamSynchronize(StreamHandle));
+            }
+            ngroups = *ngroupsAt;
+        }
+        maxGroups = ngroups;
+        if (many) {
+            many->GroupStart[nslices] = ngroups;
+            many->GroupCount.clear();
+            maxGroups = 0;
+            for (size_t i = 0; i < nslices; ++i) maxGroups = std::max(maxGroups, many->GroupStart[i + 1] - many->GroupStart[i]);
+        }
     }
 
     // next call on this step: size both table levels for what was seen
@@ -2436,6 +2638,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         }
     }
 
+    HostPhases::Mark("after-loop");
     out = std::make_shared<Batch>();
     out->Rows = ngroups;
     for (const OutColumn& oc : plan.Outs) {
@@ -2503,17 +2706,18 @@ Status Executor::ApplyStep(const TProgramStep& step, const BatchPtr& in, BatchPt
     return ApplyStepPlain(step, in, out, /*stable=*/true);
 }
 
-Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable) {
-    std::shared_ptr<const StepPlan> kept;
+// The plan of `step` for the schema of `in`; kept (PlanCache) when `stable` says the step outlives the executor's calls.
+Status Executor::PlanFor(const TProgramStep& step, const Batch& in, bool stable, std::shared_ptr<const StepPlan>& kept) {
+    kept = nullptr;
     std::string signature;
     if (stable) {
         // everything of the input the planner looks at: names, types, which columns carry nulls, decimal parameters
         // (a scalar column's value takes part in constant folding: such batches are planned every time)
-        signature.reserve(32 + 24 * in->Cols.size());
+        signature.reserve(32 + 24 * in.Cols.size());
         const void* address = &step;
         signature.append(reinterpret_cast<const char*>(&address), sizeof(address));
         signature.push_back(ForceSerializedKeys ? 'S' : 'N');
-        for (const Column& c : in->Cols) {
+        for (const Column& c : in.Cols) {
             if (c.Field.IsScalar) {
                 stable = false;
                 break;
@@ -2530,13 +2734,20 @@ Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, Ba
     }
     if (!kept) {
         auto fresh = std::make_shared<StepPlan>();
-        SSA_RETURN_NOT_OK(CompileStep(step, in->Schema(), CM_FULL, *fresh, ForceSerializedKeys));
+        SSA_RETURN_NOT_OK(CompileStep(step, in.Schema(), CM_FULL, *fresh, ForceSerializedKeys));
         kept = fresh;
         if (stable) {
             if (PlanCache.size() >= 64) PlanCache.clear();  // (a program sees a handful of schemas)
             PlanCache[signature] = kept;
         }
     }
+    return Status::OK();
+}
+
+Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable) {
+    std::shared_ptr<const StepPlan> kept;
+    SSA_RETURN_NOT_OK(PlanFor(step, *in, stable, kept));
+    StableStep = stable;
     const StepPlan& plan = *kept;
     switch (plan.Kind) {
         case StepPlan::PASS_THROUGH:
@@ -2553,6 +2764,7 @@ Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, Ba
 }
 
 Status Executor::ApplyProgram(const TProgram& program, const BatchPtr& in, BatchPtr& out) {
+    HostPhases::Mark("begin");
     (void)hipSetDevice(Device);
     BatchPtr cur = in;
     for (auto& step : program.Steps) {
@@ -2561,6 +2773,8 @@ Status Executor::ApplyProgram(const TProgram& program, const BatchPtr& in, Batch
         cur = next;
     }
     out = cur;
+    HostPhases::Mark("end");
+    HostPhases::Report("apply:");
     return Status::OK();
 }
 

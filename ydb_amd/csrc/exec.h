@@ -113,6 +113,14 @@ struct KernelProfile {
     std::string LastKernel;
 };
 
+// Diagnostics (SSA_HOST_PHASES=1): where the host's time of an apply goes.  Mark() notes the time at a named point of the
+// calling thread's apply, Report() prints the intervals between the marks to stderr and forgets them.
+struct HostPhases {
+    static bool On();
+    static void Mark(const char* name);
+    static void Report(const char* what);
+};
+
 // Column descriptions of a struct ArrowSchema (no data): used to explain / type-check a program on the host.
 Status SchemaFields(const ArrowSchema* schema, std::vector<FieldDesc>& out);
 
@@ -141,7 +149,8 @@ Status UnpackBatch(const uint8_t* header, size_t headerBytes, void* data, size_t
 struct ManySlices {
     std::vector<const Batch*> In;                  // every slice; In[0] is the batch the plan was made for
     std::vector<std::vector<OffsetCheck>> Checks;  // per slice, or empty
-    std::vector<int64_t> GroupStart;               // out: the groups of slice i are rows [GroupStart[i], GroupStart[i + 1]) of the result
+    std::vector<int64_t> GroupStart;               // out: the groups of slice i are rows [GroupStart[i], GroupStart[i + 1]) of the result ...
+    std::vector<int64_t> GroupCount;               // ... or, when this is not empty, the first GroupCount[i] of them
     std::vector<SliceDesc> HostDescs;              // what the launch reads, kept until it has been copied
     std::vector<int32_t> HostMap;
 };
@@ -164,9 +173,10 @@ public:
     // A few words of pinned host memory: where small results (a scan's status, a group count, probed offsets) land
     // without the staging copy an asynchronous copy into pageable memory takes.
     int32_t* HostWords = nullptr;
-    static constexpr int kHostWords = 64;
+    static constexpr int kHostWords = 128;
     uint8_t* HostStaging = nullptr;  // pinned, kHostStagingBytes, allocated at the first PackToHost
     static constexpr size_t kHostStagingBytes = size_t(1) << 20;
+    bool EnsureHostStaging();  // false: no pinned memory to be had
     explicit Executor(int device);
     ~Executor();
 
@@ -248,6 +258,10 @@ private:
     // its plan for this input schema may be kept (PlanCache) -- planning is a tenth of an apply of a shard-sized batch.
     Status ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable = false);
     std::map<std::string, std::shared_ptr<const StepPlan>> PlanCache;  // (step address, input schema) -> plan
+    Status PlanFor(const TProgramStep& step, const Batch& in, bool stable, std::shared_ptr<const StepPlan>& kept);
+    bool StableStep = false;  // the step being run is one of the program's own (plans made for it may be kept)
+    Status FixedKeysPlan(const TProgramStep& step, const Batch& shadow, const std::vector<std::pair<size_t, std::string>>& renames,
+                         const std::vector<uint32_t>& lens, std::shared_ptr<const StepPlan>& kept);
     // -- dictionary-encoded columns (dict.cpp) ---------------------------------------------------------------
     Status ApplyStepDict(const TProgramStep& step, const BatchPtr& in, BatchPtr& out);
     Status LowerDictStep(const TProgramStep& step, const BatchPtr& in, bool filterOnly, DictLowering& lowering);
@@ -285,6 +299,8 @@ private:
                           BufferPtr& descs, BufferPtr& map);
     Status RunSegments(const std::vector<CopySegment>& segments);
     Status StringBounds(const Batch& in, std::vector<int32_t>& bounds);
+    Status OffsetRamp(int len, int64_t n, BufferPtr& out);
+    std::map<int, BufferPtr> OffsetRamps;  // string length -> offsets of 65536 strings of that length
     Status ApplyStepMany(const TProgramStep& step, const std::vector<BatchPtr>& in, std::vector<BatchPtr>& out);
     Status RunProject(const TProgramStep& step, const StepPlan& plan, const BatchPtr& in, BatchPtr& out);
     Status RunFilterBitmap(const StepPlan& filterPlan, const Batch& in, BufferPtr& bitmap, BufferPtr& tileOffsets,
@@ -296,6 +312,7 @@ private:
                                     const void* sinkImage, size_t sinkBytes, int64_t rows, LaunchCfg& cfg);
     hipError_t LaunchSpecialized(hipFunction_t fn, const ScanArgs& args, const void* sink, size_t sinkBytes, const LaunchCfg& cfg);
     Status CheckScanStatus(bool* tableFull = nullptr, bool* notUniform = nullptr);
+    Status DecodeScanStatus(uint32_t st, bool* tableFull, bool* notUniform);
     Status CompactColumn(const Column& src, int64_t rows, const BufferPtr& bitmap, const BufferPtr& tileOffsets,
                          int64_t selected, Column& dst);
     Status MaterializeScalar(const OutColumn& oc, int64_t rows, Column& dst);
@@ -341,6 +358,16 @@ private:
         // keys).  Both ways are timed once on the step's large scans, scan to finished table.
         int DeferChoice = -1;    // -1 undecided, 0 row by row, 1 by region
         double MsDeferOn = 0, MsDeferOff = 0;
+        // The level-2 tables of the step's small scans (a few thousand slots each), kept from scan to scan: the launch that
+        // emits their groups leaves them free again.  Clean: nothing has touched them since.
+        struct SmallTable {
+            BufferPtr Lo, Hi, Acc, Seen, Rep;
+            uint64_t TotalCap = 0;
+            int Naggs = 0;
+            bool TwoWords = false;
+            bool Clean = false;
+        };
+        SmallTable Small;
     };
     std::map<const TProgramStep*, KeyedHint> KeyedHints;
 };

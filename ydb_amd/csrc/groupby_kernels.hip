@@ -507,6 +507,103 @@ __global__ __launch_bounds__(kBlock) void KeyedEmitKernel(const KeyedFinalizeArg
     }
 }
 
+// Small tables (a shard-sized batch of a few groups; the tables of the slices of one launch), counted and emitted by one
+// launch: workgroup b takes table b of `slice_cap` slots (64 .. kSmallTableSlots) and writes its groups, in slot order, to
+// rows b * slice_cap and on of the output columns -- every table has its own rows, so no workgroup waits for another's
+// count.  The number of groups of table b goes to host[kSmallEmitCounts + b], the scan's status word to host[0] (`host`:
+// pinned memory the host reads after its one wait on the stream).  With `reset` the slots that held a group are set
+// back to what KeyedTableInitKernel leaves, and the table can take the next scan as it is.
+// A table of few groups is a chain of round trips to memory and little else: every wave reads its eight words of slots at
+// once and keeps them, and up to 256 groups are emitted one aggregate per thread -- all accumulators in flight together.
+constexpr int kSmallEmitBlock = 1024;
+__global__ __launch_bounds__(kSmallEmitBlock) void SmallTablesEmitKernel(const SmallEmitArgs) {
+    const SmallEmitArgs& a = KernArgsAs<SmallEmitArgs>();
+    const KeyedFinalizeArgs& f = a.f;
+    constexpr int kWords = kSmallTableSlots / 64;
+    constexpr int kPerWave = kWords / (kSmallEmitBlock / 64);
+    static_assert(kWords == 128 && kPerWave * (kSmallEmitBlock / 64) == kWords, "the scan below takes two words a lane");
+    __shared__ uint32_t wordCount[kWords];
+    __shared__ uint32_t wordStart[kWords];
+    __shared__ uint16_t list[kSmallTableSlots];
+    __shared__ uint32_t total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cap = a.slice_cap, nwords = cap / 64;
+    const uint64_t slot0 = uint64_t(blockIdx.x) * cap;
+    uint64_t klo[kPerWave], taken[kPerWave];
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) {
+        const uint32_t w = uint32_t(wave * kPerWave + j);
+        klo[j] = w < nwords ? f.t_key_lo[slot0 + uint64_t(w) * 64 + lane] : kEmpty;
+    }
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) {
+        taken[j] = __ballot(klo[j] != kEmpty);
+        if (lane == 0) wordCount[wave * kPerWave + j] = uint32_t(__popcll(taken[j]));
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the word counts: two words a lane
+        const uint32_t c0 = wordCount[2 * lane], c1 = wordCount[2 * lane + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        wordStart[2 * lane] = incl - c0 - c1;
+        wordStart[2 * lane + 1] = incl - c1;
+        if (lane == 63) total = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) {
+        const uint32_t w = uint32_t(wave * kPerWave + j);
+        if (klo[j] != kEmpty) list[wordStart[w] + __popcll(taken[j] & ((1ull << lane) - 1ull))] = uint16_t(w * 64 + lane);
+    }
+    __syncthreads();
+    const uint32_t n = total;
+    if (n * kMaxAggs <= 4 * kSmallEmitBlock) {
+        for (uint32_t idx = threadIdx.x; idx < n * kMaxAggs; idx += kSmallEmitBlock) {
+            const uint32_t r = idx / kMaxAggs;
+            const int k = int(idx % kMaxAggs);
+            if (k >= f.naggs) continue;
+            const uint64_t i = slot0 + list[r];
+            EmitAggregate(f, k, int64_t(slot0 + r), f.t_seen[i], [&](int j) { return f.t_acc[size_t(j) * f.capacity + i]; });
+        }
+        for (uint32_t r = threadIdx.x; r < n; r += kSmallEmitBlock) {
+            const uint64_t i = slot0 + list[r];
+            if (f.group_rep_row != nullptr) f.group_rep_row[slot0 + r] = f.t_rep_row[i];
+            if (!f.hashed) {
+                const uint64_t tlo = f.t_key_lo[i], thi = f.two_words ? f.t_key_hi[i] : 0ull;
+                const uint64_t lo = tlo | (thi << 63), hi = thi >> 1;
+                int pos = 0;
+                for (int k = 0; k < f.nkeys; ++k) pos = EmitKey(f, k, pos, int64_t(slot0 + r), lo, hi);
+            }
+        }
+    } else {
+        for (uint32_t r = threadIdx.x; r < n; r += kSmallEmitBlock) {
+            const uint64_t i = slot0 + list[r];
+            const uint64_t khi = (!f.hashed && f.two_words) ? f.t_key_hi[i] : 0ull;
+            const uint64_t rep = f.group_rep_row != nullptr ? f.t_rep_row[i] : 0ull;
+            EmitGroup(f, int64_t(slot0 + r), f.t_key_lo[i], khi, f.t_seen[i], rep, [&](int j) { return f.t_acc[size_t(j) * f.capacity + i]; });
+        }
+    }
+    if (a.reset) {
+        __syncthreads();  // (an aggregate may share its accumulator with another: every read of the table is over)
+        for (uint32_t r = threadIdx.x; r < n; r += kSmallEmitBlock) {
+            const uint64_t i = slot0 + list[r];
+            const_cast<uint64_t*>(f.t_key_lo)[i] = kEmpty;
+            if (f.two_words) const_cast<uint64_t*>(f.t_key_hi)[i] = kUnpublished;
+            if (f.t_rep_row != nullptr && f.hashed) const_cast<uint64_t*>(f.t_rep_row)[i] = ~0ull;
+            const_cast<uint32_t*>(f.t_seen)[i] = 0;
+            for (int k = 0; k < a.nacc; ++k) const_cast<uint64_t*>(f.t_acc)[size_t(k) * f.capacity + i] = a.ident[k];
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.host[kSmallEmitCounts + blockIdx.x] = n;
+        if (blockIdx.x == 0) a.host[0] = *a.status;
+    }
+}
+
 // Position of a key inside the LDS table of its region.  The region itself is chosen by other bits of the same 32-bit
 // fold (DigitOf), so this takes them through another multiplier.
 __device__ __forceinline__ uint32_t RegionLdsStart(uint32_t fold, int shift) { return (fold * 0xC2B2AE35u) >> shift; }
@@ -1233,6 +1330,12 @@ hipError_t LaunchKeyedTileCount(const uint64_t* tKeyLo, uint64_t capacity, uint3
 hipError_t LaunchKeyedEmit(const KeyedFinalizeArgs& a, hipStream_t st) {
     const uint64_t ntiles = a.capacity / kTileRows;
     hipLaunchKernelGGL(KeyedEmitKernel, dim3(uint32_t(ntiles < uint64_t(kMaxGrid) ? ntiles : uint64_t(kMaxGrid))), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t LaunchSmallTablesEmit(const SmallEmitArgs& a, int tables, hipStream_t st) {
+    if (tables < 1 || a.slice_cap < 64 || a.slice_cap > uint32_t(kSmallTableSlots) || (a.slice_cap & (a.slice_cap - 1)) != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(SmallTablesEmitKernel, dim3(uint32_t(tables)), dim3(kSmallEmitBlock), 0, st, a);
     return hipGetLastError();
 }
 

@@ -131,7 +131,20 @@ hipError_t ConfigureScanKernels(int maxLdsBytes);
 
 // ---- small follow-up kernels ----------------------------------------------------------------------
 // Reduce per-workgroup partials; out_vals[k], out_valid[k] (1 = non-null).
-hipError_t LaunchNoKeyFinalize(const NoKeySink& s, int grid, uint64_t* out_vals, uint8_t* out_valid, hipStream_t st);
+// One output column of a key-less aggregation: which aggregate it shows and how its 64-bit state becomes the value.
+enum NoKeyOutMode : int32_t { NOKEY_OUT_PLAIN = 0, NOKEY_OUT_DECIMAL = 1, NOKEY_OUT_ROW = 2, NOKEY_OUT_F32 = 3 };
+struct NoKeyOutSpec {
+    int32_t agg;
+    int32_t mode;
+    int32_t mid, hi;   // NOKEY_OUT_DECIMAL: the aggregates that hold the sums of the middle and high parts
+    const void* src;   // NOKEY_OUT_ROW: row 0 of the column the value comes from, and the width of its values
+    int32_t width;
+    int32_t pad_;
+};
+// `result`: 4 * kMaxOuts + 1 words of device memory (per output: value, high half, validity word, padding; then, when
+// `host` is null, the status and the not-null bits); `host`: two words of pinned memory or nullptr.
+hipError_t LaunchNoKeyFinalize(const NoKeySink& s, int grid, const NoKeyOutSpec* outs, int nouts, uint64_t* result, const uint32_t* status,
+                               uint32_t* host, hipStream_t st);
 // tile_offsets[i] = sum(tile_counts[0..i)), total[0] = sum of all.
 hipError_t LaunchTileScan(const uint32_t* tile_counts, int64_t ntiles, int64_t* tile_offsets, int64_t* total, hipStream_t st);
 // Order-preserving compaction of one fixed-width column (width 1, 2, 4, 8 or 16 bytes).
@@ -182,6 +195,21 @@ struct KeyedFinalizeArgs {
     void* key_vals[kMaxKeys];         // exact keys only: decoded from the table
     uint8_t* key_valid_bytes[kMaxKeys];
 };
+// Tables of up to kSmallTableSlots slots each, counted and emitted by one launch (SmallTablesEmitKernel).
+constexpr int kSmallTableSlots = 8192;
+constexpr int kSmallEmitCounts = 32;   // host word of the first table's group count
+constexpr int kSmallEmitTables = 64;   // tables of one launch (their counts fit the executor's pinned words)
+struct SmallEmitArgs {
+    KeyedFinalizeArgs f;      // capacity: the slots of all tables (the stride of the accumulator arrays); tile_offsets unused
+    uint32_t slice_cap;       // slots of one table
+    int32_t reset;            // leave the table as KeyedTableInitKernel does
+    int32_t nacc;             // reset: the table's accumulators and their identities
+    int32_t pad_;
+    uint64_t ident[kMaxAggs];
+    const uint32_t* status;   // the scan's status word
+    uint32_t* host;           // pinned: [0] the status, [kSmallEmitCounts + b] the groups of table b
+};
+hipError_t LaunchSmallTablesEmit(const SmallEmitArgs& a, int tables, hipStream_t st);
 uint64_t KeyedTableIdentity(int aggKind);  // initial value of a level-2 accumulator
 hipError_t ConfigureKeyedKernels(int maxLdsBytes);
 // Free keys, identity accumulators, clear flags: every array of the level-2 table `sink` points at, in one launch.

@@ -36,6 +36,7 @@ std::atomic<int64_t> gManyStepsPerSlice{0};     // steps that ran slice by slice
     } while (0)
 
 Status Executor::ApplyProgramMany(const TProgram& program, const std::vector<BatchPtr>& in, std::vector<BatchPtr>& out) {
+    HostPhases::Mark("begin");
     (void)hipSetDevice(Device);
     std::vector<BatchPtr> cur = in;
     for (auto& step : program.Steps) {
@@ -70,6 +71,8 @@ Status Executor::ApplyProgramMany(const TProgram& program, const std::vector<Bat
         cur = next;
     }
     out = cur;
+    HostPhases::Mark("end");
+    HostPhases::Report("apply of slices:");
     return Status::OK();
 }
 
@@ -88,8 +91,10 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
             }
         }
     }
-    StepPlan plan;
-    SSA_RETURN_NOT_OK(CompileStep(step, schema, CM_FULL, plan, ForceSerializedKeys));
+    std::shared_ptr<const StepPlan> planKept;
+    SSA_RETURN_NOT_OK(PlanFor(step, *in[0], /*stable=*/true, planKept));
+    StableStep = true;
+    const StepPlan& plan = *planKept;
     const bool noKey = plan.Kind == StepPlan::AGG_NOKEY;
     if (noKey) {
         // as one group per slice in the keyed sink: sums, counts and integer extremes are the same there
@@ -104,9 +109,10 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
         return Status::Unsupported("slices in one launch: not an aggregation");
     }
 
+    HostPhases::Mark("plan");
     ManySlices many;
     std::vector<Batch> shadows;  // the slices with their one-length string keys as fixed-width columns
-    StepPlan fixedPlan;
+    std::shared_ptr<const StepPlan> fixedKept;
     const StepPlan* usePlan = &plan;
     struct Rewrite {
         size_t Key;
@@ -129,7 +135,10 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
         if (std::getenv("SSA_NO_UNIFORM_KEYS")) return Status::Unsupported("slices in one launch: string keys");
         // first, second and last offset of every such column of every slice, fetched together
         const size_t nprobe = n * rewrites.size() * 3;
-        std::vector<const int32_t*> addrs(nprobe);
+        // (addresses and answers in pinned memory the launch reads and writes where it lies: no copies, no allocation)
+        const bool pinnedProbe = nprobe * 12 + 64 <= kHostStagingBytes && EnsureHostStaging();
+        std::vector<const int32_t*> pageable(pinnedProbe ? 0 : nprobe);
+        const int32_t** addrs = pinnedProbe ? reinterpret_cast<const int32_t**>(HostStaging) : pageable.data();
         for (size_t i = 0; i < n; ++i) {
             if (in[i]->Rows < 1) return Status::Unsupported("slices in one launch: an empty slice with string keys");
             for (size_t r = 0; r < rewrites.size(); ++r) {
@@ -143,13 +152,24 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
                 addrs[at + 2] = offs + in[i]->Rows;
             }
         }
-        BufferPtr dAddrs = Buffer::Alloc(nprobe * 8 + 64), dProbe = Buffer::Alloc(nprobe * 4 + 64);
-        if (!dAddrs || !dProbe) return Status::Hip("out of device memory");
-        std::vector<int32_t> probe(nprobe);
-        SSA_HIP(hipMemcpyAsync(dAddrs->Ptr, addrs.data(), nprobe * 8, hipMemcpyHostToDevice, StreamHandle));
-        SSA_HIP(LaunchGatherI32At(static_cast<const int32_t* const*>(dAddrs->Ptr), int64_t(nprobe), static_cast<int32_t*>(dProbe->Ptr), StreamHandle));
-        SSA_HIP(hipMemcpyAsync(probe.data(), dProbe->Ptr, nprobe * 4, hipMemcpyDeviceToHost, StreamHandle));
-        SSA_HIP(hipStreamSynchronize(StreamHandle));
+        std::vector<int32_t> answers(pinnedProbe ? 0 : nprobe);
+        const int32_t* probe = answers.data();
+        if (pinnedProbe) {
+            int32_t* out = reinterpret_cast<int32_t*>(HostStaging + ((nprobe * 8 + 63) & ~size_t(63)));
+            SSA_HIP(LaunchGatherI32At(addrs, int64_t(nprobe), out, StreamHandle));
+            HostPhases::Mark("probe-launch");
+            SSA_HIP(hipStreamSynchronize(StreamHandle));
+            probe = out;
+        } else {
+            BufferPtr dAddrs = Buffer::Alloc(nprobe * 8 + 64), dProbe = Buffer::Alloc(nprobe * 4 + 64);
+            if (!dAddrs || !dProbe) return Status::Hip("out of device memory");
+            SSA_HIP(hipMemcpyAsync(dAddrs->Ptr, addrs, nprobe * 8, hipMemcpyHostToDevice, StreamHandle));
+            SSA_HIP(LaunchGatherI32At(static_cast<const int32_t* const*>(dAddrs->Ptr), int64_t(nprobe), static_cast<int32_t*>(dProbe->Ptr), StreamHandle));
+            SSA_HIP(hipMemcpyAsync(answers.data(), dProbe->Ptr, nprobe * 4, hipMemcpyDeviceToHost, StreamHandle));
+            HostPhases::Mark("probe-launch");
+            SSA_HIP(hipStreamSynchronize(StreamHandle));
+        }
+        HostPhases::Mark("probe-sync");
         shadows.resize(n);
         many.Checks.resize(n);
         for (size_t i = 0; i < n; ++i) {
@@ -178,23 +198,22 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
         }
         for (const Rewrite& r : rewrites) keyBits += int(8 * r.Len);
         if (keyBits > 119) return Status::Unsupported("slices in one launch: wide keys");
-        TProgramStep fixedStep = step;
+        std::vector<std::pair<size_t, std::string>> renames;
+        std::vector<uint32_t> lens;
         for (const Rewrite& r : rewrites) {
-            const std::string original = step.GroupByKeys[r.Key].ColumnName;
-            fixedStep.GroupByKeys[r.Key].ColumnName = r.Shadow;
-            for (auto& p : fixedStep.Projection) {
-                if (p.ColumnName == original) p.ColumnName = r.Shadow;
-            }
+            renames.emplace_back(r.Key, r.Shadow);
+            lens.push_back(r.Len);
         }
-        if (!CompileStep(fixedStep, shadows[0].Schema(), CM_FULL, fixedPlan, /*serializedKeys=*/true).ok() || fixedPlan.Kind != StepPlan::AGG_KEYED) {
+        if (!FixedKeysPlan(step, shadows[0], renames, lens, fixedKept).ok() || fixedKept->Kind != StepPlan::AGG_KEYED) {
             return Status::Unsupported("slices in one launch: string keys");
         }
-        usePlan = &fixedPlan;
+        usePlan = fixedKept.get();
         for (size_t i = 0; i < n; ++i) many.In.push_back(&shadows[i]);
     } else {
         for (size_t i = 0; i < n; ++i) many.In.push_back(in[i].get());
     }
 
+    HostPhases::Mark("shadows+plan");
     BatchPtr all;
     bool notUniform = false;
     static const std::vector<OffsetCheck> kNone;
@@ -211,9 +230,7 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
             str.Field = src.Field;
             str.Field.Nullable = false;
             str.Length = all->Rows;
-            str.Values = Buffer::Alloc(size_t(all->Rows + 1) * 4 + 16);
-            if (!str.Values) return Status::Hip("out of device memory");
-            SSA_HIP(LaunchIotaI32(static_cast<int32_t*>(str.Values->Ptr), all->Rows + 1, int32_t(r.Len), StreamHandle));
+            SSA_RETURN_NOT_OK(OffsetRamp(int(r.Len), all->Rows, str.Values));
             str.Chars = col.Values;
             if (!str.Chars) {
                 str.Chars = Buffer::Alloc(16);
@@ -223,10 +240,11 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
         }
     }
 
+    HostPhases::Mark("scan-returned");
     out.assign(n, nullptr);
     BatchPtr emptyRow;  // key-less aggregation over no row: nulls, zero counts
     for (size_t i = 0; i < n; ++i) {
-        const int64_t start = many.GroupStart[i], count = many.GroupStart[i + 1] - start;
+        const int64_t start = many.GroupStart[i], count = many.GroupCount.empty() ? many.GroupStart[i + 1] - start : many.GroupCount[i];
         if (noKey && count != 1) {
             if (count != 0) return Status::Invalid("internal: key-less aggregation produced more than one group");
             if (!emptyRow) {
@@ -260,6 +278,7 @@ Status Executor::ApplyStepMany(const TProgramStep& step, const std::vector<Batch
         for (const Column& col : all->Cols) b->Cols.push_back(ColumnView(col, start, count));
         out[i] = b;
     }
+    HostPhases::Mark("views");
     SSA_HIP(hipStreamSynchronize(StreamHandle));
     return Status::OK();
 }

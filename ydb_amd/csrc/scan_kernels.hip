@@ -14,21 +14,27 @@ namespace ssa {
 namespace {
 
 
-// One workgroup folds the per-workgroup partials in a fixed order (bit-reproducible for a fixed grid).
+// One workgroup folds the per-workgroup partials in a fixed order (bit-reproducible for a fixed grid), then writes the
+// result row as the output columns hold it: per output column four words of `result` (value, its high half for
+// decimals, a validity word, padding).  What the host needs to finish the batch -- the scan's status word and which
+// aggregates are null -- goes to `host` (pinned memory, when the executor has it), so that the apply ends with one wait
+// on the stream and no copy.
 struct FinalizeArgs {
     NoKeySink s;
     int grid;
-    uint64_t* outVals;
-    uint8_t* outValid;
+    int nouts;
+    NoKeyOutSpec outs[kMaxOuts];
+    uint64_t* result;
+    const uint32_t* status;
+    uint32_t* host;  // [0] status, [1] bit k: output k is not null; may be nullptr (then `result` word 4 * kMaxOuts and on)
 };
 __global__ __launch_bounds__(kBlock) void NoKeyFinalizeKernel(const FinalizeArgs) {
     const FinalizeArgs& fa = KernArgsAs<FinalizeArgs>();
     const NoKeySink& s = fa.s;
     const int grid = fa.grid;
-    uint64_t* outVals = fa.outVals;
-    uint8_t* outValid = fa.outValid;
     __shared__ uint64_t lds[kWaves];
     __shared__ uint32_t ldsSeen[kWaves];
+    __shared__ uint64_t vals[kMaxAggs];
     uint32_t seen = 0;
     for (int b = threadIdx.x; b < grid; b += kBlock) seen |= s.partial_seen[b];
 #pragma unroll
@@ -48,10 +54,39 @@ __global__ __launch_bounds__(kBlock) void NoKeyFinalizeKernel(const FinalizeArgs
         if (threadIdx.x == 0) {
             uint64_t r = lds[0];
             for (int w = 1; w < kWaves; ++w) r = AggCombine(kind, r, lds[w]);
-            outVals[k] = r;
-            outValid[k] = (kind == AGG_COUNT) ? 1 : ((seen >> k) & 1u);
+            vals[k] = r;
+            if (kind == AGG_COUNT) seen |= 1u << k;
         }
     }
+    if (threadIdx.x != 0) return;
+    uint32_t validOuts = 0;
+    for (int o = 0; o < fa.nouts; ++o) {
+        const NoKeyOutSpec& os = fa.outs[o];
+        const bool valid = (seen >> os.agg) & 1u;
+        uint64_t lo = vals[os.agg], hi = 0;
+        if (os.mode == NOKEY_OUT_DECIMAL) {  // 128-bit sum from the sums of its three parts
+            const unsigned __int128 total = (unsigned __int128)lo + ((unsigned __int128)vals[os.mid] << 32) + ((unsigned __int128)vals[os.hi] << 64);
+            lo = uint64_t(total);
+            hi = uint64_t(total >> 64);
+        } else if (os.mode == NOKEY_OUT_ROW) {  // the value is a row index: that row of the source column
+            const uint64_t row = lo;
+            lo = 0;
+            if (valid) {
+                const char* at = static_cast<const char*>(os.src) + row * uint64_t(os.width);
+                for (int b = 0; b < os.width; ++b) lo |= uint64_t(uint8_t(at[b])) << (8 * b);
+            }
+        } else if (os.mode == NOKEY_OUT_F32) {
+            lo = __float_as_uint(float(__longlong_as_double((long long)lo)));
+        }
+        if (!valid) lo = hi = 0;
+        fa.result[4 * o] = lo;
+        fa.result[4 * o + 1] = hi;
+        fa.result[4 * o + 2] = valid ? 1 : 0;
+        if (valid) validOuts |= 1u << o;
+    }
+    uint32_t* host = fa.host ? fa.host : reinterpret_cast<uint32_t*>(fa.result + 4 * kMaxOuts);
+    host[0] = *fa.status;
+    host[1] = validOuts;
 }
 
 // ---- exclusive scans ------------------------------------------------------------------------------
@@ -331,8 +366,17 @@ hipError_t ConfigureScanKernels(int maxLdsBytes) {
     return e;
 }
 
-hipError_t LaunchNoKeyFinalize(const NoKeySink& s, int grid, uint64_t* outVals, uint8_t* outValid, hipStream_t st) {
-    FinalizeArgs fa{s, grid, outVals, outValid};
+hipError_t LaunchNoKeyFinalize(const NoKeySink& s, int grid, const NoKeyOutSpec* outs, int nouts, uint64_t* result, const uint32_t* status,
+                               uint32_t* host, hipStream_t st) {
+    if (nouts < 0 || nouts > kMaxOuts) return hipErrorInvalidValue;
+    FinalizeArgs fa{};
+    fa.s = s;
+    fa.grid = grid;
+    fa.nouts = nouts;
+    for (int o = 0; o < nouts; ++o) fa.outs[o] = outs[o];
+    fa.result = result;
+    fa.status = status;
+    fa.host = host;
     hipLaunchKernelGGL(NoKeyFinalizeKernel, dim3(1), dim3(kBlock), 0, st, fa);
     return hipGetLastError();
 }
