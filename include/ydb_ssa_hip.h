@@ -77,6 +77,26 @@ int ssa_program_create(const uint8_t* program, size_t program_size, int olap_wra
                        const uint32_t* col_ids, const char* const* col_names, size_t ncols,
                        const struct ArrowArray* params, const struct ArrowSchema* params_schema,
                        int device, ssa_program_t** out, char** err);
+/*
+ * ssa_program_create with the operations of the program's YQL kernels.  A TFunction of type YQL_KERNEL names its kernel
+ * by KernelIdx, an index into the serialized MiniKQL kernel set of TProgram.Kernels (loaded by
+ * ydb/library/yql/core/arrow_kernels/registry/registry.cpp:19-88); binary kernels also carry YqlOperationId, unary ones
+ * (NYql::TKernelRequestBuilder::EUnaryOp, request.h:11-17: Not Size Minus Abs Just -- every pushed-down NOT is one,
+ * ydb/core/kqp/query_compiler/kqp_olap_compiler.cpp:655-676, 804-812) and If do not.  This library does not read the
+ * kernel set; the side that built it (TKernelRequestBuilder::AddUnaryOp / AddBinaryOp / AddIf return the index) says
+ * what each index stands for: kernel_ops[i] is SSA_KERNEL_UNARY_BASE + EUnaryOp, an EBinaryOp value (request.h:19-42),
+ * SSA_KERNEL_IF, or SSA_KERNEL_UNKNOWN for kernels it leaves to YqlOperationId (or that this library does not run:
+ * UDFs, ScalarApply, JSON -- a program that uses one of those is refused when it is applied).  A YqlOperationId in the
+ * program wins over the table.  `kernel_ops` may be NULL (nkernels 0): ssa_program_create.
+ */
+#define SSA_KERNEL_UNARY_BASE 0x100u
+#define SSA_KERNEL_IF 0x10000u
+#define SSA_KERNEL_UNKNOWN 0xFFFFFFFFu
+int ssa_program_create_with_kernels(const uint8_t* program, size_t program_size, int olap_wrapper,
+                                    const uint32_t* col_ids, const char* const* col_names, size_t ncols,
+                                    const struct ArrowArray* params, const struct ArrowSchema* params_schema,
+                                    const uint32_t* kernel_ops, size_t nkernels,
+                                    int device, ssa_program_t** out, char** err);
 void ssa_program_destroy(ssa_program_t* program);
 
 /* TProgram::DebugString (ydb/core/formats/arrow/program.h:451-459); malloc'd, free with ssa_free_string. */

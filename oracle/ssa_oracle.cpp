@@ -201,6 +201,7 @@ struct Step {
 struct Program {
     std::vector<Step> steps;
     bool directOperations = false;  // TFunction ids of 1000 + NKernels::EOperation are accepted
+    std::vector<uint32_t> kernelOps;  // per KernelIdx what the caller says the YQL kernel is (0xFFFFFFFF: nothing)
     std::map<uint32_t, std::string> resolver;       // column id -> table column name
     std::map<std::string, uint32_t> byName;
     std::vector<std::pair<uint32_t, std::string>> sources;  // in first-use order
@@ -264,20 +265,26 @@ static DatumPtr ReadConstant(Wire w) {
 
 // TProgramBuilder::MakeFunction (ydb/core/tx/program/program.cpp:84-251)
 static void ReadFunction(Program& prog, Wire w, Assign& a) {
-    uint32_t id = 0, ftype = 1;
+    uint32_t id = 0, ftype = 1, kernelIdx = 0;
     std::vector<PColumn> args;
     while (w.More()) {
         int wt; uint32_t f = w.Tag(wt);
         if (f == 1 && wt == 0) id = uint32_t(w.Varint());
         else if (f == 2 && wt == 2) args.push_back(ReadColumn(w.Sub()));
         else if (f == 3 && wt == 0) ftype = uint32_t(w.Varint());
-        else if (f == 4 && wt == 0) w.Varint();
+        else if (f == 4 && wt == 0) kernelIdx = uint32_t(w.Varint());
         else if (f == 5 && wt == 0) { a.yqlHasOp = true; a.yqlOp = uint32_t(w.Varint()); }
         else w.Skip(wt);
     }
     for (auto& c : args) a.args.push_back(prog.ColumnName(c));
     if (ftype == 2) {  // YQL_KERNEL
         a.op = OP_YQL;
+        // a kernel sent with its KernelIdx alone (unary kernels, If: kqp_olap_compiler.cpp:655-676, 740-759) is what the
+        // caller's table of the kernel set says it is
+        if (!a.yqlHasOp && kernelIdx < prog.kernelOps.size() && prog.kernelOps[kernelIdx] != 0xFFFFFFFFu) {
+            a.yqlHasOp = true;
+            a.yqlOp = prog.kernelOps[kernelIdx];
+        }
         return;
     }
     auto like = [&](bool icase) {  // mkLikeOptions: the pattern is a previously assigned binary-like constant
@@ -1299,6 +1306,40 @@ static DatumPtr YqlIf(const DatumPtr& pred, const DatumPtr& th, const DatumPtr& 
     return out;
 }
 
+// The unary kernels of NYql::TKernelRequestBuilder::AddUnaryOp (ydb/library/yql/core/arrow_kernels/request/request.cpp:25-46),
+// by EUnaryOp (request.h:11-17).  No fixture of the reference holds their results: restated from the kernels' sources.
+static DatumPtr YqlUnary(uint32_t op, const DatumPtr& a) {
+    const int64_t n = a->scalar ? 1 : a->n;
+    switch (op) {
+        case 0: {  // Not -- BlockNot (minikql/comp_nodes/mkql_block_logical.cpp:379-417): a Bool block is UInt8 0 / 1; nulls stay
+            if (a->ty != U8 && a->ty != BOOL) throw Error("Unsupported: YQL Not of a non-bool");
+            auto out = std::make_shared<Datum>(*a);
+            for (auto& v : out->u) v = v ? 0 : 1;
+            return out;
+        }
+        case 1: {  // Size -- BlockFunc("Size"): bytes of the string, Uint32 (kqp_olap_compiler.cpp:663-665)
+            if (!IsStr(a->ty)) throw Error("Unsupported: YQL Size of a non-string");
+            auto out = NewArray(U32, n);
+            out->scalar = a->scalar;
+            out->n = a->n;
+            out->ok = a->ok;
+            for (int64_t r = 0; r < n; ++r) out->u[r] = (out->ok.empty() || out->ok[r]) ? uint64_t(a->s[r].size()) : 0;
+            return out;
+        }
+        case 2:  // Minus -- mkql_builtins_minus.cpp: -x in the argument's type (integers wrap)
+            if (!IsNum(a->ty)) throw Error("Unsupported: YQL Minus of a non-number");
+            return CustomUnary(OP_NEGATE, "Minus", a);
+        case 3:  // Abs -- mkql_builtins_abs.cpp: the argument's type; the smallest integer stays itself, unsigned values too
+            if (!IsNum(a->ty)) throw Error("Unsupported: YQL Abs of a non-number");
+            return CustomUnary(OP_ABS, "Abs", a);
+        case 4:  // Just -- mkql_block_just.cpp: the same values under an optional type (the same Arrow array)
+            if (!a->ok.empty()) throw Error("Unsupported: YQL Just of an optional value");
+            return a;
+        default:
+            throw Error("unknown unary YQL kernel");
+    }
+}
+
 static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
     if (a.op == OP_CONST) return a.constant;
     std::vector<DatumPtr> args;
@@ -1406,8 +1447,12 @@ static DatumPtr EvalAssign(const Assign& a, const Batch& b) {
         case OP_YQL:
             // the only kernel of three arguments is If, sent with a KernelIdx alone
             // (ydb/core/kqp/query_compiler/kqp_olap_compiler.cpp:740-759)
-            if (!a.yqlHasOp && args.size() == 3) return YqlIf(args[0], args[1], args[2]);
+            if ((!a.yqlHasOp || a.yqlOp == 0x10000u) && args.size() == 3) return YqlIf(args[0], args[1], args[2]);
             if (!a.yqlHasOp) throw Error("Unsupported: YQL kernel without YqlOperationId");
+            if (a.yqlOp >= 0x100u && a.yqlOp <= 0x104u) {
+                if (args.size() != 1) throw Error("Expected 1 arg");
+                return YqlUnary(a.yqlOp - 0x100u, args[0]);
+            }
             if (args.size() != 2) throw Error("Unsupported: YQL kernel arity");
             return YqlKernel(a.yqlOp, args[0], args[1]);
         default:
@@ -1992,10 +2037,18 @@ static DatumPtr ImportCol(const orc_col& c) {
     return d;
 }
 
+void* orc_program_create_with_kernels(const uint8_t* pb, size_t n, int olap_wrapper, const uint32_t* ids, const char* const* names,
+                                      size_t ncols, const orc_col* params, size_t nparams, const uint32_t* kernelOps, size_t nkernels, char** err);
 void* orc_program_create(const uint8_t* pb, size_t n, int olap_wrapper, const uint32_t* ids, const char* const* names,
                          size_t ncols, const orc_col* params, size_t nparams, char** err) {
+    return orc_program_create_with_kernels(pb, n, olap_wrapper, ids, names, ncols, params, nparams, nullptr, 0, err);
+}
+
+void* orc_program_create_with_kernels(const uint8_t* pb, size_t n, int olap_wrapper, const uint32_t* ids, const char* const* names,
+                                      size_t ncols, const orc_col* params, size_t nparams, const uint32_t* kernelOps, size_t nkernels, char** err) {
     try {
         auto prog = std::make_unique<Program>();
+        if (kernelOps) prog->kernelOps.assign(kernelOps, kernelOps + nkernels);
         prog->directOperations = (olap_wrapper & 2) != 0;
         olap_wrapper &= 1;
         for (size_t i = 0; i < ncols; ++i) { prog->resolver[ids[i]] = names[i]; prog->byName[names[i]] = ids[i]; }

@@ -56,6 +56,10 @@ def load():
         lib.orc_program_create.restype = ctypes.c_void_p
         lib.orc_program_create.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        lib.orc_program_create_with_kernels.restype = ctypes.c_void_p
+        lib.orc_program_create_with_kernels.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                        ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                                        ctypes.POINTER(ctypes.c_void_p)]
         lib.orc_program_free.argtypes = [ctypes.c_void_p]
         lib.orc_program_steps.argtypes = [ctypes.c_void_p]
         lib.orc_program_sources.restype = ctypes.c_void_p
@@ -206,7 +210,7 @@ class OracleBatch:
 
 class Oracle:
     def __init__(self, resolver: Sequence[Tuple[int, str]], program, parameters: Optional[Dict[str, object]] = None,
-                 olap_wrapper: Optional[bool] = None):
+                 olap_wrapper: Optional[bool] = None, kernel_ops: Optional[Sequence[int]] = None):
         self._lib = load()
         direct = False
         if hasattr(program, "encode") and not isinstance(program, (bytes, bytearray)):
@@ -231,8 +235,10 @@ class Oracle:
         pcols, keep = self._columns(parameters or {})
         err = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(data, len(data))
-        self._h = self._lib.orc_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), (1 if wrapper else 0) | (2 if direct else 0), ids, names,
-                                               len(resolver), pcols, len(parameters or {}), ctypes.byref(err))
+        ops = (ctypes.c_uint32 * max(1, len(kernel_ops or [])))(*(kernel_ops or []))
+        self._h = self._lib.orc_program_create_with_kernels(ctypes.cast(buf, ctypes.c_void_p), len(data), (1 if wrapper else 0) | (2 if direct else 0),
+                                                            ids, names, len(resolver), pcols, len(parameters or {}),
+                                                            ops if kernel_ops is not None else None, len(kernel_ops or []), ctypes.byref(err))
         if not self._h:
             raise OracleError(_take(self._lib, err.value))
 

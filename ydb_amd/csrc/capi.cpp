@@ -142,6 +142,14 @@ void ssa_free_string(char* s) { std::free(s); }
 int ssa_program_create(const uint8_t* program, size_t program_size, int olap_wrapper, const uint32_t* col_ids,
                        const char* const* col_names, size_t ncols, const ArrowArray* params,
                        const ArrowSchema* params_schema, int device, ssa_program_t** out, char** err) {
+    return ssa_program_create_with_kernels(program, program_size, olap_wrapper, col_ids, col_names, ncols, params, params_schema, nullptr, 0,
+                                           device, out, err);
+}
+
+int ssa_program_create_with_kernels(const uint8_t* program, size_t program_size, int olap_wrapper, const uint32_t* col_ids,
+                                    const char* const* col_names, size_t ncols, const ArrowArray* params,
+                                    const ArrowSchema* params_schema, const uint32_t* kernel_ops, size_t nkernels, int device,
+                                    ssa_program_t** out, char** err) {
     if (err) *err = nullptr;
     if (!out) return SSA_INVALID;
     *out = nullptr;
@@ -152,7 +160,15 @@ int ssa_program_create(const uint8_t* program, size_t program_size, int olap_wra
     if (!st.ok()) return Fail(st, err);
     auto p = std::make_unique<ssa_program>();
     std::string error;
-    if (!p->Container.Init(resolver, program, program_size, (olap_wrapper & 1) != 0, parameters, error, (olap_wrapper & SSA_PROGRAM_DIRECT_OPERATIONS) != 0)) {
+    std::vector<uint32_t> kernelOps;
+    if (kernel_ops != nullptr) kernelOps.assign(kernel_ops, kernel_ops + nkernels);
+    for (uint32_t op : kernelOps) {
+        const bool known = op <= uint32_t(EYqlOp::Coalesce) || (op >= kYqlUnaryBase && op <= uint32_t(EYqlOp::Just)) || op == uint32_t(EYqlOp::If) ||
+                           op == kYqlKernelUnknown;
+        if (!known) return Fail(Status{ST_INVALID, "kernel_ops: " + std::to_string(op) + " names no kernel operation"}, err);
+    }
+    if (!p->Container.Init(resolver, program, program_size, (olap_wrapper & 1) != 0, parameters, error, (olap_wrapper & SSA_PROGRAM_DIRECT_OPERATIONS) != 0,
+                           kernel_ops != nullptr ? &kernelOps : nullptr)) {
         return Fail(Status{ST_PARSE_ERROR, error}, err);
     }
     p->Device = device;  // the executor (HIP stream, device buffers) is created at first use

@@ -696,11 +696,58 @@ struct Compiler {
         return Status::OK();
     }
 
+    // TKernelRequestBuilder::AddUnaryOp (ydb/library/yql/core/arrow_kernels/request/request.cpp:25-46):
+    //   Not   BlockNot (minikql/comp_nodes/mkql_block_logical.cpp:379-417): a Bool block (UInt8 0 / 1), nulls stay nulls
+    //   Just  BlockJust (mkql_block_just.cpp): the values as they are, now of an optional type -- the same Arrow array
+    //   Size  BlockFunc("Size"): the byte length of a string as Uint32 (kqp_olap_compiler.cpp:663-665)
+    //   Minus, Abs  BlockFunc of the argument's own type: two's-complement wrap for integers (Abs of an unsigned is the
+    //         value itself), sign operations for floats (mkql_builtins_minus.cpp, mkql_builtins_abs.cpp)
+    Status YqlUnary(EYqlOp op, ExprPtr arg, ExprPtr& out) {
+        const int t = arg->Type;
+        switch (op) {
+            case EYqlOp::Not: {
+                if (t == T_BOOL) return Unary(OP_NOT, 0, 0, arg, T_BOOL, arg->Nullable, out);
+                if (t != T_U8) return Status::Unsupported(std::string("YQL Not of ") + TypeName(t));
+                // (a Bool block holds 0 or 1: !x is x == 0)
+                return Binary(OP_CMP, CLS_U, CMP_EQ, arg, MakeConst(NumScalar(T_U8, 0, true)), T_U8, arg->Nullable, 0, out);
+            }
+            case EYqlOp::Just:
+                // (Just of an optional nests optionals: Optional<Optional<T>> blocks are structs, not this array)
+                if (arg->Nullable) return Status::Unsupported("YQL Just of an optional value");
+                out = arg;
+                return Status::OK();
+            case EYqlOp::Size: {
+                if (!IsStrLeaf(arg)) return Status::Unsupported(std::string("YQL Size of ") + TypeName(t));
+                if (arg->Kind == Expr::CONST) {
+                    out = MakeConst(NumScalar(T_U32, arg->Scalar.Bytes.size(), arg->Scalar.Valid));
+                    return Status::OK();
+                }
+                auto e = std::make_shared<Expr>();
+                e->Kind = Expr::STROP;
+                e->Op = OP_STRLEN;
+                e->L = arg;
+                e->Type = T_U32;
+                e->Nullable = arg->Nullable;
+                out = e;
+                return Status::OK();
+            }
+            case EYqlOp::Minus: case EYqlOp::Abs:
+                if (!IsNumeric(t)) return Status::Unsupported(std::string("YQL ") + (op == EYqlOp::Abs ? "Abs" : "Minus") + " of " + TypeName(t));
+                return Unary(OP_FUNC, t, op == EYqlOp::Abs ? FN_ABS : FN_NEG, arg, t, arg->Nullable, out);
+            default:
+                return Status::Unsupported("unknown unary YQL kernel");
+        }
+    }
+
     Status YqlFunction(const TAssign& a, std::vector<ExprPtr>& args, ExprPtr& out) {
         if (!a.YqlOperationId) return Status::Unsupported("YQL kernel without YqlOperationId");
         if (EYqlOp(*a.YqlOperationId) == EYqlOp::If) {
             if (args.size() != 3) return Status::Invalid("Expected 3 args");
             return YqlIf(args[0], args[1], args[2], out);
+        }
+        if (*a.YqlOperationId >= kYqlUnaryBase && *a.YqlOperationId <= uint32_t(EYqlOp::Just)) {
+            if (args.size() != 1) return Status::Invalid("Expected 1 arg");
+            return YqlUnary(EYqlOp(*a.YqlOperationId), args[0], out);
         }
         if (args.size() != 2) return Status::Unsupported("YQL kernel arity");
         ExprPtr l = args[0], r = args[1];

@@ -267,8 +267,8 @@ PbColumn ReadColumn(std::string_view bytes) {
 
 class TProgramBuilder {
 public:
-    TProgramBuilder(const IColumnResolver& resolver, const TParameters& params, bool directOperations)
-        : Resolver(resolver), Params(params), DirectOperations(directOperations) {}
+    TProgramBuilder(const IColumnResolver& resolver, const TParameters& params, bool directOperations, const std::vector<uint32_t>* kernelOps)
+        : Resolver(resolver), Params(params), DirectOperations(directOperations), KernelOps(kernelOps) {}
 
     std::string Error;
     std::vector<std::pair<uint32_t, TColumnInfo>> Sources;
@@ -449,6 +449,8 @@ private:
             // runtime version >= 4) or, failing that, by a SIMPLE function id naming the same operation.
             res.IsYqlKernel = true;
             res.KernelIdx = kernelIdx;
+            // (what the caller knows about the kernel set comes first: it is the only way a unary kernel is told)
+            if (!yqlOp && KernelOps && kernelIdx < KernelOps->size() && (*KernelOps)[kernelIdx] != kYqlKernelUnknown) yqlOp = (*KernelOps)[kernelIdx];
             if (yqlOp) {
                 res.YqlOperationId = yqlOp;
             } else if (res.Arguments.size() == 3) {
@@ -592,13 +594,15 @@ private:
     const IColumnResolver& Resolver;
     const TParameters& Params;
     bool DirectOperations;
+    const std::vector<uint32_t>* KernelOps;  // may be null
     std::unordered_map<std::string, TScalar> Constants;
 };
 
 }  // namespace
 
 bool TProgramContainer::Init(const IColumnResolver& columnResolver, const uint8_t* serialized, size_t size,
-                             bool olapWrapper, const TParameters& parameters, std::string& error, bool directOperations) {
+                             bool olapWrapper, const TParameters& parameters, std::string& error, bool directOperations,
+                             const std::vector<uint32_t>* kernelOps) {
     std::string_view program(reinterpret_cast<const char*>(serialized), size);
     if (olapWrapper) {
         bool found = false;
@@ -615,7 +619,7 @@ bool TProgramContainer::Init(const IColumnResolver& columnResolver, const uint8_
         }
         if (!found) program = std::string_view();
     }
-    if (!ParseProgram(columnResolver, program, parameters, error, directOperations)) {
+    if (!ParseProgram(columnResolver, program, parameters, error, directOperations, kernelOps)) {
         if (error.empty()) error = "Wrong olap program";
         return false;
     }
@@ -623,9 +627,10 @@ bool TProgramContainer::Init(const IColumnResolver& columnResolver, const uint8_
 }
 
 bool TProgramContainer::ParseProgram(const IColumnResolver& columnResolver, std::string_view program,
-                                     const TParameters& parameters, std::string& error, bool directOperations) {
+                                     const TParameters& parameters, std::string& error, bool directOperations,
+                                     const std::vector<uint32_t>* kernelOps) {
     auto ssaProgram = std::make_shared<TProgram>();
-    TProgramBuilder builder(columnResolver, parameters, directOperations);
+    TProgramBuilder builder(columnResolver, parameters, directOperations, kernelOps);
     auto step = std::make_shared<TProgramStep>();
 
     PbReader r(program);

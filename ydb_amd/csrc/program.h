@@ -51,7 +51,14 @@ enum class EYqlOp : uint32_t {
     // Not an EBinaryOp: TKernelRequestBuilder::AddIf (request.h:49) is the only kernel of three arguments and is sent
     // with a KernelIdx alone (ydb/core/kqp/query_compiler/kqp_olap_compiler.cpp:740-759); recognised by its arity.
     If = 0x10000,
+    // NYql::TKernelRequestBuilder::EUnaryOp (request.h:11-17) + kYqlUnaryBase.  KQP sends these with a KernelIdx alone
+    // (kqp_olap_compiler.cpp:655-676, every pushed NOT at :804-812): which operation an index stands for is written in
+    // the program's serialized MiniKQL kernel set, which this build does not read -- the caller hands the operations of
+    // the kernel indexes over beside the program (TProgramContainer::Init, kernelOps).
+    Not = 0x100, Size, Minus, Abs, Just,
 };
+constexpr uint32_t kYqlUnaryBase = 0x100;
+constexpr uint32_t kYqlKernelUnknown = 0xFFFFFFFFu;
 
 const char* GetFunctionName(EOperation op);          // program.cpp:163-301
 const char* GetFunctionName(EAggregate op);          // program.cpp:391-409
@@ -188,14 +195,16 @@ public:
     // else a bare TProgram.  Returns false and fills `error` on a malformed / unsupported program;
     // an empty error from the builder becomes "Wrong olap program" like the reference does.
     // `directOperations`: accept TFunction ids of kDirectOperationBase + EOperation as well (see EOperation).
+    // `kernelOps`: per KernelIdx the EYqlOp the kernel stands for, kYqlKernelUnknown where the caller does not say.
     bool Init(const IColumnResolver& columnResolver, const uint8_t* serialized, size_t size, bool olapWrapper,
-              const TParameters& parameters, std::string& error, bool directOperations = false);
+              const TParameters& parameters, std::string& error, bool directOperations = false,
+              const std::vector<uint32_t>* kernelOps = nullptr);
     bool HasProgram() const { return !!Program; }
     const std::shared_ptr<TProgram>& GetProgram() const { return Program; }
 
 private:
     bool ParseProgram(const IColumnResolver& columnResolver, std::string_view program, const TParameters& parameters,
-                      std::string& error, bool directOperations);
+                      std::string& error, bool directOperations, const std::vector<uint32_t>* kernelOps);
     std::shared_ptr<TProgram> Program;
 };
 

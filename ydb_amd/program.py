@@ -64,7 +64,9 @@ class ProgramContainer:
 
     # -- TProgramContainer::Init -------------------------------------------------------------------
     def Init(self, resolver: ColumnResolver, program: Union[Program, bytes], olap_wrapper: Optional[bool] = None,
-             parameters: Optional[HostBatch] = None) -> Tuple[bool, str]:
+             parameters: Optional[HostBatch] = None, kernel_ops: Optional[Sequence[int]] = None) -> Tuple[bool, str]:
+        """`kernel_ops`: what each KernelIdx of the program's YQL kernels stands for (ssa_program_create_with_kernels):
+        ssa_pb.KERNEL_UNARY_BASE + YQL_UNARY.x, a YQL.x value, KERNEL_IF or KERNEL_UNKNOWN."""
         direct = False
         if isinstance(program, Program):
             data = olap_program(program)
@@ -81,8 +83,14 @@ class ProgramContainer:
         buf = ctypes.create_string_buffer(data, len(data))
         pa = ctypes.byref(parameters.array) if parameters is not None else None
         ps = ctypes.byref(parameters.schema) if parameters is not None else None
-        rc = self._lib.ssa_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), (1 if wrapper else 0) | (2 if direct else 0), ids, names,
-                                          len(resolver), pa, ps, self._device, ctypes.byref(out), ctypes.byref(err))
+        flags = (1 if wrapper else 0) | (2 if direct else 0)
+        if kernel_ops is None:
+            rc = self._lib.ssa_program_create(ctypes.cast(buf, ctypes.c_void_p), len(data), flags, ids, names,
+                                              len(resolver), pa, ps, self._device, ctypes.byref(out), ctypes.byref(err))
+        else:
+            ops = (ctypes.c_uint32 * max(1, len(kernel_ops)))(*kernel_ops)
+            rc = self._lib.ssa_program_create_with_kernels(ctypes.cast(buf, ctypes.c_void_p), len(data), flags, ids, names, len(resolver), pa, ps,
+                                                           ops, len(kernel_ops), self._device, ctypes.byref(out), ctypes.byref(err))
         msg = _lib.take_string(self._lib, err.value)
         if rc != _lib.SSA_OK:
             if rc != _lib.SSA_PARSE_ERROR:

@@ -99,6 +99,21 @@ class YQL:
     Coalesce = 17
 
 
+class YQL_UNARY:
+    """NYql::TKernelRequestBuilder::EUnaryOp (request.h:11-17).  KQP sends these by KernelIdx alone; the table that says
+    which index is which operation goes to ProgramContainer.Init(kernel_ops=...) as KERNEL_UNARY_BASE + the value."""
+    Not = 0
+    Size = 1
+    Minus = 2
+    Abs = 3
+    Just = 4
+
+
+KERNEL_UNARY_BASE = 0x100
+KERNEL_IF = 0x10000
+KERNEL_UNKNOWN = 0xFFFFFFFF
+
+
 # --- primitive wire encoders --------------------------------------------------
 class OP:
     """NKikimr::NKernels::EOperation (ydb/library/arrow_kernels/operations.h:5-84), by position.  The ones below have no
