@@ -42,6 +42,13 @@ def main():
         for exchange in (("allgather", "alltoall", "auto") if name != "q6" else ("allgather",)):
             res = scan.run(batch, gather_device=cpu, exchange=exchange)
             out[(name, exchange)] = {k: (c.type, list(c.values) if isinstance(c.values, list) else np.asarray(c.values), np.asarray(c.valid)) for k, c in res.items()}
+    # the mixed stream of bench.py (--workload mixed): Q1 and Q6 alternate over one resident shard, each through its own
+    # scan object whose kernels, tables and exchange buffers live across the steps
+    stream = {name: (ShardedScan(prog, tpch.LINEITEM_RESOLVER, device=0), li.batch(cols)) for name, (prog, cols) in programs().items() if name != "many_groups"}
+    for step in range(3):
+        for name, (scan, batch) in stream.items():
+            res = scan.run(batch, gather_device=cpu)
+            out[("mixed", step, name)] = {k: (c.type, list(c.values) if isinstance(c.values, list) else np.asarray(c.values), np.asarray(c.valid)) for k, c in res.items()}
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
         pickle.dump(out, f)
     dist.barrier()

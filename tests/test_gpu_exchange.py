@@ -100,6 +100,40 @@ def test_pack_unpack_concat_slice_round_trip():
     compare_batches(got, exp, key_names=["k", "s"], float_sum_names=["122"])
 
 
+def test_concat_of_boolean_columns_from_views_at_any_bit():
+    """Boolean values are bits: the parts of a concatenation start at any bit of their bitmaps (views of other batches,
+    results of compare steps), with and without nulls."""
+    from ydb_amd.program import ProgramContainer
+    rng = np.random.default_rng(79)
+    res = [(1, "b"), (2, "k"), (3, "c")]
+    pc = ProgramContainer()
+    ok, err = pc.Init(res, Program().project([1, 2, 3]))
+    assert ok, err
+
+    def bools(n, nulls):
+        return {"b": Col(rng.random(n) > 0.5, valid=(rng.random(n) > 0.3) if nulls else None), "k": rng.integers(0, 9, n).astype(np.int16),
+                "c": rng.random(n) > 0.1}
+    host = [bools(1000, True), bools(0, False), bools(1, False), bools(4097, True), bools(300, False)]
+    cuts = [(3, 900), (0, 0), (0, 1), (13, 4001), (7, 293)]
+    views = [pc.Slice(pc.Import(h), at, n) for h, (at, n) in zip(host, cuts)]
+    whole = pc.Concat(views)
+    assert whole.rows == sum(n for _, n in cuts)
+
+    def cut(h, at, n):
+        return {k: (Col(v.values[at:at + n], valid=None if v.valid is None else v.valid[at:at + n]) if isinstance(v, Col) else v[at:at + n])
+                for k, v in h.items()}
+    expected = host_concat([cut(h, at, n) for h, (at, n) in zip(host, cuts)])
+    check_equal(pc.Export(whole), expected)
+    # through the flat layout as well, and once more concatenated with itself
+    import torch
+    header, data_bytes = pc.PackLayout(whole)
+    buf = torch.empty(data_bytes + 64, dtype=torch.uint8, device="cuda:0")
+    pc.PackData(whole, buf.data_ptr(), data_bytes)
+    again = pc.Unpack(header, buf.data_ptr(), data_bytes, keep=buf)
+    twice = pc.Export(pc.Concat([again, pc.Slice(whole, 5, 100)]))
+    check_equal(twice, {k: (v[0] + v[0][5:105], v[1] + v[1][5:105]) for k, v in expected.items()})
+
+
 def test_damaged_headers_are_refused():
     import torch
     from ydb_amd.program import ProgramContainer, SsaError
@@ -166,6 +200,19 @@ def test_two_ranks_on_one_gpu_end_with_the_whole_tables_result(tmp_path):
 
         want_names, want = rows_of({k: (c.type, list(c.values) if isinstance(c.values, list) else np.asarray(c.values), np.asarray(c.valid)) for k, c in whole.items()})
         assert len(want) == n_groups
+        if name != "many_groups":
+            # the mixed stream (Q1 and Q6 alternating over the resident shard): every step of it ends, on every rank, with
+            # the whole table's result
+            for step in range(3):
+                for r in ranks:
+                    _, t = rows_of(r[("mixed", step, name)])
+                    assert set(t) == set(want), (name, step)
+                    for key, vals in want.items():
+                        for g, e in zip(t[key], vals):
+                            if isinstance(e, (float, np.floating)):
+                                assert abs(g - e) <= 1e-11 * max(1.0, abs(e)), (name, step, key, g, e)
+                            else:
+                                assert g == e, (name, step, key, g, e)
         for exchange in (("allgather", "alltoall", "auto") if name != "q6" else ("allgather",)):
             parts = [rows_of(r[(name, exchange)]) for r in ranks]
             resolved = exchange
@@ -187,6 +234,27 @@ def test_two_ranks_on_one_gpu_end_with_the_whole_tables_result(tmp_path):
                             assert abs(g - e) <= 1e-11 * max(1.0, abs(e)), (name, exchange, key, col, g, e)
                         else:
                             assert g == e, (name, exchange, key, col, g, e)
+
+
+def test_two_ranks_run_the_mixed_stream_of_the_benchmark():
+    """bench.py --workload mixed with two ranks on one GPU (the exchange over gloo): one JSON line from rank 0 that counts
+    both ranks' rows of both programs."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    rows = 2_000_000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(here, "..", "bench.py"), "--gpus", "2", "--workload", "mixed", "--rows", str(rows),
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--rehearse-on-one-gpu"]
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert "mixed" in line["config"]["workload"] or "Q1" in line["config"]["workload"]
+    # every step scans the shard once per program on either rank
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 2 * 2 * rows) <= 1e-6 * 4 * rows
 
 
 def test_one_rank_over_rccl_runs_the_device_exchange():

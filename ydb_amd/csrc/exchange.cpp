@@ -346,6 +346,7 @@ Status Executor::ConcatBatches(const std::vector<BatchPtr>& parts, BatchPtr& out
     res->Rows = total;
     std::vector<CopySegment> segs;
     std::vector<BufferPtr> validBytes(first.Cols.size());
+    std::vector<BufferPtr> boolBytes(first.Cols.size());  // BOOL columns: the parts' bits as a byte per row, packed at the end
     for (size_t c = 0; c < first.Cols.size(); ++c) {
         Column col;
         col.Field = first.Cols[c].Field;
@@ -374,7 +375,10 @@ Status Executor::ConcatBatches(const std::vector<BatchPtr>& parts, BatchPtr& out
             col.Chars = Buffer::Alloc(size_t(chars) + 16);
             if (!col.Values || !col.Chars) return Status::Hip("out of device memory");
         } else if (type == T_BOOL) {
-            return Status::Unsupported("concatenating a boolean column");
+            // (the parts' bitmaps start at any bit: their rows go through a byte each and are packed behind the copies)
+            boolBytes[c] = Buffer::Alloc(size_t(total) + 16);
+            col.Values = Buffer::Alloc(size_t((total + 7) / 8) + 16);
+            if (!boolBytes[c] || !col.Values) return Status::Hip("out of device memory");
         } else {
             col.Values = Buffer::Alloc(size_t(total) * size_t(TypeWidth(type)) + 16);
             if (!col.Values) return Status::Hip("out of device memory");
@@ -397,6 +401,10 @@ Status Executor::ConcatBatches(const std::vector<BatchPtr>& parts, BatchPtr& out
                     segs.push_back(CopySegment{static_cast<const uint8_t*>(src.Chars->Ptr) + lo, static_cast<uint8_t*>(col.Chars->Ptr) + charsAt, uint64_t(hi - lo), SEG_BYTES, 0});
                     charsAt += uint64_t(hi - lo);
                 }
+            } else if (type == T_BOOL) {
+                if (!src.Values) return Status::Invalid("boolean column without values");
+                segs.push_back(CopySegment{static_cast<const uint8_t*>(src.Values->Ptr), static_cast<uint8_t*>(boolBytes[c]->Ptr) + row, uint64_t(n),
+                                           SEG_BITS_TO_BYTES, int64_t(src.ValBitOff)});
             } else {
                 const size_t w = size_t(TypeWidth(type));
                 segs.push_back(CopySegment{static_cast<const uint8_t*>(src.ValuesPtr()), static_cast<uint8_t*>(col.Values->Ptr) + size_t(row) * w, uint64_t(n) * w, SEG_BYTES, 0});
@@ -412,9 +420,19 @@ Status Executor::ConcatBatches(const std::vector<BatchPtr>& parts, BatchPtr& out
         res->Cols.push_back(std::move(col));
     }
     SSA_RETURN_NOT_OK(RunSegments(segs));
+    BufferPtr unused;
     for (size_t c = 0; c < res->Cols.size(); ++c) {
+        if (boolBytes[c] && total > 0) {
+            if (!unused) {
+                unused = Buffer::Alloc(256);
+                if (!unused) return Status::Hip("out of device memory");
+            }
+            SSA_HIP(LaunchPackBytesToBits(static_cast<const uint8_t*>(boolBytes[c]->Ptr), total, static_cast<uint8_t*>(res->Cols[c].Values->Ptr),
+                                          static_cast<unsigned long long*>(unused->Ptr), StreamHandle));
+        }
         if (validBytes[c]) SSA_RETURN_NOT_OK(PackValidity(validBytes[c], total, res->Cols[c]));
     }
+    SSA_HIP(hipStreamSynchronize(StreamHandle));  // (boolBytes are read until here)
     out = res;
     return Status::OK();
 }

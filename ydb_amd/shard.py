@@ -348,6 +348,8 @@ class ShardedScan:
         return self._head
 
     HEADER_CAPACITY = 16384  # bytes of a part's description (a few dozen per column)
+    SLOT_BYTES = 65536       # a rank's contribution to the one-collective exchange of small partial tables ...
+    SLOT_HEADER = 4096       # ... of which the first bytes hold three int64 (description length, data bytes, fits) and the description
 
     def _merge_names(self, partial) -> List[str]:
         names = {i: n for i, n in self.resolver}
@@ -404,6 +406,39 @@ class ShardedScan:
 
         heads = None
         if exchange in ("auto", "allgather"):
+            # A partial table of a few groups (TPC-H Q1: four rows of ten columns) goes out in ONE collective: every rank
+            # contributes a slot of fixed size that carries the description of its table and the packed table itself.
+            # The slot is filled on the device (the description is a few hundred bytes copied up, the table is packed in
+            # place); only after the collective do the descriptions come down, all of them in one copy.  A rank whose table
+            # does not fit says so in its slot, and every rank -- they all see the same slots -- takes the two-step way below.
+            slot_bytes, slot_head = self.SLOT_BYTES, self.SLOT_HEADER
+            header, data_bytes = pc.PackLayout(partial)
+            fits = len(header) <= slot_head - 24 and data_bytes <= slot_bytes - slot_head
+            slot = torch.empty(slot_bytes, dtype=torch.uint8, device=gpu)
+            lead = struct.pack("<qqq", len(header), data_bytes, 1 if fits else 0) + (header if fits else b"")
+            slot[:len(lead)].copy_(torch.frombuffer(bytearray(lead), dtype=torch.uint8), non_blocking=True)
+            if fits:
+                pc.PackData(partial, slot.data_ptr() + slot_head, data_bytes)
+            slots = torch.empty(world * slot_bytes, dtype=torch.uint8, device=wire)
+            dist.all_gather_into_tensor(slots, slot.to(wire))
+            settle()
+            slots = slots.to(gpu)
+            leads = slots.view(world, slot_bytes)[:, :slot_head].cpu().numpy()
+            mark("one collective")
+            seen = [struct.unpack_from("<qqq", leads[r].tobytes(), 0) for r in range(world)]
+            if all(f == 1 for _, _, f in seen):
+                heads = [(leads[r, 24:24 + seen[r][0]].tobytes(), seen[r][1]) for r in range(world)]
+                most = max(rows_of(h) for h, _ in heads)
+                if exchange == "allgather" or not (key_names and most > self.ALL_TO_ALL_GROUPS):
+                    parts = [pc.Unpack(h, slots.data_ptr() + r * slot_bytes + slot_head, db, keep=slots) for r, (h, db) in enumerate(heads)]
+                    whole = pc.Concat(parts)
+                    mark("concatenate")
+                    if timing:
+                        print("exchange: " + ", ".join(f"{w} {1e3 * (t - marks[i][1]):.2f} ms" for i, (w, t) in enumerate(marks[1:])), flush=True)
+                    return pc.Rename(whole, self._merge_names(whole))
+                exchange = "alltoall"
+                heads = None
+        if heads is None and exchange in ("auto", "allgather"):
             # every rank's description of its whole partial table: enough to decide, and the first half of an all-gather
             mine = describe([partial]).reshape(-1).to(wire)
             every = torch.empty(world * mine.numel(), dtype=torch.int64, device=wire)
