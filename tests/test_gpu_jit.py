@@ -291,3 +291,31 @@ def test_patterns_of_one_length_share_a_kernel(monkeypatch):
     built1, _, _ = _stats()
     assert counts[-1] == 0 and min(counts[:-1]) > 1000
     assert built1 - built0 <= 1, "a kernel was built per pattern"
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint8, np.int8])
+@pytest.mark.parametrize("n", [1, 8191, 8192, 8193, 300_001])
+@pytest.mark.parametrize("wide", ["16", "32"])
+def test_rows_of_one_and_two_bytes_in_wide_tiles(forced, monkeypatch, dtype, n, wide):
+    """A batch of one narrow column is scanned 16 rows per thread by the kernels built for its programs (32 with
+    SSA_WIDE_U32: tiles of 8192 rows, every bit of the row masks in use): the key-less count / sum / extremes behind a
+    filter, and the filtered GROUP BY on the column every way the keyed kernel runs (register-held groups, plain, the rows
+    behind the filter one by one)."""
+    from ydb_amd.ssa_pb import AGG, YQL, Aggregate, Program
+    if wide == "32":
+        monkeypatch.setenv("SSA_WIDE_U32", "1")
+    rng = np.random.default_rng(n)
+    info = np.iinfo(dtype)
+    x = np.where(rng.random(n) < 0.9, 0, rng.integers(max(info.min, -40), min(info.max, 90), n)).astype(dtype)
+    res = [(1, "x")]
+    zero = {"int16": "Int16", "uint8": "Uint8", "int8": "Int8"}[np.dtype(dtype).name]
+    nokey = (Program(version=5).assign_const(100, zero, 0).assign_yql(101, YQL.NotEquals, [1, 100]).filter(101)
+             .group_by([Aggregate(110, AGG.COUNT, []), Aggregate(111, AGG.SUM, [1]), Aggregate(112, AGG.MIN, [1]), Aggregate(113, AGG.MAX, [1])]))
+    got, exp = P.both(res, nokey, {"x": x})
+    compare_batches(got, exp)
+    keyed = (Program(version=5).assign_const(100, zero, 0).assign_yql(101, YQL.NotEquals, [1, 100]).filter(101)
+             .group_by([Aggregate(110, AGG.COUNT, []), Aggregate(111, AGG.SUM, [1])], keys=[1]))
+    for hot in ("0", "1", "2"):
+        monkeypatch.setenv("SSA_KEYED_HOT", hot)
+        got, exp = P.both(res, keyed, {"x": x})
+        compare_batches(got, exp, key_names=["x"])

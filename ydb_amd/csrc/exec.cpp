@@ -1244,6 +1244,10 @@ int Executor::WideRowsPerThread(const StepPlan& plan, const Batch& in) const {
     }
     bytes += 8 * plan.NumRegsUsed;
     if (bytes == 0) return kRowsPerThread;
+    // (32 rows per thread for rows of two bytes measured no faster than 16 -- ClickBench's AdvEngineID count 0.43 against
+    // 0.41 ms per 10^9 rows: with every row masked out the same kernel takes 0.32 ms, so what is left above the loads is
+    // the rows' own arithmetic on 64-bit payloads, not the per-tile work; SSA_WIDE_U32=1 builds such kernels all the same)
+    if (bytes <= 2 && plan.NumRegsUsed == 0 && std::getenv("SSA_WIDE_U32")) return 32;
     if (bytes <= 8 && plan.NumRegsUsed == 0) return 16;
     if (bytes <= 16) return 8;
     return kRowsPerThread;
@@ -2078,7 +2082,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     // narrow rows with exact keys (a filter and a small integer key): 8 rows per thread, as the key-less kernels do
     if (!hashed && plan.NumRegsUsed == 0 && WideRowsPerThread(plan, in) >= 8) specRows = 8;
     if (const char* env = std::getenv("SSA_KEYED_U")) specRows = std::atoi(env);
-    if (specRows != 1 && specRows != 2 && specRows != 4 && specRows != 8 && specRows != 16) specRows = kRowsPerThread;
+    if (specRows != 1 && specRows != 2 && specRows != 4 && specRows != 8 && specRows != 16 && specRows != 32) specRows = kRowsPerThread;
     ScanArgs sargs = args;
     LaunchCfg scfg = cfg;
     KeyedSink ssink = sink;
@@ -2184,15 +2188,16 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         if (hotMode == 2 && !canCompact) hotMode = 0;
         // Row by row behind the filter, the per-tile work is what is left to shrink: such a kernel takes 16 rows per thread
         // when the rows are narrow enough.
-        if (hotMode == 2 && specRows < 16 && WideRowsPerThread(plan, in) >= 16 && !std::getenv("SSA_KEYED_U")) {
+        const int wideRows = WideRowsPerThread(plan, in);
+        if (hotMode == 2 && specRows < wideRows && wideRows >= 16 && !std::getenv("SSA_KEYED_U")) {
             ScanArgs wargs;
             LaunchCfg wcfg;
             KeyedSink wsink{};
-            if (describe(16, wargs, wcfg, wsink).ok() && wsink.compact_n > 0) {
+            if (describe(wideRows, wargs, wcfg, wsink).ok() && wsink.compact_n > 0) {
                 sargs = wargs;
                 scfg = wcfg;
                 ssink = wsink;
-                specRows = 16;
+                specRows = wideRows;
             }
         }
     }

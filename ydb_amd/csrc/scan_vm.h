@@ -42,7 +42,7 @@ struct Val {
 
 template <int U>
 __device__ __forceinline__ constexpr uint32_t AllMask() {
-    return (1u << U) - 1u;
+    return U >= 32 ? 0xFFFFFFFFu : (1u << (U & 31)) - 1u;
 }
 
 __device__ __forceinline__ uint64_t LoadRaw(const void* base, int width, int64_t row) {
