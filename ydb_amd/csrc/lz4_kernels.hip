@@ -16,6 +16,10 @@
 // Bound: the serial chain of a frame's copies (instructions per sequence of one wave), not HBM.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ssa {
@@ -612,6 +616,364 @@ __global__ __launch_bounds__(64) void Lz4CopyKernel(const uint8_t* blob, const L
     if ((bad || op != total) && lane == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
 }
 
+// ---- the copies of a frame, 256 sequences at a time ---------------------------------------------------------------
+// Lz4BatchCopyKernel: a workgroup per frame takes the records of a block in batches of up to 256 sequences / 2 KB of
+// output.  Inside a batch nothing is serial: a prefix sum of the records' lengths places every sequence, every output
+// byte finds its sequence (the records' first bytes are marked, a running maximum carries the owner along) and its
+// source -- a literal, a byte in front of the batch (in the ring, final), or an earlier byte of the batch.  Chains of
+// the last kind are shortened by pointer jumping (a few rounds: as many as the logarithm of the longest chain of
+// matches inside the batch), until every byte points at one whose value is known; those are written to the ring first,
+// the others fetch theirs from there.  The ring in LDS holds the frame's last 64 KB and a batch more, so that no match
+// reaches past it; whole words go out to the ring and to HBM.  A sequence longer than a batch is copied by all threads
+// together, a match among them in pieces that read what the pieces before wrote.
+#ifdef SSA_LZ4_STATS
+__device__ unsigned long long gLz4Stats[16];
+#define LZ4_T(i) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
+#define LZ4_C(i, v) do { if (tid == 0) tacc[i] += (v); } while (0)
+#else
+#define LZ4_T(i) do {} while (0)
+#define LZ4_C(i, v) do {} while (0)
+#endif
+constexpr uint32_t kBatchThreads = 1024;
+constexpr uint32_t kBatchWaves = kBatchThreads / 64;
+constexpr uint32_t kBatchCap = 8 * kBatchThreads;                      // output bytes of a batch, counted from the aligned word below its first
+constexpr uint32_t kBatchRing = 65536 + kBatchCap + 256;  // bytes of the ring
+constexpr uint32_t kBatchRecAt = kBatchRing;
+constexpr uint32_t kBatchFromAt = kBatchRecAt + kBatchThreads * 16;
+constexpr uint32_t kBatchWordsAt = kBatchFromAt + (kBatchCap + 8) * 2;
+constexpr uint32_t kBatchLds = kBatchWordsAt + 6 * kBatchWaves * 4;
+static_assert(kBatchRing % 4 == 0 && kBatchFromAt % 16 == 0 && kBatchWordsAt % 16 == 0, "alignment of the batch copy's LDS");
+
+// Inclusive scans across a wave by data-parallel primitives (row shifts, then the rows' last lanes broadcast): no LDS round trips.
+template <bool kMax>
+__device__ __forceinline__ uint32_t WaveScan(uint32_t v) {
+    auto op = [](uint32_t a, uint32_t b) { return kMax ? (a > b ? a : b) : a + b; };
+    v = op(uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false)), v);  // row_shr:1
+    v = op(uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false)), v);  // row_shr:2
+    v = op(uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false)), v);  // row_shr:4
+    v = op(uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false)), v);  // row_shr:8
+    v = op(uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false)), v);  // row_bcast:15 into rows 1 and 3
+    v = op(uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false)), v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__global__ __launch_bounds__(kBatchThreads) void Lz4BatchCopyKernel(const uint8_t* blob, const Lz4FrameTask* tasks, const Lz4BlockRef* blocks,
+                                                                    const uint64_t* recStart, const Lz4Seq* recs, const Lz4BlockSummary* summaries,
+                                                                    uint32_t* status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* ring = lds;
+    uint32_t* ring32 = reinterpret_cast<uint32_t*>(lds);
+    uint4* brec = reinterpret_cast<uint4*>(lds + kBatchRecAt);
+    uint16_t* from16 = reinterpret_cast<uint16_t*>(lds + kBatchFromAt);
+    uint32_t* wsh = reinterpret_cast<uint32_t*>(lds + kBatchWordsAt);  // per wave: lengths, counts, ends, owners (two chunks), flags of the jumping rounds
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const Lz4FrameTask t = tasks[blockIdx.x];
+    __attribute__((address_space(1))) uint8_t* dst = (__attribute__((address_space(1))) uint8_t*)t.dst;
+    const uint32_t total = uint32_t(t.dst_bytes);
+    uint32_t op = 0;   // bytes of the frame written
+    uint32_t rop = 0;  // op's place in the ring (op mod kBatchRing)
+    bool bad = false;
+#ifdef SSA_LZ4_STATS
+    unsigned long long tacc[16] = {0};
+    unsigned long long tlast = wall_clock64();
+#endif
+    // the place in the ring of the byte `rel` bytes from op (|rel| below the ring's size)
+    auto ringAt = [&](int32_t rel) -> uint32_t {
+        int32_t i = int32_t(rop) + rel;
+        i += i < 0 ? int32_t(kBatchRing) : 0;
+        i -= i >= int32_t(kBatchRing) ? int32_t(kBatchRing) : 0;
+        return uint32_t(i);
+    };
+    for (uint32_t b = 0; b < t.nblocks && !bad; ++b) {
+        const uint64_t g = t.first_block + b;
+        const Lz4BlockRef blk = blocks[g];
+        const uint8_t* bsrc = blob + blk.Src;
+        const uint32_t n = blk.SrcBytes;
+        if (n == 0) continue;
+        if (blk.Stored) {
+            if (n > total - op) {
+                bad = true;
+                break;
+            }
+            for (uint32_t i0 = 0; i0 < n; i0 += 16u * kBatchThreads) {  // (a piece is far shorter than the ring: no two of its bytes share a place)
+                uint8_t x[16];
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) {
+                    const uint32_t i = i0 + q * kBatchThreads + tid;
+                    x[q] = i < n ? bsrc[i] : uint8_t(0);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) {
+                    const uint32_t i = i0 + q * kBatchThreads + tid;
+                    if (i < n) {
+                        ring[(rop + i) % kBatchRing] = x[q];
+                        dst[op + i] = x[q];
+                    }
+                }
+                __syncthreads();
+            }
+            op += n;
+            rop = (rop + n) % kBatchRing;
+            continue;
+        }
+        const Lz4BlockSummary sum = summaries[g];
+        // (the parse has checked every sequence against the block itself: what is left is the block against the frame)
+        if (sum.Sequences == 0 || sum.Bytes > total - op || sum.ReachesBack > (t.linked ? op : 0u)) {
+            bad = true;
+            break;
+        }
+        const uint32_t nrec = sum.Sequences;
+        const uint4* rec = reinterpret_cast<const uint4*>(recs + recStart[g]);
+        uint32_t k = 0;
+        while (k < nrec) {
+            const uint32_t sh = op & 3u;            // the batch is laid out from the aligned word below op: position p is byte op - sh + p
+            const uint32_t cap = kBatchCap - sh;
+            const uint32_t navail = nrec - k < kBatchThreads ? nrec - k : kBatchThreads;
+            const uint4 x = tid < navail ? rec[k + tid] : uint4{0, 0, 0, 0};
+            const uint32_t lit = x.x & kSeqCount, ml = x.y & 0xFFFFu, off = x.y >> 16;
+            const uint32_t len = lit + ml < kBatchCap + 1u ? lit + ml : kBatchCap + 1u;
+            LZ4_T(0);
+            // the marks of the records' first bytes start from zero (the array is free: its last readers are behind a barrier)
+            reinterpret_cast<uint4*>(from16)[tid] = uint4{0, 0, 0, 0};
+            if (tid == 0) {
+                reinterpret_cast<uint4*>(from16)[kBatchThreads] = uint4{0, 0, 0, 0};
+                wsh[5 * kBatchWaves] = 0;  // (the flags of the jumping rounds)
+                wsh[5 * kBatchWaves + 1] = 0;
+                wsh[5 * kBatchWaves + 2] = 0;
+            }
+            uint32_t end = WaveScan<false>(len);
+            if (lane == 63) wsh[w] = end;
+            __syncthreads();
+            for (uint32_t q = 0; q < w; ++q) end += wsh[q];
+            const uint32_t start = end - len;
+            const bool ok = tid < navail && end <= cap;
+            {
+                const uint64_t oks = __ballot(ok);
+                const uint32_t cnt = uint32_t(__popcll(oks));
+                const uint32_t lastEnd = uint32_t(__builtin_amdgcn_readlane(int(end), int(cnt ? cnt - 1u : 0u)));
+                if (lane == 0) {
+                    wsh[kBatchWaves + w] = cnt;
+                    wsh[2 * kBatchWaves + w] = cnt ? lastEnd : 0u;
+                }
+            }
+            if (ok) {
+                brec[tid] = uint4{(start + sh) | (lit << 14) | ((x.x & kSeqExternal) ? 0x80000000u : 0u), off, x.z, x.w};
+                if (len != 0) from16[sh + start] = uint16_t(tid + 1u);
+            }
+            __syncthreads();
+            uint32_t m = 0, bytes = 0;  // the batch: its records and what they decode to
+#pragma unroll
+            for (uint32_t q = 0; q < kBatchWaves; ++q) {
+                m += wsh[kBatchWaves + q];
+                bytes = max(bytes, wsh[2 * kBatchWaves + q]);
+            }
+            LZ4_T(1);
+            LZ4_C(8, 1);
+            LZ4_C(9, m);
+            if (m == 0) {
+                // A sequence longer than a batch: all threads copy its literals, then its match.
+                const uint4 s = rec[k];
+                const uint32_t slit = s.x & kSeqCount, sml = s.y & 0xFFFFu, soff = s.y >> 16;
+                if (slit > total - op || sml > total - op - slit) {
+                    bad = true;
+                    break;
+                }
+                const uint64_t inl = uint64_t(s.z) | (uint64_t(s.w) << 32);
+                for (uint32_t i0 = 0; i0 < slit; i0 += 32768u) {
+                    const uint32_t i1 = slit - i0 < 32768u ? slit : i0 + 32768u;
+                    for (uint32_t i = i0 + tid; i < i1; i += kBatchThreads) {
+                        const uint8_t v = (s.x & kSeqExternal) ? bsrc[s.z + i] : uint8_t(inl >> (8u * (i & 7u)));
+                        ring[(rop + i) % kBatchRing] = v;
+                        dst[op + i] = v;
+                    }
+                    __syncthreads();
+                }
+                op += slit;
+                rop = (rop + slit) % kBatchRing;
+                if (sml != 0) {
+                    // Bytes further on than a piece read the match's own output a whole number of periods back (what lies
+                    // `soff` back of them may have left the ring by then): written by the pieces before.
+                    const uint32_t back = soff >= kBatchCap ? soff : soff * ((kBatchCap + soff - 1u) / soff);
+                    for (uint32_t i0 = 0; i0 < sml; i0 += kBatchCap) {
+                        uint8_t v[8];
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q) {
+                            const uint32_t i = i0 + q * kBatchThreads + tid;
+                            v[q] = 0;
+                            if (i < sml) v[q] = ring[ringAt(i < kBatchCap ? int32_t(i % soff) - int32_t(soff) : int32_t(i) - int32_t(back))];
+                        }
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q) {
+                            const uint32_t i = i0 + q * kBatchThreads + tid;
+                            if (i < sml) {
+                                ring[ringAt(int32_t(i))] = v[q];
+                                dst[op + i] = v[q];
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    rop = ringAt(int32_t(sml));
+                    op += sml;
+                }
+                k += 1;
+                LZ4_T(7);
+                continue;
+            }
+            const uint32_t nch = (sh + bytes + 4u * kBatchThreads - 1u) / (4u * kBatchThreads);  // chunks of a word per thread
+            // the sequence every byte belongs to: the last mark at or before it
+            uint32_t own[2][4];
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                if (c < nch) {
+                    const uint2 mk = reinterpret_cast<const uint2*>(from16)[tid + kBatchThreads * c];
+                    own[c][0] = mk.x & 0xFFFFu;
+                    own[c][1] = max(own[c][0], mk.x >> 16);
+                    own[c][2] = max(own[c][1], mk.y & 0xFFFFu);
+                    own[c][3] = max(own[c][2], mk.y >> 16);
+                    const uint32_t s = WaveScan<true>(own[c][3]);
+                    const uint32_t before = uint32_t(__builtin_amdgcn_update_dpp(0, int(s), 0x138, 0xf, 0xf, false));  // wave_shr:1
+                    if (lane == 63) wsh[3 * kBatchWaves + c * kBatchWaves + w] = s;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) own[c][i] = max(own[c][i], before);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                if (c < nch) {
+                    uint32_t carry = 0;
+                    for (uint32_t q = 0; q < c * kBatchWaves + w; ++q) carry = max(carry, wsh[3 * kBatchWaves + q]);
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) own[c][i] = max(own[c][i], carry);
+                }
+            }
+            LZ4_T(2);
+            // every byte's source; the values of literals and of bytes that come from in front of the batch
+            uint32_t from[2][4];
+            uint32_t val[2] = {0, 0}, inside[2] = {0, 0}, open[2] = {0, 0};
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                if (c < nch) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t p = 4u * (tid + kBatchThreads * c) + i;
+                        from[c][i] = p;
+                        if (p >= sh && p < sh + bytes) {
+                            inside[c] |= 1u << i;
+                            const uint4 r = brec[own[c][i] - 1u];
+                            const uint32_t rs = r.x & 0x3FFFu, rlit = (r.x >> 14) & 0x3FFFu;
+                            const uint32_t at = p - rs;
+                            uint32_t v = 0;
+                            if (at < rlit) {
+                                v = (r.x >> 31) ? uint32_t(bsrc[r.z + at]) : uint32_t((uint64_t(r.z) | (uint64_t(r.w) << 32)) >> (8u * (at & 7u))) & 0xFFu;
+                            } else {
+                                uint32_t mi = at - rlit;
+                                if (mi >= r.y) {  // the match repeats a pattern of r.y bytes: mi mod r.y (both below 8192: the rounded quotient is off by one at most)
+                                    const uint32_t qf = uint32_t((float(mi) + 0.5f) * __builtin_amdgcn_rcpf(float(r.y)));
+                                    mi -= qf * r.y;
+                                    if (int32_t(mi) < 0) mi += r.y;
+                                    else if (mi >= r.y) mi -= r.y;
+                                }
+                                const int32_t s = int32_t(rs + rlit + mi) - int32_t(r.y);
+                                if (s < int32_t(sh)) {
+                                    v = ring[ringAt(s - int32_t(sh))];
+                                } else {
+                                    from[c][i] = uint32_t(s);
+                                    open[c] |= 1u << i;
+                                }
+                            }
+                            val[c] |= v << (8u * i);
+                        }
+                    }
+                    reinterpret_cast<uint2*>(from16)[tid + kBatchThreads * c] = uint2{from[c][0] | (from[c][1] << 16), from[c][2] | (from[c][3] << 16)};
+                }
+            }
+            __syncthreads();
+            LZ4_T(3);
+            // pointer jumping: a byte whose source is itself waiting takes over that byte's source
+            uint32_t live[2] = {open[0], open[1]};
+            for (uint32_t round = 0;; ++round) {
+                int changed = 0;
+                uint32_t* flag = wsh + 5 * kBatchWaves + (round % 3u);  // three flags in turn: the one after this round's is cleared meanwhile
+                if (tid == 0) wsh[5 * kBatchWaves + ((round + 1u) % 3u)] = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < 2; ++c) {
+                    if (c < nch && live[c] != 0) {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; ++i) {
+                            if (live[c] & (1u << i)) {
+                                const uint32_t f = from[c][i];
+                                const uint32_t gq = from16[f];
+                                if (gq != f) {
+                                    from[c][i] = gq;
+                                    changed = 1;
+                                } else {
+                                    live[c] &= ~(1u << i);
+                                }
+                            }
+                        }
+                        reinterpret_cast<uint2*>(from16)[tid + kBatchThreads * c] = uint2{from[c][0] | (from[c][1] << 16), from[c][2] | (from[c][3] << 16)};
+                    }
+                }
+                LZ4_C(10, 1);
+                if (__ballot(changed != 0) != 0 && lane == 0) *flag = 1;
+                __syncthreads();
+                if (*flag == 0) break;
+            }
+            LZ4_T(4);
+            // the known bytes into the ring, then the others fetch theirs
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                if (c < nch) {
+                    const uint32_t known = inside[c] & ~open[c];
+                    if (known != 0 && (open[c] != 0 || inside[c] != 0xFu)) {  // (a word that is complete goes out whole below)
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; ++i) {
+                            if (known & (1u << i)) ring[ringAt(int32_t(4u * (tid + kBatchThreads * c) + i) - int32_t(sh))] = uint8_t(val[c] >> (8u * i));
+                        }
+                    } else if (known != 0) {
+                        ring32[ringAt(int32_t(4u * (tid + kBatchThreads * c)) - int32_t(sh)) >> 2] = val[c];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                if (c < nch && inside[c] != 0) {
+                    const uint32_t p0 = 4u * (tid + kBatchThreads * c);
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        if (open[c] & (1u << i)) val[c] |= uint32_t(ring[ringAt(int32_t(from[c][i]) - int32_t(sh))]) << (8u * i);
+                    }
+                    if (inside[c] == 0xFu) {
+                        if (open[c] != 0) ring32[ringAt(int32_t(p0) - int32_t(sh)) >> 2] = val[c];
+                        *reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(dst + (op - sh + p0)) = val[c];
+                    } else {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; ++i) {
+                            if (inside[c] & (1u << i)) {
+                                const uint8_t v = uint8_t(val[c] >> (8u * i));
+                                if (open[c] & (1u << i)) ring[ringAt(int32_t(p0 + i) - int32_t(sh))] = v;
+                                dst[op - sh + p0 + i] = v;
+                            }
+                        }
+                    }
+                }
+            }
+            rop = ringAt(int32_t(bytes));
+            op += bytes;
+            k += m;
+            LZ4_T(5);
+        }
+    }
+    if ((bad || op != total) && tid == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
+#ifdef SSA_LZ4_STATS
+    if (tid == 0) {
+        for (int i = 0; i < 16; ++i) atomicAdd(&gLz4Stats[i], tacc[i]);
+    }
+#endif
+}
+
 }  // namespace
 
 hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t* status, hipStream_t st) {
@@ -626,7 +988,33 @@ hipError_t LaunchLz4DecodeSplit(const uint8_t* blob, const Lz4FrameTask* tasks, 
     hipLaunchKernelGGL(Lz4ParseKernel, dim3(uint32_t(nblocks)), dim3(64), 0, st, blob, blocks, recStart, recs, summaries, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(Lz4CopyKernel, dim3(uint32_t(ntasks)), dim3(64), 0, st, blob, tasks, blocks, recStart, recs, summaries, status);
+    const char* way = std::getenv("SSA_LZ4_COPY");  // "wave": the copies of a frame by one wave, sequence after sequence
+    if (way && way[0] == 'w') {
+        hipLaunchKernelGGL(Lz4CopyKernel, dim3(uint32_t(ntasks)), dim3(64), 0, st, blob, tasks, blocks, recStart, recs, summaries, status);
+        return hipGetLastError();
+    }
+    static std::atomic<uint64_t> attributeSetOn{0};  // one bit per device
+    int dev = 0;
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!(attributeSetOn.load() >> (dev & 63) & 1u)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&Lz4BatchCopyKernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(kBatchLds));
+        if (e != hipSuccess) return e;
+        attributeSetOn.fetch_or(uint64_t(1) << (dev & 63));
+    }
+    hipLaunchKernelGGL(Lz4BatchCopyKernel, dim3(uint32_t(ntasks)), dim3(kBatchThreads), kBatchLds, st, blob, tasks, blocks, recStart, recs, summaries, status);
+#ifdef SSA_LZ4_STATS
+    {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(gLz4Stats), sizeof(h));
+        std::fprintf(stderr, "lz4 batch copy, %lld frames: record load %.1f, place %.1f, owners %.1f, sources %.1f, jumping %.1f, output %.1f, long %.1f (us per frame); batches %llu, records per batch %.1f, rounds per batch %.2f\n",
+                     (long long)ntasks, h[0] / 100.0 / ntasks, h[1] / 100.0 / ntasks, h[2] / 100.0 / ntasks, h[3] / 100.0 / ntasks, h[4] / 100.0 / ntasks, h[5] / 100.0 / ntasks,
+                     h[7] / 100.0 / ntasks, h[8], double(h[9]) / double(h[8] ? h[8] : 1), double(h[10]) / double(h[8] ? h[8] : 1));
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gLz4Stats), z, sizeof(z));
+    }
+#endif
     return hipGetLastError();
 }
 
