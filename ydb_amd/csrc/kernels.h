@@ -377,7 +377,7 @@ struct Lz4FrameTask {
 // Decodes every frame (one wavefront each) from the blob in device memory (256-byte aligned, 64 bytes of padding
 // behind it).  A frame that does not decode to its announced length raises SCAN_BAD_BLOB in *status.
 hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, uint32_t* status, hipStream_t st);
-// One sequence of a block, as Lz4ParseKernel leaves it for Lz4CopyKernel.
+// One sequence of a block, as Lz4ParseKernel leaves it for Lz4BatchCopyKernel.
 struct Lz4Seq {
     uint32_t lit;    // literal count (low 24 bits) and the flags of lz4_kernels.hip
     uint32_t match;  // match length (low 16 bits; 0: none -- a block's last sequence) and offset (high 16)
@@ -390,8 +390,8 @@ struct Lz4BlockSummary {
     uint32_t ReachesBack;  // how far before the block's own first byte its matches read
     uint32_t pad_;
 };
-// The same decode in two launches: every block parsed by a wave of its own into records (block g's at recs[recStart[g]...],
-// room for SrcBytes / 3 + 2 of them) and a summary, then the copies frame by frame.
+// The same decode in two launches: every block parsed into records (block g's at recs[recStart[g]...], room for
+// SrcBytes / 3 + 2 of them) and a summary, then the copies frame by frame (a workgroup each, batches of records).
 hipError_t LaunchLz4DecodeSplit(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, int64_t nblocks,
                                 const uint64_t* recStart, Lz4Seq* recs, Lz4BlockSummary* summaries, uint32_t* status, hipStream_t st);
 

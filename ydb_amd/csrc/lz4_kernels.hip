@@ -9,11 +9,11 @@
 // the 64 lanes side by side.  The last 64 KB of output live in an LDS ring, which is where matches read from (LDS
 // accesses of one wave complete in issue order, so a match sees the bytes earlier sequences wrote); every byte goes to
 // the ring and to the output buffer in HBM, 64 consecutive bytes per store instruction.
-// Lz4ParseKernel + Lz4CopyKernel (the default, given room for the records): every block is parsed by a wavefront of its
-// own into one record per sequence, then one wavefront per frame walks the records and does the copies as above (with
-// a ring of 32 KB: four frames to a CU; matches that read further back take their bytes from the output).
+// Lz4ParseKernel + Lz4BatchCopyKernel (the default, given room for the records): every block is parsed into one record
+// per sequence, a block per lane; then a workgroup per frame does the copies, a batch of up to 1024 records at a time, with
+// nothing serial inside a batch (the bytes' sources are resolved by pointer jumping) and the frame's last 64 KB in LDS.
 // Parallelism across frames comes from the grid: a blob has up to three buffers per column, a portion many blobs.
-// Bound: the serial chain of a frame's copies (instructions per sequence of one wave), not HBM.
+// Bound: per frame, the chain of batches (a dozen barriers each); across frames, instruction issue -- not HBM.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -291,44 +291,53 @@ __global__ __launch_bounds__(64) void Lz4DecodeKernel(const uint8_t* blob, const
 
 // ---- the same decode split in two: the parse of all blocks side by side, then the copies frame by frame -------------
 // The parse of a block needs nothing but the block (tokens, lengths, offsets); only the copies chain through the frame
-// (a match may read what the previous block wrote).  Lz4ParseKernel gives every block a wave and writes one record per
-// sequence; Lz4CopyKernel walks a frame's records in order and is left with the copies: four v_readlane per sequence
-// instead of the token arithmetic.
+// (a match may read what the previous block wrote).  Lz4ParseKernel turns every block into one record per sequence;
+// Lz4BatchCopyKernel is left with the copies.
 
-constexpr uint32_t kSeqSlow = 0x80000000u;      // Lz4Seq::lit: not the common shape (literals outside the record, or more than 64 bytes in all)
-constexpr uint32_t kSeqExternal = 0x40000000u;  // the literals are not in the record (lo = where they start in the block)
-constexpr uint32_t kSeqOverlap = 0x20000000u;   // the match is longer than its offset: a pattern of `offset` bytes repeated
-constexpr uint32_t kSeqFar = 0x10000000u;       // the match reads further back than the copy kernel's ring reaches: from the output itself
+constexpr uint32_t kSeqExternal = 0x40000000u;  // Lz4Seq::lit: the literals are not in the record (lo = where they start in the block)
 constexpr uint32_t kSeqCount = 0x00FFFFFFu;
-// The copy kernel keeps the last 32 KB of a frame's output in LDS, so that four frames share a CU; the few matches that
-// read further back (an offset has 16 bits) take their bytes from the output in HBM.  kCopyNear: the largest offset the
-// ring serves, whatever the piece of the sequence that is being copied (64 bytes at most at a time).
-constexpr uint32_t kCopyRing = 32768;
-constexpr uint32_t kCopyNear = kCopyRing - 128;
 
-__global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const Lz4BlockRef* blocks, const uint64_t* recStart, Lz4Seq* recs,
+// A block per lane: the token arithmetic is a chain of dependent integer operations with nothing to share between lanes,
+// so sixty-four blocks advance with every instruction (one block per wave left the parse bound by the one scalar unit of
+// a compute unit).  A lane reads its block sixteen bytes at a time from wherever it stands -- its cache lines are its own
+// for a dozen sequences -- and writes its records one by one.
+struct __attribute__((packed, aligned(4))) Lz4Window {
+    uint32_t w[4];
+};
+
+__global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const Lz4BlockRef* blocks, uint32_t nblocks, const uint64_t* recStart, Lz4Seq* recs,
                                                     Lz4BlockSummary* summaries, uint32_t* status) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t g = blockIdx.x;
+    const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+    if (g >= nblocks) return;
     const Lz4BlockRef blk = blocks[g];
     const uint8_t* src = blob + blk.Src;
     const uint32_t n = blk.SrcBytes;
     if (blk.Stored || n == 0) {
-        if (lane == 0) summaries[g] = Lz4BlockSummary{0, 0, 0, 0};
+        summaries[g] = Lz4BlockSummary{0, 0, 0, 0};
         return;
     }
-    Lz4Seq* out = recs + recStart[g];
+    uint4* out = reinterpret_cast<uint4*>(recs + recStart[g]);
     const uint32_t cap = n / 3u + 2u;  // (a sequence with a match takes three bytes at least, the last one at least one)
     uint32_t k = 0;
-    uint32_t produced = 0;  // bytes the block's sequences so far decode to
+    uint32_t produced = 0;     // bytes the block's sequences so far decode to
     uint32_t reachesBack = 0;  // how far before the block's first byte its matches read (0: the block stands alone)
     bool bad = false;
+    // twelve bytes of the block from byte `at` on (the blob has padding behind it: bytes past the block are read, never used)
+    auto fetch = [&](uint32_t at, uint64_t& w0, uint32_t& w1) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(src + at);
+        const Lz4Window x = *reinterpret_cast<const Lz4Window*>(a & ~uintptr_t(3));
+        const uint32_t sh = 8u * uint32_t(a & 3u);
+        const uint32_t b0 = uint32_t((uint64_t(x.w[0]) | (uint64_t(x.w[1]) << 32)) >> sh);
+        const uint32_t b1 = uint32_t((uint64_t(x.w[1]) | (uint64_t(x.w[2]) << 32)) >> sh);
+        w1 = uint32_t((uint64_t(x.w[2]) | (uint64_t(x.w[3]) << 32)) >> sh);
+        w0 = uint64_t(b0) | (uint64_t(b1) << 32);
+    };
     auto emit = [&](uint32_t lit, uint32_t match, uint32_t lo, uint32_t hi) {
         if (k >= cap) {
             bad = true;
             return;
         }
-        if (lane == 0) out[k] = Lz4Seq{lit, match, lo, hi};
+        out[k] = uint4{lit, match, lo, hi};
         ++k;
     };
     // every match: its offset is checked here, against the bytes the block itself has produced, so that the copy kernel
@@ -348,68 +357,22 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
             produced += ml;
         }
     };
-    // (the window over the compressed bytes: as in Lz4DecodeKernel)
-    const uint32_t skew = uint32_t(reinterpret_cast<uintptr_t>(src) & 3u);
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(src - skew);
-    const uint32_t lastWord = (skew + n - 1u) >> 2;
-    auto load = [&](uint32_t first) -> uint32_t {
-        const uint32_t i = first + lane;
-        return words[i < lastWord ? i : lastWord];
-    };
-    uint32_t wbase = 0;
-    uint32_t A = load(0), B = load(64);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    auto rebase = [&](uint32_t d) {
-        const uint32_t s = d - wbase;
-        if (s < 64u) {
-            const uint32_t j = (lane + s) & 63u;
-            const uint32_t a = uint32_t(__shfl(int(A), int(j))), c = uint32_t(__shfl(int(B), int(j)));
-            A = lane + s < 64u ? a : c;
-        } else {
-            A = load(d);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
-        B = load(d + 64u);
-        wbase = d;
-    };
-    auto fetch = [&](uint32_t at, uint64_t& w0, uint32_t& w1) {
-        const uint32_t y = skew + at;
-        uint32_t r = (y >> 2) - wbase;
-        if (r > 60u) {
-            rebase(y >> 2);
-            r = 0;
-        }
-        const uint32_t x0 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r)));
-        const uint32_t x1 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 1u)));
-        const uint32_t x2 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 2u)));
-        const uint32_t x3 = uint32_t(__builtin_amdgcn_readlane(int(A), int(r + 3u)));
-        const uint32_t sh = 8u * (y & 3u);
-        const uint32_t b0 = uint32_t((uint64_t(x0) | (uint64_t(x1) << 32)) >> sh);
-        const uint32_t b1 = uint32_t((uint64_t(x1) | (uint64_t(x2) << 32)) >> sh);
-        w1 = uint32_t((uint64_t(x2) | (uint64_t(x3) << 32)) >> sh);
-        w0 = uint64_t(b0) | (uint64_t(b1) << 32);
-    };
     uint32_t ip = 0;
+    // the bytes of a length that follow a token's 15: adds them to `len`, stops behind the first that is not 255
     auto readLength = [&](uint32_t& len) {
         for (;;) {
             if (ip >= n) {
                 bad = true;
                 return;
             }
-            uint64_t a;
-            uint32_t unused;
-            fetch(ip, a, unused);
-            for (int q = 0; q < 8; ++q) {
-                if (ip >= n) {
-                    bad = true;
-                    return;
-                }
-                const uint32_t x = uint32_t(a) & 0xFFu;
-                a >>= 8;
-                ++ip;
-                len += x;
-                if (x != 255u) return;
+            const uint32_t x = src[ip];
+            ++ip;
+            if (x > 0x7FFFFFFFu - len) {
+                bad = true;
+                return;
             }
+            len += x;
+            if (x != 255u) return;
         }
     };
     while (ip < n && !bad) {
@@ -425,7 +388,7 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
             const uint32_t fm = (token & 15u) + 4u;
             const uint64_t lits = (w0 >> 8) | (uint64_t(w1) << 56);  // bytes 1..8
             account(fl, fm, off);
-            emit(fl | (off < fm ? kSeqOverlap : 0u) | (off > kCopyNear ? kSeqSlow | kSeqFar : 0u), fm | (off << 16), uint32_t(lits), uint32_t(lits >> 32));
+            emit(fl, fm | (off << 16), uint32_t(lits), uint32_t(lits >> 32));
             ip += 3u + fl;
             continue;
         }
@@ -440,184 +403,37 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
         ip += lit;
         if (ip >= n) {  // the last sequence of a block is literals only
             account(lit, 0, 0);
-            emit(lit | kSeqSlow | kSeqExternal, 0, litAt, 0);
+            emit(lit | kSeqExternal, 0, litAt, 0);
             break;
         }
         if (n - ip < 2) {
             bad = true;
             break;
         }
-        fetch(ip, w0, w1);
-        const uint32_t off = uint32_t(w0) & 0xFFFFu;
+        const uint32_t off = uint32_t(src[ip]) | (uint32_t(src[ip + 1]) << 8);
         ip += 2;
         uint32_t ml = token & 15u;
         if (ml == 15u) readLength(ml);
-        if (bad) break;
+        if (bad || ml > 0x7FFFFFF0u) {
+            bad = true;
+            break;
+        }
         ml += 4;
         account(lit, ml, off);
         // (a record's match length has sixteen bits: a longer match is as many records, each reading `off` bytes back)
         uint32_t piece = ml < 65535u ? ml : 65535u;
-        const uint32_t far = off > kCopyNear ? kSeqFar : 0u;
-        emit(lit | kSeqSlow | kSeqExternal | far, piece | (off << 16), litAt, 0);
+        emit(lit | kSeqExternal, piece | (off << 16), litAt, 0);
         for (ml -= piece; ml > 0 && !bad; ml -= piece) {
             piece = ml < 65535u ? ml : 65535u;
-            emit(kSeqSlow | far, piece | (off << 16), 0, 0);
+            emit(0, piece | (off << 16), 0, 0);
         }
     }
-    if (lane == 0) {
-        summaries[g] = bad ? Lz4BlockSummary{0, 0, 0, 0} : Lz4BlockSummary{k, produced, reachesBack, 0};
-        if (bad) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
-    }
+    summaries[g] = bad ? Lz4BlockSummary{0, 0, 0, 0} : Lz4BlockSummary{k, produced, reachesBack, 0};
+    if (bad) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
 }
 
-__global__ __launch_bounds__(64) void Lz4CopyKernel(const uint8_t* blob, const Lz4FrameTask* tasks, const Lz4BlockRef* blocks, const uint64_t* recStart,
-                                                   const Lz4Seq* recs, const Lz4BlockSummary* summaries, uint32_t* status) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kCopyRing];
-    const uint32_t lane = threadIdx.x;
-    const Lz4FrameTask t = tasks[blockIdx.x];
-    __attribute__((address_space(1))) uint8_t* dst = (__attribute__((address_space(1))) uint8_t*)t.dst;
-    const uint32_t total = uint32_t(t.dst_bytes);
-    uint32_t op = 0;
-    bool bad = false;
-    for (uint32_t b = 0; b < t.nblocks && !bad; ++b) {
-        const uint64_t g = t.first_block + b;
-        const Lz4BlockRef blk = blocks[g];
-        const uint8_t* src = blob + blk.Src;
-        const uint32_t n = blk.SrcBytes;
-        if (n == 0) continue;
-        if (blk.Stored) {
-            if (n > total - op) {
-                bad = true;
-                break;
-            }
-            for (uint32_t base = 0; base < n; base += 1024) {
-                uint8_t x[16];
-#pragma unroll
-                for (uint32_t q = 0; q < 16; ++q) {
-                    const uint32_t i = base + q * 64 + lane;
-                    x[q] = i < n ? src[i] : uint8_t(0);
-                }
-#pragma unroll
-                for (uint32_t q = 0; q < 16; ++q) {
-                    const uint32_t i = base + q * 64 + lane;
-                    if (i < n) {
-                        ring[(op + i) & (kCopyRing - 1)] = x[q];
-                        dst[op + i] = x[q];
-                    }
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            op += n;
-            continue;
-        }
-        const Lz4BlockSummary sum = summaries[g];
-        // the parse has checked every sequence against the block itself: what is left is the block against the frame --
-        // its bytes fit, and its matches reach back no further than the frame's bytes before it (none, if blocks stand alone)
-        if (sum.Sequences == 0 || sum.Bytes > total - op || sum.ReachesBack > (t.linked ? op : 0u)) {
-            bad = true;
-            break;
-        }
-        const uint32_t nrec = sum.Sequences;
-        const uint4* rec = reinterpret_cast<const uint4*>(recs + recStart[g]);
-        // sixty-four records at a time, one per lane; the next sixty-four are on their way meanwhile
-        uint4 next = lane < nrec ? rec[lane] : uint4{0, 0, 0, 0};
-        for (uint32_t k0 = 0; k0 < nrec; k0 += 64) {
-            const uint4 cur = next;
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            next = k0 + 64u + lane < nrec ? rec[k0 + 64u + lane] : uint4{0, 0, 0, 0};
-            const uint32_t m = nrec - k0 < 64u ? nrec - k0 : 64u;
-            for (uint32_t j = 0; j < m; ++j) {
-                const uint32_t x0 = uint32_t(__builtin_amdgcn_readlane(int(cur.x), int(j)));
-                const uint32_t x1 = uint32_t(__builtin_amdgcn_readlane(int(cur.y), int(j)));
-                const uint32_t x2 = uint32_t(__builtin_amdgcn_readlane(int(cur.z), int(j)));
-                const uint32_t x3 = uint32_t(__builtin_amdgcn_readlane(int(cur.w), int(j)));
-                const uint32_t lit = x0 & kSeqCount, ml = x1 & 0xFFFFu, off = x1 >> 16;
-                const uint32_t mp = op + lit;  // where the match lands
-                if (!(x0 & kSeqSlow)) {
-                    // At most eight literals and a match of at most 19 bytes, written by one lane each in one step: a literal
-                    // comes out of the record, a match byte out of the ring -- or out of the record too, where the match
-                    // reaches back into the literals of its own sequence.
-                    const uint64_t lits = uint64_t(x2) | (uint64_t(x3) << 32);
-                    const uint32_t mi = lane - lit;
-                    uint32_t r = mi;
-                    if (x0 & kSeqOverlap) {  // mi mod off (mi < 19: the rounded quotient is exact)
-                        r = mi - __umul24(uint32_t((float(int(mi)) + 0.5f) * __builtin_amdgcn_rcpf(float(off))), off);
-                    }
-                    const uint32_t back = off - r;  // bytes before the match's start
-                    const bool literal = lane < lit || back <= lit;
-                    const uint32_t li = lane < lit ? lane : lit - back;
-                    const uint8_t fromWords = uint8_t(lits >> (8u * (li & 7u)));
-                    const uint8_t fromRing = ring[(mp - back) & (kCopyRing - 1)];
-                    if (lane < lit + ml) {
-                        const uint8_t x = literal ? fromWords : fromRing;
-                        ring[(op + lane) & (kCopyRing - 1)] = x;
-                        dst[op + lane] = x;
-                    }
-                    op = mp + ml;
-                    continue;
-                }
-                if (x0 & kSeqExternal) {
-                    for (uint32_t base = 0; base < lit; base += 64) {
-                        const uint32_t i = base + lane;
-                        const uint8_t x = i < lit ? src[x2 + i] : uint8_t(0);
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        if (i < lit) {
-                            ring[(op + i) & (kCopyRing - 1)] = x;
-                            dst[op + i] = x;
-                        }
-                    }
-                } else if (lane < lit) {  // (at most eight, in the record)
-                    const uint8_t x = uint8_t((uint64_t(x2) | (uint64_t(x3) << 32)) >> (8u * lane));
-                    ring[(op + lane) & (kCopyRing - 1)] = x;
-                    dst[op + lane] = x;
-                }
-                op = mp;
-                if (x0 & kSeqFar) {
-                    // further back than the ring reaches: the bytes are in the output, written at least 32 KB ago -- their
-                    // cache lines were complete before anything read them, the stores before this read are waited for
-                    for (uint32_t base = 0; base < ml; base += 64) {
-                        const uint32_t i = base + lane;
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        const uint8_t x = i < ml ? dst[op + i - off] : uint8_t(0);
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        if (i < ml) {
-                            ring[(op + i) & (kCopyRing - 1)] = x;
-                            dst[op + i] = x;
-                        }
-                    }
-                } else if (off >= 64) {
-                    for (uint32_t base = 0; base < ml; base += 64) {
-                        const uint32_t i = base + lane;
-                        if (i < ml) {
-                            const uint8_t x = ring[(op + i - off) & (kCopyRing - 1)];
-                            ring[(op + i) & (kCopyRing - 1)] = x;
-                            dst[op + i] = x;
-                        }
-                    }
-                } else if (ml != 0) {
-                    // The match overlaps its own output: a pattern of `off` bytes repeated.  The first 128 bytes are taken
-                    // from the pattern before the match; further on (a match may be longer than the ring, which by then
-                    // no longer holds those bytes) from the match's own output, a whole number of periods back.
-                    const uint32_t periods = off * ((63u + off) / off);  // the least multiple of off that is 64 or more
-                    for (uint32_t base = 0; base < ml; base += 64) {
-                        const uint32_t i = base + lane;
-                        if (i < ml) {
-                            const uint32_t from = i < 128u ? op - off + (i % off) : op + i - periods;
-                            const uint8_t x = ring[from & (kCopyRing - 1)];
-                            ring[(op + i) & (kCopyRing - 1)] = x;
-                            dst[op + i] = x;
-                        }
-                    }
-                }
-                op += ml;
-            }
-        }
-    }
-    if ((bad || op != total) && lane == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
-}
-
-// ---- the copies of a frame, 256 sequences at a time ---------------------------------------------------------------
-// Lz4BatchCopyKernel: a workgroup per frame takes the records of a block in batches of up to 256 sequences / 2 KB of
+// ---- the copies of a frame, 1024 sequences at a time --------------------------------------------------------------
+// Lz4BatchCopyKernel: a workgroup per frame takes the records of a block in batches of up to 1024 sequences / 8 KB of
 // output.  Inside a batch nothing is serial: a prefix sum of the records' lengths places every sequence, every output
 // byte finds its sequence (the records' first bytes are marked, a running maximum carries the owner along) and its
 // source -- a literal, a byte in front of the batch (in the ring, final), or an earlier byte of the batch.  Chains of
@@ -985,14 +801,9 @@ hipError_t LaunchLz4Decode(const uint8_t* blob, const Lz4FrameTask* tasks, int64
 hipError_t LaunchLz4DecodeSplit(const uint8_t* blob, const Lz4FrameTask* tasks, int64_t ntasks, const Lz4BlockRef* blocks, int64_t nblocks,
                                 const uint64_t* recStart, Lz4Seq* recs, Lz4BlockSummary* summaries, uint32_t* status, hipStream_t st) {
     if (ntasks <= 0 || nblocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(Lz4ParseKernel, dim3(uint32_t(nblocks)), dim3(64), 0, st, blob, blocks, recStart, recs, summaries, status);
+    hipLaunchKernelGGL(Lz4ParseKernel, dim3(uint32_t((nblocks + 63) / 64)), dim3(64), 0, st, blob, blocks, uint32_t(nblocks), recStart, recs, summaries, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const char* way = std::getenv("SSA_LZ4_COPY");  // "wave": the copies of a frame by one wave, sequence after sequence
-    if (way && way[0] == 'w') {
-        hipLaunchKernelGGL(Lz4CopyKernel, dim3(uint32_t(ntasks)), dim3(64), 0, st, blob, tasks, blocks, recStart, recs, summaries, status);
-        return hipGetLastError();
-    }
     static std::atomic<uint64_t> attributeSetOn{0};  // one bit per device
     int dev = 0;
     e = hipGetDevice(&dev);
