@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
 // together, a match among them in pieces that read what the pieces before wrote.
 #ifdef SSA_LZ4_STATS
 __device__ unsigned long long gLz4Stats[16];
-#define LZ4_T(i) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
+#define LZ4_T(i) do { if (tid == 0) { const uint32_t now_ = uint32_t(wall_clock64()); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
 #define LZ4_C(i, v) do { if (tid == 0) tacc[i] += (v); } while (0)
 #else
 #define LZ4_T(i) do {} while (0)
@@ -490,8 +490,8 @@ __global__ __launch_bounds__(kBatchThreads) void Lz4BatchCopyKernel(const uint8_
     uint32_t rop = 0;  // op's place in the ring (op mod kBatchRing)
     bool bad = false;
 #ifdef SSA_LZ4_STATS
-    unsigned long long tacc[16] = {0};
-    unsigned long long tlast = wall_clock64();
+    uint32_t tacc[11] = {0};
+    uint32_t tlast = uint32_t(wall_clock64());
 #endif
     // the place in the ring of the byte `rel` bytes from op (|rel| below the ring's size)
     auto ringAt = [&](int32_t rel) -> uint32_t {
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(kBatchThreads) void Lz4BatchCopyKernel(const uint8_
     if ((bad || op != total) && tid == 0) atomicOr(status, uint32_t(SCAN_BAD_BLOB));
 #ifdef SSA_LZ4_STATS
     if (tid == 0) {
-        for (int i = 0; i < 16; ++i) atomicAdd(&gLz4Stats[i], tacc[i]);
+        for (int i = 0; i < 11; ++i) atomicAdd(&gLz4Stats[i], (unsigned long long)tacc[i]);
     }
 #endif
 }
