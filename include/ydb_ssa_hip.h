@@ -189,6 +189,27 @@ int ssa_batch_from_device(const struct ssa_device_column* cols, size_t ncols, in
  * used them as values. */
 void ssa_dictionary_stats(int64_t* steps_on_codes, int64_t* columns_decoded);
 
+/*
+ * Operator-level seam.  Replaces the Arrow registry function "ch.group_by" (CH::ArrowGroupBy,
+ * ydb/library/arrow_clickhouse/AggregateFunctions/AggregateFunctionWrapper.h:100-255, registered at
+ * ydb/core/formats/arrow/custom_registry.cpp:65-82, called by TProgramStep::ApplyAggregates,
+ * ydb/core/formats/arrow/program.cpp:722-750) for callers that hold a CH::GroupByOptions rather than a program:
+ * `assigns` is GroupByOptions::assigns (IAggregateFunction.h:498-511) -- aggregates and keys in the order the result is
+ * to have; `function` is CH::AggFunctionId (IAggregateFunction.h:478-485): 0 marks a key named by `result_column`, 1 any,
+ * 2 count, 3 min, 4 max, 5 sum; `argument` is the aggregate's one argument column (NULL: count of rows).  Anything else
+ * (avg and the ids the reference leaves commented out) is "Unexpected agregate function in GROUP BY".  The handle is a
+ * program of one aggregation like any other: apply it with ssa_program_apply / ssa_program_apply_device /
+ * ssa_program_apply_many to the datums' batch (GroupByOptions::schema is the batch's own; has_nullable_key is read off
+ * the key columns, as ApplyAggregates does), destroy it with ssa_program_destroy.  Kernels built for it stay with the
+ * handle, so keep it for as long as the same aggregation comes back.
+ */
+struct ssa_group_by_assign {
+    int32_t function;
+    const char* result_column;
+    const char* argument;
+};
+int ssa_group_by_create(const struct ssa_group_by_assign* assigns, size_t n_assigns, int device, ssa_program_t** out, char** err);
+
 /* TProgram::ApplyTo on an HBM-resident batch; the result stays in HBM. */
 int ssa_program_apply_device(ssa_program_t* program, const ssa_batch_t* in, ssa_batch_t** out, char** err);
 /* TProgram::ApplyTo on each of `n` HBM-resident batches -- the slices of a table, which the reference runs one by one

@@ -190,3 +190,19 @@ def test_mutated_program_bytes_never_crash_the_parsers():
                     pass
                 tried += 1
     assert tried >= 2000
+
+
+def test_group_by_seam_builds_a_program_of_one_aggregation():
+    """ssa_group_by_create (CH::GroupByOptions): what it accepts, what it refuses and the program it makes."""
+    from ydb_amd.program import ProgramContainer
+    pc = ProgramContainer()
+    ok, err = pc.InitGroupBy([(5, "total", "v"), (0, "k", None)])
+    assert ok, err
+    assert pc.StepCount() == 1
+    assert sorted(pc.GetSourceColumns()) == ["k", "v"]
+    ok, err = pc.InitGroupBy([(0, "k", None), (5, "total", "v")])  # keys first: a projection puts the result in that order
+    assert ok and pc.StepCount() == 2
+    for bad, text in (([(6, "avg", "v"), (0, "k", None)], "Unexpected agregate function"), ([(5, "t", None), (0, "k", None)], "argument"),
+                      ([(0, "k", None)], "without aggregates"), ([], "without options"), ([(5, "k", "v"), (0, "k", None)], "twice")):
+        ok, err = pc.InitGroupBy(bad)
+        assert not ok and text in err, (bad, err)

@@ -40,7 +40,7 @@ class LineitemColumns(ctypes.Structure):
 
 # Every symbol include/ydb_ssa_hip.h declares.
 EXPORTED_SYMBOLS = [
-    "ssa_device_count", "ssa_version", "ssa_shutdown", "ssa_free_string", "ssa_program_create", "ssa_program_create_with_kernels", "ssa_program_destroy",
+    "ssa_device_count", "ssa_version", "ssa_shutdown", "ssa_free_string", "ssa_program_create", "ssa_program_create_with_kernels", "ssa_group_by_create", "ssa_program_destroy",
     "ssa_program_debug_string", "ssa_program_source_columns", "ssa_program_early_filter_columns",
     "ssa_program_step_count", "ssa_program_explain", "ssa_program_apply", "ssa_program_build_filter", "ssa_batch_import",
     "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_program_apply_many", "ssa_apply_many_stats", "ssa_keyed_stats", "ssa_keyed_compact_stats",
@@ -59,6 +59,11 @@ BENCH_EXPORTED_SYMBOLS = ["ssa_gen_lineitem"]
 
 _lib = None
 _bench = None
+
+
+class GroupByAssign(ctypes.Structure):
+    """struct ssa_group_by_assign (CH::GroupByOptions::Assign)."""
+    _fields_ = [("function", ctypes.c_int32), ("result_column", ctypes.c_char_p), ("argument", ctypes.c_char_p)]
 
 
 def load_bench() -> ctypes.CDLL:
@@ -105,6 +110,8 @@ def load() -> ctypes.CDLL:
     lib.ssa_program_create_with_kernels.argtypes = [vp, sz, i32, P(ctypes.c_uint32), P(cp), sz, P(ArrowArray), P(ArrowSchema),
                                                     P(ctypes.c_uint32), sz, i32, P(vp), P(vp)]
     lib.ssa_program_create_with_kernels.restype = i32
+    lib.ssa_group_by_create.argtypes = [P(GroupByAssign), sz, i32, P(vp), P(vp)]
+    lib.ssa_group_by_create.restype = i32
     lib.ssa_program_destroy.argtypes = [vp]
     for f in (lib.ssa_program_debug_string, lib.ssa_program_source_columns, lib.ssa_program_early_filter_columns):
         f.argtypes = [vp]

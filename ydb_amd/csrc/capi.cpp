@@ -176,6 +176,67 @@ int ssa_program_create_with_kernels(const uint8_t* program, size_t program_size,
     return SSA_OK;
 }
 
+// CH::ArrowGroupBy (AggregateFunctionWrapper.h:100-255) as a program of one step: the aggregates and the keys of the
+// options, and -- when the result is to have another order than a GroupBy command's (aggregates, then keys) -- a
+// projection behind it.
+int ssa_group_by_create(const ssa_group_by_assign* assigns, size_t n_assigns, int device, ssa_program_t** out, char** err) {
+    if (err) *err = nullptr;
+    if (!out) return SSA_INVALID;
+    *out = nullptr;
+    if (!assigns || n_assigns == 0) return Fail(Status{ST_INVALID, "GROUP BY without options"}, err);
+    auto program = std::make_shared<TProgram>();
+    auto step = std::make_shared<TProgramStep>();
+    auto source = [&](const std::string& name) {
+        for (auto& kv : program->SourceColumns) {
+            if (kv.second.ColumnName == name) return kv.second;
+        }
+        const uint32_t id = uint32_t(program->SourceColumns.size()) + 1u;
+        program->SourceColumns.emplace_back(id, TColumnInfo::Original(id, name));
+        return program->SourceColumns.back().second;
+    };
+    std::vector<TColumnInfo> order;  // the result's columns as the caller listed them
+    std::set<std::string> results;
+    size_t naggs = 0;
+    for (size_t i = 0; i < n_assigns; ++i) {
+        const ssa_group_by_assign& a = assigns[i];
+        if (!a.result_column || !a.result_column[0]) return Fail(Status{ST_INVALID, "GROUP BY: assign without a result column"}, err);
+        if (!results.insert(a.result_column).second) return Fail(Status{ST_INVALID, std::string("GROUP BY: column '") + a.result_column + "' assigned twice"}, err);
+        if (a.function == 0) {
+            step->GroupByKeys.push_back(source(a.result_column));
+            order.push_back(step->GroupByKeys.back());
+            continue;
+        }
+        if (a.function < int32_t(EAggregate::Some) || a.function > int32_t(EAggregate::Sum)) {
+            return Fail(Status{ST_INVALID, "Unexpected agregate function in GROUP BY"}, err);
+        }
+        TAggregateAssign g;
+        g.Column = TColumnInfo::Generated(10000u + uint32_t(i), a.result_column);
+        g.Operation = EAggregate(a.function);
+        if (a.argument && a.argument[0]) g.Arguments.push_back(source(a.argument));
+        else if (g.Operation != EAggregate::Count) return Fail(Status{ST_INVALID, "Unexpected aggregate function argument in GROUP BY"}, err);
+        step->GroupBy.push_back(g);
+        order.push_back(g.Column);
+        ++naggs;
+    }
+    if (naggs == 0) return Fail(Status{ST_UNSUPPORTED, "GROUP BY without aggregates (the keys' distinct values)"}, err);
+    program->Steps.push_back(step);
+    bool natural = true;  // aggregates first, keys behind them: what the step produces
+    for (size_t i = 0; i < n_assigns; ++i) natural = natural && ((assigns[i].function != 0) == (i < naggs));
+    if (!natural) {
+        auto projection = std::make_shared<TProgramStep>();
+        projection->Projection = order;
+        program->Steps.push_back(projection);
+    }
+    if (program->SourceColumns.empty()) {  // count of rows and nothing else: any column of the batch will do
+        return Fail(Status{ST_UNSUPPORTED, "GROUP BY that reads no column"}, err);
+    }
+    auto p = std::make_unique<ssa_program>();
+    p->Container.Adopt(program);
+    p->Device = device;
+    *out = p.release();
+    return SSA_OK;
+}
+
 void ssa_program_destroy(ssa_program_t* program) { delete program; }
 
 char* ssa_program_debug_string(const ssa_program_t* program) {

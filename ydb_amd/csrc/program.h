@@ -199,6 +199,8 @@ public:
     bool Init(const IColumnResolver& columnResolver, const uint8_t* serialized, size_t size, bool olapWrapper,
               const TParameters& parameters, std::string& error, bool directOperations = false,
               const std::vector<uint32_t>* kernelOps = nullptr);
+    // A program built from objects (the operator-level seams), not parsed.
+    void Adopt(std::shared_ptr<TProgram> program) { Program = std::move(program); }
     bool HasProgram() const { return !!Program; }
     const std::shared_ptr<TProgram>& GetProgram() const { return Program; }
 

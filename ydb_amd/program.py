@@ -100,6 +100,29 @@ class ProgramContainer:
         self._h = out.value
         return True, ""
 
+    # -- CH::GroupByOptions ("ch.group_by") ------------------------------------------------------------
+    def InitGroupBy(self, assigns: Sequence[Tuple[int, str, Optional[str]]]) -> Tuple[bool, str]:
+        """`assigns`: (CH::AggFunctionId, result column, argument column or None) in the order of the result; function 0
+        marks a key (ssa_group_by_create)."""
+        arr = (_lib.GroupByAssign * max(1, len(assigns)))()
+        keep = []
+        for i, (fn, res, arg) in enumerate(assigns):
+            keep.append((res.encode(), arg.encode() if arg is not None else None))
+            arr[i].function = fn
+            arr[i].result_column = keep[-1][0]
+            arr[i].argument = keep[-1][1]
+        out = ctypes.c_void_p()
+        err = ctypes.c_void_p()
+        rc = self._lib.ssa_group_by_create(arr, len(assigns), self._device, ctypes.byref(out), ctypes.byref(err))
+        msg = _lib.take_string(self._lib, err.value)
+        if rc != _lib.SSA_OK:
+            if rc == _lib.SSA_HIP_ERROR:
+                raise SsaError(rc, msg)
+            return False, msg
+        self.close()
+        self._h = out.value
+        return True, ""
+
     def HasProgram(self) -> bool:
         return self._h is not None
 
