@@ -299,15 +299,23 @@ Status Executor::ImportBlobsQueued(const std::vector<std::pair<const uint8_t*, s
         SSA_HIP(hipStreamSynchronize(StreamHandle));
     }
     mark("decode");
-    // RecordBatch::Validate of the reference: offsets of a string column must describe its data buffer
-    for (const StringCheck& sc : strings) {
-        const Column& col = *sc.Col;
-        if (col.Length == 0) continue;
-        int32_t ends[2] = {0, 0};
-        SSA_HIP(hipMemcpyAsync(&ends[0], col.Values->Ptr, 4, hipMemcpyDeviceToHost, StreamHandle));
-        SSA_HIP(hipMemcpyAsync(&ends[1], static_cast<const int32_t*>(col.Values->Ptr) + col.Length, 4, hipMemcpyDeviceToHost, StreamHandle));
+    // RecordBatch::Validate of the reference: offsets of a string column must describe its data buffer.  The first and
+    // the last offset of every string column, all copies queued before the one wait.
+    {
+        std::vector<int32_t> ends(2 * strings.size(), 0);
+        for (size_t i = 0; i < strings.size(); ++i) {
+            const Column& col = *strings[i].Col;
+            if (col.Length == 0) continue;
+            SSA_HIP(hipMemcpyAsync(&ends[2 * i], col.Values->Ptr, 4, hipMemcpyDeviceToHost, StreamHandle));
+            SSA_HIP(hipMemcpyAsync(&ends[2 * i + 1], static_cast<const int32_t*>(col.Values->Ptr) + col.Length, 4, hipMemcpyDeviceToHost, StreamHandle));
+        }
         SSA_HIP(hipStreamSynchronize(StreamHandle));
-        if (ends[0] < 0 || ends[1] < ends[0] || int64_t(ends[1]) > sc.Bytes) return Status::Invalid("validation error: string offsets run past the data buffer");
+        for (size_t i = 0; i < strings.size(); ++i) {
+            if (strings[i].Col->Length == 0) continue;
+            if (ends[2 * i] < 0 || ends[2 * i + 1] < ends[2 * i] || int64_t(ends[2 * i + 1]) > strings[i].Bytes) {
+                return Status::Invalid("validation error: string offsets run past the data buffer");
+            }
+        }
     }
     mark("validation");
     out = batches;
