@@ -121,6 +121,27 @@ def test_lz4_blocks_of_every_shape(rows, seed, split, monkeypatch):
             assert np.array_equal(np.asarray(got[name]["values"]), np.asarray(exp[name]["values"])), name
 
 
+def test_an_import_of_tens_of_megabytes_goes_through_the_pinned_slots():
+    """Blobs of 16 MB and more in all reach the device through slots of pinned memory filled by several threads: the
+    pieces cut the blobs wherever a slot ends."""
+    from oracle import ipc_oracle
+    schema = [("mixed", "int64"), ("text", "binary"), ("zeros", "int64"), ("sparse", "int32")]
+    distinct = [shapes_blob(700_000, 80), shapes_blob(650_001, 81), shapes_blob(300_000, 82)]
+    blobs = [distinct[i % 3] for i in range(7)]
+    assert sum(len(b) for b in blobs) > (24 << 20)
+    pc = container(schema)
+    devs = pc.ImportBlobs(blobs)
+    expected = [ipc_oracle.read_blob(b, None) for b in distinct]
+    for i, dev in enumerate(devs):
+        got = as_columns(pc.Export(dev))
+        exp = expected[i % 3]
+        for name, typ in schema:
+            if typ == "binary":
+                assert got[name]["chars"] == bytes(exp[name]["chars"][exp[name]["offsets"][0]:exp[name]["offsets"][-1]]), (i, name)
+            else:
+                assert np.array_equal(np.asarray(got[name]["values"]), np.asarray(exp[name]["values"])), (i, name)
+
+
 @pytest.mark.parametrize("split", ["1", "0"], ids=["parse_and_copy_apart", "one_wave_does_both"])
 def test_zstd_is_declined_and_damage_is_an_error(split, monkeypatch):
     from ydb_amd import _lib

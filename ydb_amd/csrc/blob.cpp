@@ -6,11 +6,15 @@
 // reference's default, native.h:54-57); ZSTD is declined with SSA_UNSUPPORTED.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 #include "exec.h"
 #include "ipc.h"
@@ -45,6 +49,88 @@ struct PendingBuffer {
 };
 
 }  // namespace
+
+bool Executor::EnsureBlobStaging() {
+    if (BlobStaging) return true;
+    void* pinned = nullptr;
+    if (hipHostMalloc(&pinned, kBlobSlots * kBlobSlotBytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    for (hipEvent_t& e : BlobSlotDone) {
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(pinned);
+            return false;
+        }
+    }
+    BlobStaging = static_cast<uint8_t*>(pinned);
+    return true;
+}
+
+// The device copy of the blobs is cut into pieces of a slot's size; a piece is put together in a slot (the parts of the
+// blobs that fall into it, at the places they have on the device) and sent by one DMA copy.  Threads take the pieces in
+// order; a slot is written again when the copy that last left it has completed.
+Status Executor::UploadBlobs(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<size_t>& base, size_t total,
+                             char* deviceBase, bool& done) {
+    done = false;
+    if (total < 2 * kBlobSlotBytes || !EnsureBlobStaging()) return Status::OK();
+    const size_t npieces = (total + kBlobSlotBytes - 1) / kBlobSlotBytes;
+    const int nthreads = int(std::min<size_t>(4, npieces));
+    std::atomic<size_t> next{0};
+    std::atomic<int64_t> queued[kBlobSlots];  // the last piece whose copy out of the slot is queued, its event recorded
+    for (auto& q : queued) q.store(-1);
+    std::atomic<int> failed{0};
+    std::mutex errLock;
+    std::string errText;
+    auto fail = [&](hipError_t e, const char* what) {
+        std::lock_guard<std::mutex> g(errLock);
+        if (!failed.exchange(1)) errText = std::string(what) + ": " + hipGetErrorString(e);
+    };
+    auto work = [&]() {
+        (void)hipSetDevice(Device);
+        size_t first = 0;  // the first blob that may reach into the piece (pieces come in rising order per thread)
+        for (;;) {
+            const size_t piece = next.fetch_add(1);
+            if (piece >= npieces) return;
+            const int slot = int(piece % kBlobSlots);
+            const int64_t before = int64_t(piece) - kBlobSlots;
+            while (queued[slot].load(std::memory_order_acquire) != (before >= 0 ? before : -1)) {
+                if (failed.load()) return;
+                std::this_thread::yield();
+            }
+            if (before >= 0) {
+                const hipError_t e = hipEventSynchronize(BlobSlotDone[slot]);
+                if (e != hipSuccess) {
+                    fail(e, "hipEventSynchronize");
+                    queued[slot].store(int64_t(piece), std::memory_order_release);
+                    return;
+                }
+            }
+            const size_t lo = piece * kBlobSlotBytes, hi = std::min(total, lo + kBlobSlotBytes);
+            uint8_t* at = BlobStaging + size_t(slot) * kBlobSlotBytes;
+            while (first + 1 < blobs.size() && base[first + 1] <= lo) ++first;
+            for (size_t i = first; i < blobs.size() && base[i] < hi; ++i) {
+                const size_t b0 = std::max(lo, base[i]), b1 = std::min(hi, base[i] + blobs[i].second);
+                if (b0 < b1) std::memcpy(at + (b0 - lo), blobs[i].first + (b0 - base[i]), b1 - b0);
+            }
+            hipError_t e = failed.load() ? hipSuccess : hipMemcpyAsync(deviceBase + lo, at, hi - lo, hipMemcpyHostToDevice, StreamHandle);
+            if (e == hipSuccess) e = hipEventRecord(BlobSlotDone[slot], StreamHandle);
+            if (e != hipSuccess) fail(e, "hipMemcpyAsync");
+            queued[slot].store(int64_t(piece), std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < nthreads; ++t) threads.emplace_back(work);
+    work();
+    for (auto& t : threads) t.join();
+    if (failed.load()) {
+        (void)hipGetLastError();
+        return Status::Hip(errText);
+    }
+    done = true;
+    return Status::OK();
+}
 
 Status Executor::ImportBlobs(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<FieldDesc>& schema,
                              std::vector<BatchPtr>& out) {
@@ -95,7 +181,9 @@ Status Executor::ImportBlobsQueued(const std::vector<std::pair<const uint8_t*, s
     // the blobs as stored, one copy each over PCIe
     BufferPtr dblob = Buffer::Alloc(total + 256);
     if (!dblob) return Status::Hip("out of device memory");
-    for (size_t i = 0; i < nb; ++i) {
+    bool uploaded = false;
+    SSA_RETURN_NOT_OK(UploadBlobs(blobs, base, total, static_cast<char*>(dblob->Ptr), uploaded));
+    for (size_t i = 0; i < nb && !uploaded; ++i) {
         if (blobs[i].second) {
             SSA_HIP(hipMemcpyAsync(static_cast<char*>(dblob->Ptr) + base[i], blobs[i].first, blobs[i].second, hipMemcpyHostToDevice, StreamHandle));
         }

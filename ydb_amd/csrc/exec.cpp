@@ -222,6 +222,10 @@ Executor::~Executor() {
     if (StreamHandle) (void)hipStreamDestroy(StreamHandle);
     if (HostWords) (void)hipHostFree(HostWords);
     if (HostStaging) (void)hipHostFree(HostStaging);
+    if (BlobStaging) {
+        (void)hipHostFree(BlobStaging);
+        for (hipEvent_t e : BlobSlotDone) (void)hipEventDestroy(e);
+    }
 }
 
 bool Executor::EnsureHostStaging() {

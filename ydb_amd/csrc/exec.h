@@ -177,6 +177,16 @@ public:
     uint8_t* HostStaging = nullptr;  // pinned, kHostStagingBytes, allocated at the first PackToHost
     static constexpr size_t kHostStagingBytes = size_t(1) << 20;
     bool EnsureHostStaging();  // false: no pinned memory to be had
+    // Stored blobs on their way to the device: pageable host memory is copied by a few threads into slots of pinned
+    // memory and leaves them by DMA (one thread's memcpy, which is what a pageable hipMemcpy is, feeds half the link).
+    static constexpr size_t kBlobSlotBytes = size_t(8) << 20;
+    static constexpr int kBlobSlots = 6;
+    uint8_t* BlobStaging = nullptr;  // pinned, kBlobSlots * kBlobSlotBytes, allocated at the first large import
+    hipEvent_t BlobSlotDone[kBlobSlots] = {};
+    bool EnsureBlobStaging();
+    // Copies the blobs to deviceBase + base[i]; false: no pinned memory, nothing queued.
+    Status UploadBlobs(const std::vector<std::pair<const uint8_t*, size_t>>& blobs, const std::vector<size_t>& base, size_t total, char* deviceBase,
+                       bool& done);
     explicit Executor(int device);
     ~Executor();
 
