@@ -2753,7 +2753,102 @@ Status Executor::PlanFor(const TProgramStep& step, const Batch& in, bool stable,
     return Status::OK();
 }
 
+namespace {
+
+// Refusals that say a step is too wide for one scan, not that it cannot run.
+bool IsWidthLimit(const Status& st) {
+    return st.Code == ST_UNSUPPORTED && (st.Msg.find("too many") != std::string::npos || st.Msg.find("more output columns than") != std::string::npos);
+}
+
+// `step` as `parts` steps: part p keeps the assigns its share of the aggregates (key-less aggregations) or of the
+// projected columns needs, and every filter.  An assign nothing reads stays with the first part (the reference evaluates
+// it, and its errors are the program's).  False: a step of this kind is not split (keyed aggregations: the parts'
+// groups would have to be matched up again).
+bool SplitStep(const TProgramStep& step, size_t parts, std::vector<std::shared_ptr<TProgramStep>>& out) {
+    out.clear();
+    if (!step.GroupByKeys.empty()) return false;
+    const bool aggregates = !step.GroupBy.empty();
+    if (aggregates && !step.Projection.empty()) return false;
+    const size_t n = aggregates ? step.GroupBy.size() : step.Projection.size();
+    if (n < 2 || parts > n) return false;
+    std::vector<std::set<std::string>> needs(parts);
+    std::vector<char> read(step.Assignes.size(), 0);
+    for (size_t p = 0; p < parts; ++p) {
+        auto part = std::make_shared<TProgramStep>();
+        part->Filters = step.Filters;
+        part->FilterOriginalColumnIds = step.FilterOriginalColumnIds;
+        std::set<std::string>& need = needs[p];
+        for (const TColumnInfo& f : step.Filters) need.insert(f.ColumnName);
+        for (size_t i = p * n / parts; i < (p + 1) * n / parts; ++i) {
+            if (aggregates) {
+                part->GroupBy.push_back(step.GroupBy[i]);
+                for (const TColumnInfo& a : step.GroupBy[i].Arguments) need.insert(a.ColumnName);
+            } else {
+                part->Projection.push_back(step.Projection[i]);
+                need.insert(step.Projection[i].ColumnName);
+            }
+        }
+        for (size_t i = step.Assignes.size(); i-- > 0;) {
+            if (!need.count(step.Assignes[i].Column.ColumnName)) continue;
+            read[i] = 1;
+            for (const TColumnInfo& a : step.Assignes[i].Arguments) need.insert(a.ColumnName);
+        }
+        out.push_back(part);
+    }
+    // (the assigns nothing reads and what they read in turn: with the first part)
+    for (size_t i = step.Assignes.size(); i-- > 0;) {
+        if (read[i]) continue;
+        needs[0].insert(step.Assignes[i].Column.ColumnName);
+        for (const TColumnInfo& a : step.Assignes[i].Arguments) needs[0].insert(a.ColumnName);
+    }
+    for (size_t p = 0; p < parts; ++p) {
+        for (const TAssign& a : step.Assignes) {
+            if (needs[p].count(a.Column.ColumnName)) out[p]->Assignes.push_back(a);
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+Status Executor::ApplySplit(const std::vector<std::shared_ptr<TProgramStep>>& parts, const BatchPtr& in, BatchPtr& out) {
+    auto whole = std::make_shared<Batch>();
+    for (size_t p = 0; p < parts.size(); ++p) {
+        BatchPtr piece;
+        SSA_RETURN_NOT_OK(ApplyStepWhole(*parts[p], in, piece, /*stable=*/true));
+        if (p == 0) whole->Rows = piece->Rows;
+        if (piece->Rows != whole->Rows) return Status::Invalid("internal: the parts of a split step disagree about the rows");
+        for (const Column& c : piece->Cols) whole->Cols.push_back(c);  // (a piece may be the input itself: its columns are shared, not taken)
+    }
+    out = whole;
+    return Status::OK();
+}
+
 Status Executor::ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable) {
+    if (stable) {
+        auto it = SplitSteps.find(&step);
+        if (it != SplitSteps.end()) return ApplySplit(it->second, in, out);
+    }
+    const Status st = ApplyStepWhole(step, in, out, stable);
+    if (!stable || !IsWidthLimit(st)) return st;
+    for (size_t parts = 2; parts <= 64; parts *= 2) {
+        std::vector<std::shared_ptr<TProgramStep>> pieces;
+        if (!SplitStep(step, parts, pieces)) break;
+        const Status sp = ApplySplit(pieces, in, out);
+        if (sp.ok()) {
+            if (std::getenv("SSA_DEBUG_PLAN")) std::fprintf(stderr, "step: too wide for one scan (%s), run as %zu scans\n", st.Msg.c_str(), parts);
+            SplitSteps[&step] = std::move(pieces);
+            return sp;
+        }
+        // (plans are kept by step address: the steps of an attempt that was given up are never freed, so that no later
+        // step takes their addresses and their plans)
+        RetiredSteps.insert(RetiredSteps.end(), pieces.begin(), pieces.end());
+        if (!IsWidthLimit(sp)) return sp;
+    }
+    return st;
+}
+
+Status Executor::ApplyStepWhole(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable) {
     std::shared_ptr<const StepPlan> kept;
     SSA_RETURN_NOT_OK(PlanFor(step, *in, stable, kept));
     StableStep = stable;

@@ -267,6 +267,13 @@ private:
     // `stable`: `step` is one of the program's own steps (it lives as long as the executor does and never changes), so
     // its plan for this input schema may be kept (PlanCache) -- planning is a tenth of an apply of a shard-sized batch.
     Status ApplyStepPlain(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable = false);
+    Status ApplyStepWhole(const TProgramStep& step, const BatchPtr& in, BatchPtr& out, bool stable);
+    // A step too wide for one scan (more aggregates, computed outputs, temporaries, source columns or constants than the
+    // kernels hold): the key-less aggregates, or the projected columns, are dealt out over several steps of the same
+    // assigns and filters, each run as a scan of its own, and their results put side by side.  Kept per step.
+    std::map<const TProgramStep*, std::vector<std::shared_ptr<TProgramStep>>> SplitSteps;
+    std::vector<std::shared_ptr<TProgramStep>> RetiredSteps;
+    Status ApplySplit(const std::vector<std::shared_ptr<TProgramStep>>& parts, const BatchPtr& in, BatchPtr& out);
     std::map<std::string, std::shared_ptr<const StepPlan>> PlanCache;  // (step address, input schema) -> plan
     Status PlanFor(const TProgramStep& step, const Batch& in, bool stable, std::shared_ptr<const StepPlan>& kept);
     bool StableStep = false;  // the step being run is one of the program's own (plans made for it may be kept)
