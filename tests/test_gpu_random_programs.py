@@ -1,5 +1,7 @@
 """Randomly generated step programs, GPU (generic kernels and kernels built for the program) against the CPU oracle:
 every projected column bit-exact, or both sides refuse the program with an error."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,8 @@ from cases import compare_batches
 from ydb_amd.arrow_c import Col
 from ydb_amd.ssa_pb import OP, F, Program
 
+# other seeds for a sweep: SSA_RANDOM_SEEDS_FROM=1000 python -m pytest tests/test_gpu_random_programs.py
+SEEDS_FROM = int(os.environ.get("SSA_RANDOM_SEEDS_FROM", "0"))
 pytestmark = pytest.mark.gpu
 
 RES = [(1, "i32"), (2, "i64"), (3, "f64"), (4, "u8"), (5, "nz"), (6, "i32n"), (7, "f64n"), (8, "flag"), (9, "f32"), (10, "s")]
@@ -164,7 +168,7 @@ def run_both(program, batch, monkeypatch, jit):
     return got, gerr, exp, oerr
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(SEEDS_FROM, SEEDS_FROM + 80))
 def test_random_programs(seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 63, 1025, 20_011]))
@@ -231,7 +235,7 @@ def random_group_by(rng, nassign):
     return p, info["keys"], info["fsums"]
 
 
-@pytest.mark.parametrize("seed", range(100))
+@pytest.mark.parametrize("seed", range(SEEDS_FROM, SEEDS_FROM + 100))
 def test_random_group_bys(seed, monkeypatch):
     rng = np.random.default_rng(5000 + seed)
     n = int(rng.choice([1, 64, 1025, 4097, 50_021]))
@@ -270,7 +274,7 @@ def random_filter_projection(rng, nassign):
     return random_program(rng, nassign, finish, strings=True)
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(SEEDS_FROM, SEEDS_FROM + 80))
 def test_random_filter_projections(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.choice([1, 64, 1025, 4097, 30_011]))
