@@ -1982,13 +1982,14 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
     }
     if (L == 0) R = 1;
     const int sinkLds = L * 24 + 64 + naggs * L * R * 8 + L * 8 + 16;
+    int sinkExtra = 0;  // LDS behind the sink's own: the row list of the kernel that takes the rows behind a filter one by one
 
     // Scan arguments and sink description for a kernel that takes `rowsPerThread` rows per thread (the LDS plan, and with
     // it every operand offset in the sink, belongs to one tile size).
     int64_t algoBytes = 0;
     auto describe = [&](int rowsPerThread, ScanArgs& args, LaunchCfg& cfg, KeyedSink& sink) -> Status {
         ScanRowsPerThread = rowsPerThread;
-        Status st = FillScanArgs(plan, in, sinkLds, hashed ? SCAN_KEYED_HASHED : SCAN_KEYED_EXACT, args, cfg, algoBytes);
+        Status st = FillScanArgs(plan, in, sinkLds + sinkExtra, hashed ? SCAN_KEYED_HASHED : SCAN_KEYED_EXACT, args, cfg, algoBytes);
         ScanRowsPerThread = kRowsPerThread;
         if (!st.ok()) return st;
         args.nchecks = int32_t(checks.size());
@@ -2073,6 +2074,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             }
             if (!can) sink.compact_n = 0;
         }
+        sink.compact_slots = sinkExtra > 0 ? ((sinkLds + 15) & ~15) : 0;
 
         return Status::OK();
     };
@@ -2193,15 +2195,27 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
         // Row by row behind the filter, the per-tile work is what is left to shrink: such a kernel takes 16 rows per thread
         // when the rows are narrow enough.
         const int wideRows = WideRowsPerThread(plan, in);
-        if (hotMode == 2 && specRows < wideRows && wideRows >= 16 && !std::getenv("SSA_KEYED_U")) {
+        if (hotMode == 2) {
+            // (and it is given room for the list of the rows that passed: two bytes per row of a tile)
+            const int rowsPer = (specRows < wideRows && wideRows >= 16 && !std::getenv("SSA_KEYED_U")) ? wideRows : specRows;
             ScanArgs wargs;
             LaunchCfg wcfg;
             KeyedSink wsink{};
-            if (describe(wideRows, wargs, wcfg, wsink).ok() && wsink.compact_n > 0) {
+            sinkExtra = std::getenv("SSA_NO_COMPACT_SLOTS") ? 0 : 16 + kBlock * rowsPer * 2;
+            const bool fits = describe(rowsPer, wargs, wcfg, wsink).ok() && wsink.compact_n > 0;
+            sinkExtra = 0;
+            if (fits) {
                 sargs = wargs;
                 scfg = wcfg;
                 ssink = wsink;
-                specRows = wideRows;
+                specRows = rowsPer;
+            } else if (rowsPer != specRows) {
+                if (describe(rowsPer, wargs, wcfg, wsink).ok() && wsink.compact_n > 0) {  // (the wide tile without the list)
+                    sargs = wargs;
+                    scfg = wcfg;
+                    ssink = wsink;
+                    specRows = rowsPer;
+                }
             }
         }
     }

@@ -101,6 +101,10 @@ struct KeyedSink {
     int32_t compact_n;
     uint32_t compact_off[kMaxCompact];
     int32_t compact_w[kMaxCompact];
+    // Such a kernel may be given, behind the sink's own LDS (this many bytes from lds_sink_off; 0: none), two bytes per row
+    // of a tile: the lanes list their rows that passed there, and the lane that takes a row reads which one it is.
+    int32_t compact_slots;
+    int32_t pad3_;
 };
 
 // Kernel arguments of a scan kernel: passed by value, read in place from the kernel-argument segment.

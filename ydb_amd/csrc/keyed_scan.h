@@ -582,27 +582,52 @@ __device__ __forceinline__ void ScanKeyedBody() {
             // lane l takes the rows l, l + 64, ...  It finds the lane that owns a row by a binary search over the running
             // counts (six shuffles) -- thirty rows of a thousand are one trip of the loop instead of three.
             const uint32_t mine = uint32_t(__popc(m.P));
-            uint32_t upTo = mine;  // rows that passed in this lane and the lanes before it
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = uint32_t(__shfl_up(int(upTo), off, 64));
-                if (lane >= off) upTo += o;
-            }
+            // rows that passed in this lane and the lanes before it: a running sum across the wave by row shifts and row
+            // broadcasts (no round trips through the LDS crossbar)
+            uint32_t upTo = mine;
+            upTo += uint32_t(__builtin_amdgcn_update_dpp(0, int(upTo), 0x111, 0xf, 0xf, false));  // row_shr:1
+            upTo += uint32_t(__builtin_amdgcn_update_dpp(0, int(upTo), 0x112, 0xf, 0xf, false));  // row_shr:2
+            upTo += uint32_t(__builtin_amdgcn_update_dpp(0, int(upTo), 0x114, 0xf, 0xf, false));  // row_shr:4
+            upTo += uint32_t(__builtin_amdgcn_update_dpp(0, int(upTo), 0x118, 0xf, 0xf, false));  // row_shr:8
+            upTo += uint32_t(__builtin_amdgcn_update_dpp(0, int(upTo), 0x142, 0xa, 0xf, false));  // row_bcast:15
+            upTo += uint32_t(__builtin_amdgcn_update_dpp(0, int(upTo), 0x143, 0xc, 0xf, false));  // row_bcast:31
             const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(upTo), 63));
+            // With room in LDS every lane lists its rows at their numbers (row slot and lane in two bytes), and the lane that
+            // takes a row reads which one it is: one write per row that passed and one read per row taken.  (LDS accesses
+            // of a wave complete in order: the reads below see the list.)
+            uint16_t* const slots = s.compact_slots != 0
+                ? reinterpret_cast<uint16_t*>(gLds + a.lds_sink_off + s.compact_slots) + (threadIdx.x >> 6) * (64 * U) : nullptr;
+            if (slots != nullptr) {
+                uint32_t left = m.P, at = upTo - mine;
+                while (left != 0) {
+                    slots[at++] = uint16_t((__ffs(int(left)) - 1) * 64 + lane);
+                    left &= left - 1u;
+                }
+            }
             for (uint32_t first = 0; first < total; first += 64) {
                 const uint32_t want = first + uint32_t(lane);
                 const bool has = want < total;
                 int owner = 0;  // the first lane whose running count exceeds `want`
+                int pu = 0;
+                if (slots != nullptr) {
+                    const uint32_t v = has ? slots[want] : 0u;
+                    owner = int(v & 63u);
+                    pu = int(v >> 6);
+                } else {
+                    // without it: a binary search over the running counts (six shuffles), then the owner's rows counted off
 #pragma unroll
-                for (int step = 32; step >= 1; step >>= 1) {
-                    if (uint32_t(__shfl(int(upTo), owner + step - 1, 64)) <= want) owner += step;
+                    for (int step = 32; step >= 1; step >>= 1) {
+                        if (uint32_t(__shfl(int(upTo), owner + step - 1, 64)) <= want) owner += step;
+                    }
+                    owner = owner < 64 ? owner : 63;
+                    uint32_t ownerRows = uint32_t(__shfl(int(m.P), owner, 64));
+                    uint32_t skip = want - uint32_t(__shfl(int(upTo - mine), owner, 64));  // the owner's rows before this one
+                    if (has) {
+                        while (skip-- != 0) ownerRows &= ownerRows - 1u;
+                        pu = __ffs(int(ownerRows)) - 1;
+                    }
                 }
-                owner = owner < 64 ? owner : 63;
-                uint32_t ownerRows = uint32_t(__shfl(int(m.P), owner, 64));
-                uint32_t skip = want - uint32_t(__shfl(int(upTo - mine), owner, 64));  // the owner's rows before this one
                 if (has) {
-                while (skip-- != 0) ownerRows &= ownerRows - 1u;
-                const int pu = __ffs(int(ownerRows)) - 1;
                 const int idx = m.waveBase + pu * 64 + owner;
                 uint64_t klo = 0, khi = 0;
                 int pos = 0;
