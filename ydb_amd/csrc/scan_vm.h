@@ -691,9 +691,14 @@ struct Machine {
             uint32_t d[8];
             d[0] = cur.x, d[1] = cur.y, d[2] = cur.z, d[3] = cur.w;
             // the 16 bytes behind mine: the next lane's, for the last lane the first lane's of the next piece
-            const uint4 nb = make_uint4(__shfl_down(cur.x, 1, 64), __shfl_down(cur.y, 1, 64), __shfl_down(cur.z, 1, 64), __shfl_down(cur.w, 1, 64));
-            const uint4 n0 = make_uint4(__shfl(nxt.x, 0, 64), __shfl(nxt.y, 0, 64), __shfl(nxt.z, 0, 64), __shfl(nxt.w, 0, 64));
-            d[4] = lane == 63 ? n0.x : nb.x, d[5] = lane == 63 ? n0.y : nb.y, d[6] = lane == 63 ? n0.z : nb.z, d[7] = lane == 63 ? n0.w : nb.w;
+            // (a shift of the whole wave by one lane, a data-parallel move that leaves the last lane what it is given: the
+            // next piece's first words, read as scalars -- no trip through the LDS crossbar)
+            const uint32_t n0x = uint32_t(__builtin_amdgcn_readfirstlane(int(nxt.x))), n0y = uint32_t(__builtin_amdgcn_readfirstlane(int(nxt.y)));
+            const uint32_t n0z = uint32_t(__builtin_amdgcn_readfirstlane(int(nxt.z))), n0w = uint32_t(__builtin_amdgcn_readfirstlane(int(nxt.w)));
+            d[4] = uint32_t(__builtin_amdgcn_update_dpp(int(n0x), int(cur.x), 0x130, 0xf, 0xf, false));  // wave_shl:1
+            d[5] = uint32_t(__builtin_amdgcn_update_dpp(int(n0y), int(cur.y), 0x130, 0xf, 0xf, false));
+            d[6] = uint32_t(__builtin_amdgcn_update_dpp(int(n0z), int(cur.z), 0x130, 0xf, 0xf, false));
+            d[7] = uint32_t(__builtin_amdgcn_update_dpp(int(n0w), int(cur.w), 0x130, 0xf, 0xf, false));
             // the pattern's first (up to) four bytes at each of the 16 start positions; the rest of a longer pattern is
             // compared for the few hits only
             uint32_t hits = 0;
