@@ -357,11 +357,14 @@ struct Machine {
     __device__ __forceinline__ void BeginTile(int64_t tileBase, int64_t nextBase) {
         const int lane = threadIdx.x & 63;
         row0 = tileBase + waveBase + lane;
-        act = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) act |= (Row(u) < nrows ? 1u : 0u) << u;
         const bool full = (tileBase + kTile <= nrows);
         tileFull = full;
+        act = AllMask<U>();
+        if (!full) {  // (the same for the whole workgroup: only the table's last tile compares its rows with the end)
+            act = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) act |= (Row(u) < nrows ? 1u : 0u) << u;
+        }
         const int64_t slice0 = tileBase + waveBase;  // first row of the wave's slice
         // the wave's own LDS traffic of the previous tile (register stores included) has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -942,6 +945,20 @@ struct Machine {
     __device__ __forceinline__ uint32_t CompareByMask(int cls, uint32_t cmpMask, const uint64_t* x, const uint64_t* y) {
         uint32_t lt, eq, un;
         CompareMasks<U>(cls, x, y, lt, eq, un);
+        if (cls == CLS_I || cls == CLS_U || cls == CLS_IU || cls == CLS_UI) {
+            // integers are never unordered, and less / equal / greater part the rows: every combination is one of the two
+            // masks or its complement (what the other is computed from is then dead code in a kernel built for the step)
+            switch (cmpMask & 7u) {
+                case 0: return 0;
+                case 1: return lt & AllMask<U>();
+                case 2: return eq & AllMask<U>();
+                case 3: return (lt | eq) & AllMask<U>();
+                case 4: return ~(lt | eq) & AllMask<U>();
+                case 5: return ~eq & AllMask<U>();
+                case 6: return ~lt & AllMask<U>();
+                default: return AllMask<U>();
+            }
+        }
         const uint32_t gt = ~(lt | eq | un);
         return ((lt & (0u - (cmpMask & 1u))) | (eq & (0u - ((cmpMask >> 1) & 1u))) | (gt & (0u - ((cmpMask >> 2) & 1u))) |
                 (un & (0u - ((cmpMask >> 3) & 1u)))) & AllMask<U>();
