@@ -992,6 +992,39 @@ struct Machine {
                     const uint64_t cbits = ConstBits(fa);
 #pragma unroll
                     for (int u = 0; u < U; ++u) c[u] = cbits;
+#ifdef SSA_SPEC
+                    // A staged column of at most 32 bits against a constant that fits them (the same for the whole launch):
+                    // compared in 32 bits, half the instructions per row of the 64-bit payloads' compare.
+                    {
+                        const int cls = fb >> 4;
+                        const bool narrowSigned = cls == CLS_I && (fk == FK_LDS_I32 || fk == FK_LDS_I16 || fk == FK_LDS_I8);
+                        const bool narrowUnsigned = cls == CLS_U && (fk == FK_LDS_U32 || fk == FK_LDS_U16 || fk == FK_LDS_U8);
+                        const bool fits = narrowSigned ? int64_t(cbits) == int64_t(int32_t(uint32_t(cbits))) : (cbits >> 32) == 0;
+                        if ((narrowSigned || narrowUnsigned) && fits) {
+                            const uint32_t c32 = uint32_t(cbits);
+                            uint32_t lt = 0, eq = 0;
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const uint32_t x32 = uint32_t(B.v[u]);
+                                lt |= ((narrowSigned ? int32_t(x32) < int32_t(c32) : x32 < c32) ? 1u : 0u) << u;
+                                eq |= (x32 == c32 ? 1u : 0u) << u;
+                            }
+                            uint32_t r;
+                            switch (uint32_t(fb) & 7u) {
+                                case 0: r = 0; break;
+                                case 1: r = lt; break;
+                                case 2: r = eq; break;
+                                case 3: r = lt | eq; break;
+                                case 4: r = ~(lt | eq); break;
+                                case 5: r = ~eq; break;
+                                case 6: r = ~lt; break;
+                                default: r = ~0u; break;
+                            }
+                            P &= r & AllMask<U>();
+                            break;
+                        }
+                    }
+#endif
                     P &= CompareByMask(fb >> 4, uint32_t(fb & 15), B.v, c);
                     break;
                 }
