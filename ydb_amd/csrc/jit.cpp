@@ -240,7 +240,10 @@ bool Compile(const Job& job, std::vector<char>& code, std::string& why) {
     src << "\n};\n#include \"" << job.MainHeader << "\"\n";
     const std::string text = src.str();
     if (const char* dump = std::getenv("SSA_JIT_DUMP")) {  // diagnostics: the translation unit, for offline inspection
-        if (FILE* f = std::fopen(dump, "w")) {
+        static std::atomic<int> dumps{0};  // (a file per build: <path>.0, <path>.1, ... with the entry point in a comment)
+        const std::string path = std::string(dump) + "." + std::to_string(dumps.fetch_add(1));
+        if (FILE* f = std::fopen(path.c_str(), "w")) {
+            std::fprintf(f, "// %s\n", job.MainHeader.c_str());
             std::fwrite(text.data(), 1, text.size(), f);
             std::fclose(f);
         }

@@ -959,6 +959,38 @@ struct Machine {
                 default: return AllMask<U>();
             }
         }
+#ifdef SSA_SPEC
+        if (cls == CLS_F64 || cls == CLS_F32) {
+            // floating point, in a kernel built for the step (the mask is a constant there): one compare per row says
+            // whether the pair's relation -- less, equal, greater or unordered -- is among those asked for
+            uint32_t r = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double p = BitsToF64(x[u]), q = BitsToF64(y[u]);
+                bool t;
+                switch (cmpMask & 15u) {
+                    case 0: t = false; break;
+                    case 1: t = p < q; break;
+                    case 2: t = p == q; break;
+                    case 3: t = p <= q; break;
+                    case 4: t = p > q; break;
+                    case 5: t = p < q || p > q; break;
+                    case 6: t = p >= q; break;
+                    case 7: t = p == p && q == q; break;
+                    case 8: t = p != p || q != q; break;
+                    case 9: t = !(p >= q); break;
+                    case 10: t = !(p < q || p > q); break;
+                    case 11: t = !(p > q); break;
+                    case 12: t = !(p <= q); break;
+                    case 13: t = p != q; break;
+                    case 14: t = !(p < q); break;
+                    default: t = true; break;
+                }
+                r |= (t ? 1u : 0u) << u;
+            }
+            return r;
+        }
+#endif
         const uint32_t gt = ~(lt | eq | un);
         return ((lt & (0u - (cmpMask & 1u))) | (eq & (0u - ((cmpMask >> 1) & 1u))) | (gt & (0u - ((cmpMask >> 2) & 1u))) |
                 (un & (0u - ((cmpMask >> 3) & 1u)))) & AllMask<U>();
