@@ -658,9 +658,10 @@ struct Machine {
         const uint32_t lane = threadIdx.x & 63;
         uint64_t* words = reinterpret_cast<uint64_t*>(gLds + endOff + 16);
         if (lane < uint32_t(U)) words[lane] = 0;
-        if (e < b0 || e > limit) {  // offsets that do not describe this buffer (or its last, partial piece): the per-row path
+        if (e < b0 || e > limit || limit < 16u) {  // offsets that do not describe this buffer (or its last, partial piece): the per-row path
             return false;
         }
+        const uint32_t safe = e >= 16u ? (e - 16u) & ~15u : 0u;  // a whole piece inside the buffer
         // the pattern as two 64-bit words (zero behind its bytes)
         auto lower8 = [](uint64_t x) {  // ASCII upper-case bytes get bit 5
             const uint64_t t = x & 0x7F7F7F7F7F7F7F7Full;
@@ -679,18 +680,27 @@ struct Machine {
             const uint32_t up = ((t + 0x3F3F3F3Fu) & ~(t + 0x25252525u)) & ~x & 0x80808080u;
             return x | (up >> 2);
         };
-        auto piece = [&](uint32_t at) {  // the lane's 16 bytes of the piece that starts at `at` (zero past the slice)
+        auto piece = [&](uint32_t at) {  // the lane's 16 bytes of the piece that starts at `at`
             uint4 v = make_uint4(0, 0, 0, 0);
             const uint32_t my = at + lane * 16u;
-            if (my < e) v = *reinterpret_cast<const uint4*>(chars + my);
+            // (through a pointer said to be global: a pointer made from an integer is of no known address space, its loads
+            // are FLAT loads, which count as LDS operations too -- the compiler then waits for every load in flight at the
+            // top of the loop, and the pieces meant to be on their way during the search are not)
+            // (and without a branch around the load: behind a load that may or may not have been issued the compiler waits
+            // for all of them just the same.  A lane past the slice reads the slice's last whole piece instead and searches
+            // it like any other -- whatever it finds lies past the slice's end and is dropped with the hits there)
+            {
+                typedef uint32_t Words4 __attribute__((ext_vector_type(4)));
+                const uint32_t from = my < e ? my : safe;
+                const Words4 t = *reinterpret_cast<__attribute__((address_space(1))) const Words4*>(charsAddr + from);
+                v = make_uint4(t.x, t.y, t.z, t.w);
+            }
             if (icase) v = make_uint4(lower4(v.x), lower4(v.y), lower4(v.z), lower4(v.w));
             return v;
         };
         const uint32_t first = b0 & ~15u;
-        uint4 cur = piece(first);
-        uint4 nxt = piece(first + 1024u);
-        for (uint32_t base = first; base < e; base += 1024u) {
-            const uint4 ahead = piece(base + 2048u);  // two pieces are in flight while `cur` is searched (four measured no faster)
+        // one piece searched: `cur` the lane's 16 bytes of the piece at `base`, `nxt` those of the piece behind it
+        auto search = [&](const uint4& cur, const uint4& nxt, uint32_t base) {
             uint32_t d[8];
             d[0] = cur.x, d[1] = cur.y, d[2] = cur.z, d[3] = cur.w;
             // the 16 bytes behind mine: the next lane's, for the last lane the first lane's of the next piece
@@ -718,7 +728,7 @@ struct Machine {
                 if (pos < b0 || pos + uint32_t(pn) > e) continue;
                 bool rest = true;
                 for (int32_t i = 4; i < pn && rest; ++i) {
-                    const uint8_t ch = chars[pos + uint32_t(i)];
+                    const uint8_t ch = *reinterpret_cast<__attribute__((address_space(1))) const uint8_t*>(charsAddr + pos + uint32_t(i));
                     rest = (icase ? AsciiLower(ch) : ch) == uint8_t(pw[i >> 3] >> (8 * (i & 7)));
                 }
                 if (!rest) continue;
@@ -730,8 +740,20 @@ struct Machine {
                 const uint32_t rowEnd = lo + 1 < 64 * U ? l[lo + 1] : e;
                 if (pos + uint32_t(pn) <= rowEnd) atomicOr(reinterpret_cast<unsigned long long*>(words + (lo >> 6)), 1ull << (lo & 63));
             }
-            cur = nxt;
-            nxt = ahead;
+        };
+        // Three pieces go round in three sets of registers, so that two loads are on their way while a piece is searched
+        // (one loop over `cur = nxt; nxt = ahead` moves registers, and a move waits for its load: nothing was in flight).
+        uint4 pa = piece(first);
+        uint4 pb = piece(first + 1024u);
+        for (uint32_t base = first; base < e; base += 3072u) {
+            uint4 pc = piece(base + 2048u);
+            search(pa, pb, base);
+            if (base + 1024u >= e) break;
+            pa = piece(base + 3072u);
+            search(pb, pc, base + 1024u);
+            if (base + 2048u >= e) break;
+            pb = piece(base + 4096u);
+            search(pc, pa, base + 2048u);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) out[u] = (words[u] >> lane) & 1ull;
