@@ -34,7 +34,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
 # FETCH_SIZE passes of the scan kernels (rocprofv3 --pmc, their own runs), kept as ratios to the algorithmic bytes
-PMC_TRAFFIC_FILES = ("r2_c_pmc_traffic.json", "r2_b_pmc_traffic.json", "r2_a_pmc_traffic.json", "r1_d_pmc_traffic.json")  # newest first; a workload missing from one is looked up in the next
+PMC_TRAFFIC_FILES = ("r3_f_pmc_traffic.json", "r2_c_pmc_traffic.json", "r2_b_pmc_traffic.json", "r2_a_pmc_traffic.json", "r1_d_pmc_traffic.json")  # newest first; a workload missing from one is looked up in the next
 SF1000_SHARD_ROWS = 750_000_000  # SF1000 lineitem (6.0e9 rows) over the 8 GPUs of a node
 
 
