@@ -2,6 +2,8 @@
 // the hash table into output columns.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 #include "keyed_scan.h"
 
@@ -793,8 +795,9 @@ constexpr int kEmitC = 4;                  // records per lane and trip
 constexpr int kEmitWave = kEmitC * 64;
 // kRaw: 64-bit keys carried as one word; kTwo: the table keeps a hi word; kCountOnly: one aggregate, a count of rows (no
 // operands, no masks, no seen flags).  (What the launch knows is compiled in: the pass is bound by its instructions.)
-template <bool kRaw, bool kTwo, bool kCountOnly>
-__global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmitArgs) {
+// kThreads: threads of a workgroup -- a region is a chain of LDS round trips per record, and what hides them is waves.
+template <bool kRaw, bool kTwo, bool kCountOnly, int kThreads>
+__global__ __launch_bounds__(kThreads) void RegionEmitExactKernel(const RegionEmitArgs) {
     const RegionEmitArgs& a = KernArgsAs<RegionEmitArgs>();
     const KeyedSink& s = a.s;
     extern __shared__ uint64_t lRegion[];
@@ -877,9 +880,9 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
         loadRecords(first + wave * kEmitWave, last, nlo, nhi);
         SSA_RT(0);
         // (also keeps the previous region's last pass over the table and this region's set-up apart)
-        if (!__syncthreads_or((first != last || seed0 != kEmpty || Rs > kBlock) ? 1 : 0)) continue;
+        if (!__syncthreads_or((first != last || seed0 != kEmpty || Rs > kThreads) ? 1 : 0)) continue;
         SSA_RT(1);
-        for (int i = threadIdx.x; i < R1; i += kBlock) {
+        for (int i = threadIdx.x; i < R1; i += kThreads) {
             lLo[i] = kEmpty;
             if (two && i < R) lHi[i] = kUnpublished;
             if (anyCheck) lSeen[i] = 0;
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
         __syncthreads();
         SSA_RT(2);
         // what the scan's workgroups merged into this region of their table
-        for (int i = threadIdx.x; i < Rs && !(s.pad2_ & 4); i += kBlock) {
+        for (int i = threadIdx.x; i < Rs && !(s.pad2_ & 4); i += kThreads) {
             const uint64_t slo = i == int(threadIdx.x) ? seed0 : s.t_key_lo[small0 + i];
             if (slo == kEmpty || err != 0) continue;
             const uint64_t shi = s.two_words ? s.t_key_hi[small0 + i] : 0ull;
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
         }
         SSA_RT(3);
         // the region's records, kEmitWave per wave at a time
-        for (uint32_t w0 = first + wave * kEmitWave; w0 < last && !(s.pad2_ & 1); w0 += (kBlock / 64) * kEmitWave) {
+        for (uint32_t w0 = first + wave * kEmitWave; w0 < last && !(s.pad2_ & 1); w0 += (kThreads / 64) * kEmitWave) {
             uint64_t lo[kEmitC], hi[kEmitC];
             uint32_t slot[kEmitC], step[kEmitC];
             uint32_t live = 0, pending = 0;
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
                 lo[c] = nlo[c];
                 hi[c] = nhi[c];
             }
-            if (w0 + (kBlock / 64) * kEmitWave < last) loadRecords(w0 + (kBlock / 64) * kEmitWave, last, nlo, nhi);
+            if (w0 + (kThreads / 64) * kEmitWave < last) loadRecords(w0 + (kThreads / 64) * kEmitWave, last, nlo, nhi);
             uint64_t seen[kEmitC];
 #pragma unroll
             for (int c = 0; c < kEmitC; ++c) {
@@ -1032,8 +1035,8 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
         SSA_RT(5);
         if (s.pad2_ & 2) continue;
         // The groups leave in slot order.  Word w of the table = slots 64 w .. 64 w + 63.
-        for (int j = 0; j * kBlock < R; ++j) {
-            const int i = j * kBlock + threadIdx.x;
+        for (int j = 0; j * kThreads < R; ++j) {
+            const int i = j * kThreads + threadIdx.x;
             const uint64_t taken = __ballot(i < R && lLo[i] != kEmpty);
             if (lane == 0 && i < R) lWordStart[(i >> 6) + 1] = uint32_t(__popcll(taken));
         }
@@ -1061,8 +1064,8 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
         if (threadIdx.x == 0) a.region_groups[region] = ngroups;
         // the slots in use, listed, then array after array over the list: every lane has a group, and neighbouring lanes
         // write neighbouring rows
-        for (int j = 0; j * kBlock < R; ++j) {
-            const int i = j * kBlock + threadIdx.x;
+        for (int j = 0; j * kThreads < R; ++j) {
+            const int i = j * kThreads + threadIdx.x;
             const bool there = i < R && lLo[i] != kEmpty;
             const uint64_t taken = __ballot(there);
             if (there) lList[lWordStart[i >> 6] + __popcll(taken & ((1ull << lane) - 1ull))] = uint16_t(i);
@@ -1070,7 +1073,7 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
         if (threadIdx.x == 0 && extra) lList[inTable] = uint16_t(R);
         __syncthreads();
         const uint64_t row0 = uint64_t(region) * uint64_t(R);
-        for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kBlock) {
+        for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kThreads) {
             const int i = lList[idx];
             uint64_t elo = lLo[i < R ? i : 0], ehi = two ? lHi[i < R ? i : 0] : 0ull;
             if (raw) RawKeyWords(i == R ? kEmpty : elo, elo, ehi);
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(kBlock) void RegionEmitExactKernel(const RegionEmit
             a.tmp_seen[row0 + idx] = anyCheck ? lSeen[i] : 0u;
         }
         for (int k = 0; k < naggs; ++k) {
-            for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kBlock) a.tmp_acc[size_t(k) * a.tmp_stride + row0 + idx] = lAcc[size_t(k) * R1 + lList[idx]];
+            for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kThreads) a.tmp_acc[size_t(k) * a.tmp_stride + row0 + idx] = lAcc[size_t(k) * R1 + lList[idx]];
         }
         SSA_RT(7);
     }
@@ -1289,17 +1292,36 @@ namespace {
 bool CountOnlySink(const KeyedSink& s) { return s.naggs == 1 && s.aggs[0].kind == AGG_COUNT && s.aggs[0].check_valid == 0; }
 
 using RegionKernel = void (*)(const RegionEmitArgs);
-RegionKernel ExactRegionKernel(bool raw, bool two, bool countOnly) {
-    if (raw) return countOnly ? RegionEmitExactKernel<true, false, true> : RegionEmitExactKernel<true, false, false>;
-    if (two) return countOnly ? RegionEmitExactKernel<false, true, true> : RegionEmitExactKernel<false, true, false>;
-    return countOnly ? RegionEmitExactKernel<false, false, true> : RegionEmitExactKernel<false, false, false>;
+template <int kThreads>
+RegionKernel ExactRegionKernelOf(bool raw, bool two, bool countOnly) {
+    if (raw) return countOnly ? RegionEmitExactKernel<true, false, true, kThreads> : RegionEmitExactKernel<true, false, false, kThreads>;
+    if (two) return countOnly ? RegionEmitExactKernel<false, true, true, kThreads> : RegionEmitExactKernel<false, true, false, kThreads>;
+    return countOnly ? RegionEmitExactKernel<false, false, true, kThreads> : RegionEmitExactKernel<false, false, false, kThreads>;
+}
+constexpr int kExactThreadChoices[] = {256, 512, 1024};
+RegionKernel ExactRegionKernel(bool raw, bool two, bool countOnly, int threads) {
+    if (threads == 1024) return ExactRegionKernelOf<1024>(raw, two, countOnly);
+    if (threads == 512) return ExactRegionKernelOf<512>(raw, two, countOnly);
+    return ExactRegionKernelOf<256>(raw, two, countOnly);
+}
+// threads of a workgroup of the exact-key region pass (SSA_REGION_THREADS: experiments)
+int ExactRegionThreads() {
+    static const int chosen = [] {
+        const char* env = std::getenv("SSA_REGION_THREADS");
+        const int t = env ? std::atoi(env) : 512;
+        return (t == 256 || t == 512 || t == 1024) ? t : 512;
+    }();
+    return chosen;
 }
 }  // namespace
 
 hipError_t ConfigureRegionKernels(int maxLdsBytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&RegionEmitKernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
-    for (int v = 0; v < 6 && e == hipSuccess; ++v) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ExactRegionKernel(v / 2 == 0, v / 2 == 1, v % 2 != 0)), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+    for (int threads : kExactThreadChoices) {
+        for (int v = 0; v < 6 && e == hipSuccess; ++v) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(ExactRegionKernel(v / 2 == 0, v / 2 == 1, v % 2 != 0, threads)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
+        }
     }
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&RegionApplyKernel), hipFuncAttributeMaxDynamicSharedMemorySize, maxLdsBytes);
     return e;
@@ -1312,7 +1334,8 @@ hipError_t LaunchRegionEmit(const RegionEmitArgs& a, hipStream_t st) {
     } else {
         const bool raw = a.s.rec_raw64 != 0, two = a.s.two_words != 0 && !raw;
         const bool countOnly = CountOnlySink(a.s) && a.rec.mask == nullptr;
-        hipLaunchKernelGGL(ExactRegionKernel(raw, two, countOnly), dim3(uint32_t(grid)), dim3(kBlock), RegionEmitLdsBytes(a.s, a.region_slots), st, a);
+        const int threads = ExactRegionThreads();
+        hipLaunchKernelGGL(ExactRegionKernel(raw, two, countOnly, threads), dim3(uint32_t(grid)), dim3(uint32_t(threads)), RegionEmitLdsBytes(a.s, a.region_slots), st, a);
     }
     return hipGetLastError();
 }
