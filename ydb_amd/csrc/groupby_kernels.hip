@@ -82,10 +82,22 @@ __global__ __launch_bounds__(kBlock) void RadixCountKernel(const RadixArgs) {
         if (raw) {
             // 64-bit keys in one word: the table's two words from it; which indices hold a record at all, the first
             // round reads from the bitmap (64 consecutive records are one wave's load: one word of it)
+            // (the words of the bitmap like the keys: loaded without conditions, all of them in flight together -- a load
+            // and a wait per row made a tile sixteen round trips to memory)
+            uint64_t pres[kRadixPerThread];
+#pragma unroll
+            for (int u = 0; u < kRadixPerThread; ++u) pres[u] = ~0ull;
+            if (a.present != nullptr) {
+#pragma unroll
+                for (int u = 0; u < kRadixPerThread; ++u) {
+                    const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                    pres[u] = a.present[(r < end ? r : end - 1) >> 6];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < kRadixPerThread; ++u) {
                 const uint32_t r = r0 + u * kBlock + threadIdx.x;
-                const bool there = r < end && (a.present == nullptr || ((a.present[r >> 6] >> (r & 63u)) & 1ull) != 0);
+                const bool there = r < end && ((pres[u] >> (r & 63u)) & 1ull) != 0;
                 uint64_t l, h;
                 RawKeyWords(lo[u], l, h);
                 lo[u] = there ? l : kEmpty;
@@ -205,10 +217,21 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         if (raw) {
             // 64-bit keys in one word: the table's two words from it; which indices hold a record at all, the first
             // round reads from the bitmap (64 consecutive records are one wave's load: one word of it)
+            // (the words of the bitmap like the keys: loaded without conditions, all of them in flight together)
+            uint64_t pres[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) pres[u] = ~0ull;
+            if (a.present != nullptr) {
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) {
+                    const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                    pres[u] = a.present[(r < end ? r : end - 1) >> 6];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < kPer; ++u) {
                 const uint32_t r = r0 + u * kBlock + threadIdx.x;
-                const bool there = r < end && (a.present == nullptr || ((a.present[r >> 6] >> (r & 63u)) & 1ull) != 0);
+                const bool there = r < end && ((pres[u] >> (r & 63u)) & 1ull) != 0;
                 uint64_t l, h;
                 RawKeyWords(lo[u], l, h);
                 lo[u] = there ? l : kEmpty;
