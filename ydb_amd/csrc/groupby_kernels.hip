@@ -276,6 +276,24 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         }
         __syncthreads();
         const uint32_t n = lBase[256];
+        if (raw && !more) {
+            // One word a record, read once more from the cache: the reads of a thread's kPer records first, all of them in
+            // flight together, then the writes (a read and a write per trip of the loop below is a round trip per record).
+            uint64_t word[kPer];
+            uint32_t to[kPer];
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const uint32_t p = uint32_t(j) * kBlock + threadIdx.x;
+                const bool there = p < n;
+                const uint32_t d = there ? lDigit[p] : 0u;
+                to[j] = there ? lCursor[d] + (p - lBase[d]) : 0xFFFFFFFFu;
+                word[j] = a.src.lo[r0 + (there ? uint32_t(lOrder[p]) : 0u)];
+            }
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                if (to[j] != 0xFFFFFFFFu) a.dst.lo[to[j]] = word[j];
+            }
+        } else
         for (uint32_t p = threadIdx.x; p < n; p += kBlock) {
             const uint32_t d = lDigit[p];
             const uint32_t at = lCursor[d] + (p - lBase[d]);
