@@ -179,7 +179,7 @@ Status Executor::ImportBlobsQueued(const std::vector<std::pair<const uint8_t*, s
         total += (blobs[i].second + 255) & ~size_t(255);
     }
     // the blobs as stored, one copy each over PCIe
-    BufferPtr dblob = Buffer::Alloc(total + 256);
+    BufferPtr dblob = Buffer::Alloc(total + 512);  // (the parse reads a window of 256 bytes ahead of where it stands)
     if (!dblob) return Status::Hip("out of device memory");
     bool uploaded = false;
     SSA_RETURN_NOT_OK(UploadBlobs(blobs, base, total, static_cast<char*>(dblob->Ptr), uploaded));

@@ -322,14 +322,57 @@ __global__ __launch_bounds__(64) void Lz4ParseKernel(const uint8_t* blob, const 
     uint32_t produced = 0;     // bytes the block's sequences so far decode to
     uint32_t reachesBack = 0;  // how far before the block's first byte its matches read (0: the block stands alone)
     bool bad = false;
-    // twelve bytes of the block from byte `at` on (the blob has padding behind it: bytes past the block are read, never used)
+    // A lane reads its block through a window of 256 bytes in LDS (64 words, word i of every lane side by side).  The
+    // lanes stand at sixty-four different places in sixty-four different cache lines: read straight from memory, some lane
+    // misses its line at every sequence and the wave waits for memory every time.  Here the wave goes to memory for all
+    // of its lanes at once -- when the first of them nears the end of its window every lane drops what it has consumed
+    // and loads as much behind it -- and reads LDS in between.  (The blob has padding behind it: bytes past a block are
+    // loaded, never used.)
+    __shared__ uint32_t win[64 * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t skew = uint32_t(reinterpret_cast<uintptr_t>(src) & 3u);
+    const Lz4Window* const groups = reinterpret_cast<const Lz4Window*>(src - skew);  // the block as groups of four aligned words
+    uint32_t wd = 0;  // the window holds the words [wd, wd + 64) of the block, counted from the aligned word below its first byte; a multiple of 4
+    auto refill = [&](uint32_t newWd, uint32_t loadFrom) {
+        const uint32_t count = (newWd + 64u - loadFrom) >> 2;  // groups to load: 0 .. 16
+#pragma unroll
+        for (uint32_t half = 0; half < 2; ++half) {
+            if (half == 1 && !__any(count > 8u)) break;
+            Lz4Window t[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t q = half * 8u + j;
+                if (q < count) t[j] = groups[(loadFrom >> 2) + q];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t q = half * 8u + j;
+                if (q < count) {
+                    const uint32_t w = loadFrom + 4u * q;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) win[((w + i) & 63u) * 64u + lane] = t[j].w[i];
+                }
+            }
+        }
+        wd = newWd;
+    };
+    refill(0, 0);
+    // twelve bytes of the block from byte `at` on
     auto fetch = [&](uint32_t at, uint64_t& w0, uint32_t& w1) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(src + at);
-        const Lz4Window x = *reinterpret_cast<const Lz4Window*>(a & ~uintptr_t(3));
-        const uint32_t sh = 8u * uint32_t(a & 3u);
-        const uint32_t b0 = uint32_t((uint64_t(x.w[0]) | (uint64_t(x.w[1]) << 32)) >> sh);
-        const uint32_t b1 = uint32_t((uint64_t(x.w[1]) | (uint64_t(x.w[2]) << 32)) >> sh);
-        w1 = uint32_t((uint64_t(x.w[2]) | (uint64_t(x.w[3]) << 32)) >> sh);
+        const uint32_t y = skew + at;
+        const uint32_t d = y >> 2;
+        // (every lane that is still parsing takes part whenever one of them has to)
+        if (__any(d + 4u > wd + 64u)) {
+            const uint32_t newWd = d & ~3u;
+            refill(newWd, newWd > wd + 64u ? newWd : wd + 64u);
+        }
+        uint32_t x[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) x[i] = win[((d + i) & 63u) * 64u + lane];
+        const uint32_t sh = 8u * (y & 3u);
+        const uint32_t b0 = uint32_t((uint64_t(x[0]) | (uint64_t(x[1]) << 32)) >> sh);
+        const uint32_t b1 = uint32_t((uint64_t(x[1]) | (uint64_t(x[2]) << 32)) >> sh);
+        w1 = uint32_t((uint64_t(x[2]) | (uint64_t(x[3]) << 32)) >> sh);
         w0 = uint64_t(b0) | (uint64_t(b1) << 32);
     };
     auto emit = [&](uint32_t lit, uint32_t match, uint32_t lo, uint32_t hi) {
