@@ -249,6 +249,10 @@ void ssa_apply_many_stats(int64_t* steps_in_one_launch, int64_t* steps_slice_by_
 /* Process-wide counter: GROUP BY scans that applied the rows missing the workgroups' own tables region by region of the
  * table in HBM (groupings of a million groups and more take this way; SSA_KEYED_PARTITION=0 / 1 forbids / forces it). */
 void ssa_keyed_stats(int64_t* scans_applied_by_region);
+/* Process-wide counter: of those, the scans whose records were first sorted without counting passes (every region's place
+ * in the sorted arrays gets room to spare), found a place too small for its region and were sorted again with counts --
+ * keys that crowd into few regions of the table do that; the step sorts with counts from then on. */
+void ssa_keyed_sort_stats(int64_t* sorts_done_again_with_counts);
 /* Process-wide counter: GROUP BY scans run by the kernel that deals the rows that passed the step's filters out evenly
  * over the lanes of a wave and aggregates them one by one (steps behind a selective filter whose keys and aggregate
  * arguments are plain columns without nulls; timed against the other ways on the step's first large scans,

@@ -35,6 +35,13 @@ def applied_by_region():
     return n.value
 
 
+def sorted_again_with_counts():
+    from ydb_amd import _lib
+    n = ctypes.c_int64(0)
+    _lib.load().ssa_keyed_sort_stats(ctypes.byref(n))
+    return n.value
+
+
 def run_three_ways(monkeypatch, resolver, program, batch, expect_region=True, lds=None):
     """Results with the records applied by region, with every row updating the table itself, and the oracle's."""
     from oracle import ssa_oracle
@@ -198,6 +205,36 @@ def test_more_groups_than_the_last_scan_found(monkeypatch):
     for batch in (few, few, many, few, many):
         got = pc.Export(pc.ApplyDevice(pc.Import(batch)))
         compare_batches(got, ssa_oracle.Oracle(res, p).apply(batch), key_names=["k"])
+
+
+def test_a_sort_whose_places_run_out_of_room_is_done_again_with_counts(monkeypatch, emit_mode, region_slots):
+    """The first of the sort's two rounds goes without its counting pass, every digit's place in the sorted arrays with
+    room to spare; with a third of the room (a switch of the library) some place is too small: the scan's records are
+    sorted again with counts, the results are the same, and the step's next scans count from the start."""
+    from oracle import ssa_oracle
+    from ydb_amd.program import ProgramContainer
+    if emit_mode != "1" or region_slots is None:
+        pytest.skip("two rounds of the sort, the groups emitted from LDS: the table in HBM is always filled from counted places")
+    monkeypatch.setenv("SSA_JIT", "1")
+    monkeypatch.setenv("SSA_KEYED_PARTITION", "1")
+    monkeypatch.setenv("SSA_KEYED_LDS", "0,1")  # (no tables of the workgroups' own: every row is a record)
+    rng = np.random.default_rng(511)
+    n = 350_000
+    batch = {"k": rng.integers(0, 90_000, n).astype(np.int64), "v": nullable(rng, rng.integers(-100, 100, n).astype(np.int32), 0.1)}
+    res = [(1, "k"), (2, "v")]
+    p = Program().group_by([Aggregate(100, AGG.COUNT, []), Aggregate(101, AGG.SUM, [2]), Aggregate(102, AGG.MIN, [2])], keys=[1])
+    want = ssa_oracle.Oracle(res, p).apply(batch)
+    pc = ProgramContainer()
+    ok, err = pc.Init(res, p)
+    assert ok, err
+    dev = pc.Import(batch)
+    compare_batches(pc.Export(pc.ApplyDevice(dev)), want, key_names=["k"])  # (sizes the table; room to spare)
+    monkeypatch.setenv("SSA_RADIX_ROOM_PERMILLE", "300")
+    before = sorted_again_with_counts()
+    compare_batches(pc.Export(pc.ApplyDevice(dev)), want, key_names=["k"])
+    assert sorted_again_with_counts() - before == 1
+    compare_batches(pc.Export(pc.ApplyDevice(dev)), want, key_names=["k"])
+    assert sorted_again_with_counts() - before == 1
 
 
 def test_large_grouping_takes_the_region_pass_by_itself(monkeypatch, region_slots):

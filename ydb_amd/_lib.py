@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "ssa_device_count", "ssa_version", "ssa_shutdown", "ssa_free_string", "ssa_program_create", "ssa_program_create_with_kernels", "ssa_group_by_create", "ssa_program_destroy",
     "ssa_program_debug_string", "ssa_program_source_columns", "ssa_program_early_filter_columns",
     "ssa_program_step_count", "ssa_program_explain", "ssa_program_apply", "ssa_program_build_filter", "ssa_batch_import",
-    "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_program_apply_many", "ssa_apply_many_stats", "ssa_keyed_stats", "ssa_keyed_compact_stats",
+    "ssa_batch_from_device", "ssa_dictionary_stats", "ssa_program_apply_device", "ssa_program_apply_many", "ssa_apply_many_stats", "ssa_keyed_stats", "ssa_keyed_sort_stats", "ssa_keyed_compact_stats",
     "ssa_batch_pack_layout", "ssa_batch_pack_data", "ssa_batch_unpack", "ssa_batch_concat", "ssa_batch_slice", "ssa_batch_rename",
     "ssa_batch_column_name", "ssa_merge_sorted", "ssa_batch_export", "ssa_batch_rows",
     "ssa_batch_columns", "ssa_batch_destroy", "ssa_sharding_hash", "ssa_sharding_split", "ssa_batch_partition_by_key", "ssa_profile_enable", "ssa_profile_read", "ssa_specialization_stats",
@@ -152,6 +152,8 @@ def load() -> ctypes.CDLL:
     lib.ssa_apply_many_stats.restype = None
     lib.ssa_keyed_stats.argtypes = [P(i64)]
     lib.ssa_keyed_stats.restype = None
+    lib.ssa_keyed_sort_stats.argtypes = [P(i64)]
+    lib.ssa_keyed_sort_stats.restype = None
     lib.ssa_keyed_compact_stats.argtypes = [P(i64)]
     lib.ssa_keyed_compact_stats.restype = None
     lib.ssa_program_apply_device.argtypes = [vp, vp, P(vp), P(vp)]

@@ -632,6 +632,10 @@ void ssa_keyed_stats(int64_t* scans_applied_by_region) {
     if (scans_applied_by_region) *scans_applied_by_region = ssa::gKeyedStepsDeferred.load();
 }
 
+void ssa_keyed_sort_stats(int64_t* sorts_done_again_with_counts) {
+    if (sorts_done_again_with_counts) *sorts_done_again_with_counts = ssa::gRadixCursorOverflows.load();
+}
+
 int ssa_batch_export(ssa_program_t* program, const ssa_batch_t* batch, ArrowArray* out, ArrowSchema* out_schema, char** err) {
     if (err) *err = nullptr;
     std::lock_guard<std::mutex> g(program->Lock);

@@ -1836,6 +1836,7 @@ static int64_t AlgorithmicBytes(const StepPlan& plan, const Batch& in) {
 // `many`: the scan covers several slices of one schema in one launch (`in` is the first of them, the plan and the LDS
 // layout are made for it); the result holds the groups of all slices, slice after slice.
 std::atomic<int64_t> gKeyedStepsDeferred{0};
+std::atomic<int64_t> gRadixCursorOverflows{0};
 std::atomic<int64_t> gKeyedStepsCompacted{0};
 
 Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, const Batch& in, BatchPtr& out,
@@ -2535,9 +2536,44 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             RegionGroups regionGroups;
             int64_t found = 0;
             int64_t* foundAt = HostWords ? reinterpret_cast<int64_t*>(HostWords + 8) : &found;  // (pinned: no staging copy)
-            Status st = SortDeferredRecords(ssink, in.Rows, nvals, needMask, 63 - __builtin_clzll(uint64_t(smallSlots)), regionCount, sorted);
-            if (st.ok()) st = AggregateDeferredRecords(ssink, sargs, sorted, in.Rows, nvals, ldsSlots, smallSlots, regionCount, regionGroups, foundAt);
-            if (st.ok()) st = CheckScanStatus(&tableFull, nullptr);  // (synchronises the stream: the count has arrived)
+            // The sort's first round without its counting pass first (a digit's place in the sorted arrays has room to
+            // spare); keys that crowd into few regions run one out of room: the scan's records are still there then, and are
+            // sorted again with counts -- for this step, from then on.
+            uint32_t overflowed = 0;
+            uint32_t* overflowAt = HostWords ? reinterpret_cast<uint32_t*>(HostWords + 12) : &overflowed;
+            Status st = Status::OK();
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                const bool byCursors = attempt == 0 && !hint.NoRadixCursors && std::getenv("SSA_NO_RADIX_CURSORS") == nullptr;
+                if (attempt == 0 && !byCursors) continue;
+                sorted = SortedRecords{};
+                regionGroups = RegionGroups{};
+                *overflowAt = 0;
+                st = SortDeferredRecords(ssink, in.Rows, nvals, needMask, 63 - __builtin_clzll(uint64_t(smallSlots)), regionCount, sorted, byCursors);
+                if (st.ok()) st = AggregateDeferredRecords(ssink, sargs, sorted, in.Rows, nvals, ldsSlots, smallSlots, regionCount, regionGroups, foundAt);
+                if (st.ok() && sorted.overflow != nullptr) {
+                    const hipError_t e = hipMemcpyAsync(overflowAt, sorted.overflow, 4, hipMemcpyDeviceToHost, StreamHandle);
+                    if (e != hipSuccess) st = Status::Hip(hipGetErrorString(e));
+                }
+                if (st.ok() && sorted.overflow != nullptr) {
+                    hipError_t e = hipStreamSynchronize(StreamHandle);
+                    // (what the region pass said about a part of the records says nothing)
+                    if (e == hipSuccess && *overflowAt != 0) e = hipMemsetAsync(StatusWord->Ptr, 0, 4, StreamHandle);
+                    if (e != hipSuccess) st = Status::Hip(hipGetErrorString(e));
+                }
+                if (st.ok() && *overflowAt == 0) st = CheckScanStatus(&tableFull, nullptr);  // (synchronises the stream: the count has arrived)
+                if (!st.ok() || *overflowAt == 0) break;
+                hint.NoRadixCursors = true;
+                gRadixCursorOverflows.fetch_add(1, std::memory_order_relaxed);
+                if (std::getenv("SSA_DEBUG_PLAN")) {
+                    std::vector<uint32_t> words(sorted.ncursors);
+                    (void)hipMemcpy(words.data(), sorted.cursors, words.size() * 4, hipMemcpyDeviceToHost);
+                    uint32_t fullest = 0;
+                    uint64_t sum = 0;
+                    for (uint32_t w : words) fullest = std::max(fullest, w), sum += w;
+                    std::fprintf(stderr, "regions: a place of the sort ran out of room (%llu records, the fullest digit %u of them, room for %u); sorting again with counts\n",
+                                 (unsigned long long)sum, fullest, sorted.cursor_cap);
+                }
+            }
             if (st.ok() && !tableFull) {
                 found = *foundAt;
                 st = prepareOutputs(found);

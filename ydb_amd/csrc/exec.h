@@ -57,6 +57,7 @@ extern std::atomic<int64_t> gDictStepsOnCodes, gDictColumnsDecoded;
 // ... sets of slices (of one schema, under one step) that ApplyProgramMany scanned with one launch; sets it ran slice by slice.
 extern std::atomic<int64_t> gManyStepsOneLaunch, gManyStepsPerSlice;
 extern std::atomic<int64_t> gKeyedStepsCompacted;  // keyed scans run the third way: the rows behind the filter dealt out over the lanes, taken one by one
+extern std::atomic<int64_t> gRadixCursorOverflows;  // sorts by region whose places ran out of room and were done again with counts
 extern std::atomic<int64_t> gKeyedStepsDeferred;  // keyed scans whose level-2 updates were applied region by region
 
 struct Column {
@@ -298,10 +299,19 @@ private:
     struct SortedRecords {
         RecordSet set{};
         const uint32_t* region_start = nullptr;
+        // the first round went without its counting pass (RadixArgs.cursor): *overflow says that some digit's place ran out
+        // of room and the sort is void; the digits' cursors and the room of a place for diagnostics
+        const uint32_t* overflow = nullptr;
+        const uint32_t* cursors = nullptr;
+        size_t ncursors = 0;
+        uint32_t cursor_cap = 0;
+        int64_t stride = 0;  // elements between two operand arrays of `set`
         std::vector<BufferPtr> keep;
     };
+    // `byCursors`: the first of two rounds without its counting pass -- every digit's place in the sorted arrays gets room to
+    // spare; the caller looks at *overflow once the stream is synchronised and sorts again without if it is set.
     Status SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nvals, bool needMask, int regionShift, uint64_t regions,
-                               SortedRecords& out);
+                               SortedRecords& out, bool byCursors = false);
     Status ApplyDeferredRecords(const KeyedSink& sink, const ScanArgs& args, int64_t rows, int nvals, bool needMask, int regionSlots,
                                 uint64_t cap);
     // The groups of a region pass in its temporary table, and what the kernel that moves them to the output needs.
@@ -375,6 +385,7 @@ private:
         // keys).  Both ways are timed once on the step's large scans, scan to finished table.
         int DeferChoice = -1;    // -1 undecided, 0 row by row, 1 by region
         double MsDeferOn = 0, MsDeferOff = 0;
+        bool NoRadixCursors = false;  // a sort by region without counting passes ran out of room once: with counts from then on
         // The level-2 tables of the step's small scans (a few thousand slots each), kept from scan to scan: the launch that
         // emits their groups leaves them free again.  Clean: nothing has touched them since.
         struct SmallTable {

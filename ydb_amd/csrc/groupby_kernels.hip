@@ -47,7 +47,9 @@ constexpr int kRadixTile = kBlock * kRadixPerThread;
 // The records a workgroup takes: chunk `blockIdx.x % chunks` of segment `blockIdx.x / chunks`, whole tiles.
 __device__ __forceinline__ void RadixChunk(const RadixArgs& a, uint32_t& begin, uint32_t& end) {
     const int seg = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-    const uint32_t s0 = a.seg_start[seg], s1 = a.seg_start[seg + 1];
+    // (a segment left by a round with cursors: at seg * seg_cap, seg_count[seg] records of it)
+    const uint32_t s0 = a.seg_count != nullptr ? uint32_t(seg) * a.seg_cap : a.seg_start[seg];
+    const uint32_t s1 = a.seg_count != nullptr ? s0 + (a.seg_count[seg] < a.seg_cap ? a.seg_count[seg] : a.seg_cap) : a.seg_start[seg + 1];
     uint32_t per = (s1 - s0 + uint32_t(a.chunks) - 1) / uint32_t(a.chunks);
     per = (per + kRadixTile - 1) / kRadixTile * kRadixTile;
     const uint64_t b = uint64_t(s0) + uint64_t(chunk) * per;
@@ -190,7 +192,9 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
     const bool more = (a.two_words != 0 && a.raw64 == 0) || a.dst.mask != nullptr || a.dst.row != nullptr || a.nvals > 0;  // more than the lo word to move
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     lCount[threadIdx.x] = 0;
-    if (int(threadIdx.x) < a.ndigits) {
+    const bool byCursor = a.cursor != nullptr;
+    const int64_t dstStride = a.dst_stride != 0 ? a.dst_stride : a.stride;
+    if (int(threadIdx.x) < a.ndigits && !byCursor) {
         lCursor[threadIdx.x] = a.out_start[size_t(seg) * a.ndigits + threadIdx.x] + a.counts[size_t(blockIdx.x) * a.ndigits + threadIdx.x];
     }
     __syncthreads();
@@ -252,6 +256,14 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         // first position of each digit inside the ordered tile: exclusive scan of lCount (256 entries, one wave's worth each)
         {
             const uint32_t c = lCount[threadIdx.x];
+            if (byCursor && int(threadIdx.x) < a.ndigits) {
+                // the tile's records of this digit take the next c places of the digit's room in dst; those past the room's
+                // end are not written (the sort is void then, but every place the cursors count holds a record)
+                const size_t bucket = size_t(seg) * a.ndigits + threadIdx.x;
+                const uint32_t before = c != 0 ? atomicAdd(a.cursor + bucket, c) : 0u;
+                if (before + c > a.bucket_cap) atomicOr(a.overflow, 1u);
+                lCursor[threadIdx.x] = uint32_t(bucket) * a.bucket_cap + (before < a.bucket_cap ? before : a.bucket_cap);
+            }
             uint32_t inc = c;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -276,6 +288,9 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         }
         __syncthreads();
         const uint32_t n = lBase[256];
+        // first place past the room of digit d (places by cursors)
+        const uint32_t room0 = (uint32_t(seg) * uint32_t(a.ndigits) + 1u) * a.bucket_cap;
+        auto fits = [&](uint32_t d, uint32_t at) { return !byCursor || at < room0 + d * a.bucket_cap; };
         if (raw && !more) {
             // One word a record, read once more from the cache: the reads of a thread's kPer records first, all of them in
             // flight together, then the writes (a read and a write per trip of the loop below is a round trip per record).
@@ -287,6 +302,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
                 const bool there = p < n;
                 const uint32_t d = there ? lDigit[p] : 0u;
                 to[j] = there ? lCursor[d] + (p - lBase[d]) : 0xFFFFFFFFu;
+                if (!fits(d, to[j])) to[j] = 0xFFFFFFFFu;
                 word[j] = a.src.lo[r0 + (there ? uint32_t(lOrder[p]) : 0u)];
             }
 #pragma unroll
@@ -297,6 +313,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         for (uint32_t p = threadIdx.x; p < n; p += kBlock) {
             const uint32_t d = lDigit[p];
             const uint32_t at = lCursor[d] + (p - lBase[d]);
+            if (!fits(d, at)) continue;
             const uint32_t r = r0 + lOrder[p];
             // (64-bit keys in one word: the word as it came, read once more -- from the cache)
             a.dst.lo[at] = raw ? a.src.lo[r] : lSortedLo[raw ? 0 : p];
@@ -304,10 +321,10 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
             if (two && !raw) a.dst.hi[at] = a.src.hi[r];
             if (a.dst.mask != nullptr) a.dst.mask[at] = a.src.mask[r];
             if (a.dst.row != nullptr) a.dst.row[at] = a.src.row != nullptr ? a.src.row[r] : r;
-            for (int v = 0; v < a.nvals; ++v) a.dst.val[size_t(v) * size_t(a.stride) + at] = a.src.val[size_t(v) * size_t(a.stride) + r];
+            for (int v = 0; v < a.nvals; ++v) a.dst.val[size_t(v) * size_t(dstStride) + at] = a.src.val[size_t(v) * size_t(a.stride) + r];
         }
         __syncthreads();
-        lCursor[threadIdx.x] += lCount[threadIdx.x];
+        if (!byCursor) lCursor[threadIdx.x] += lCount[threadIdx.x];
         lCount[threadIdx.x] = 0;
         __syncthreads();
     }

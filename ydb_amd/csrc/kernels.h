@@ -251,6 +251,17 @@ struct RadixArgs {
     const uint32_t* seg_start;    // [nseg + 1]
     uint32_t* counts;             // [nseg][chunks][ndigits] records per chunk and digit; then those of the earlier chunks
     uint32_t* out_start;          // [nseg * ndigits + 1] first record of each (segment, digit) in dst
+    // Without a counting pass: (segment, digit) number b of dst has room for bucket_cap records from b * bucket_cap on
+    // (out_start is not read), a tile's records of a digit take their places by one atomic add on the digit's cursor, and
+    // a digit that runs out of room raises *overflow (the caller sorts again, with counts).  The segments of src may have
+    // been left that way by the round before: segment seg then is the seg_count[seg] (at most seg_cap) records from
+    // seg * seg_cap on, and seg_start is not read.
+    uint32_t* cursor;             // [nseg * ndigits], zero before the launch; nullptr: counts / out_start as above
+    uint32_t bucket_cap;
+    uint32_t* overflow;
+    const uint32_t* seg_count;    // [nseg] or nullptr: seg_start[seg + 1] ends segment seg
+    uint32_t seg_cap;
+    int64_t dst_stride;           // elements between two operand arrays of dst (0: stride)
 };
 hipError_t LaunchRadixCount(const RadixArgs& a, hipStream_t st);
 hipError_t LaunchRadixOffsets(const RadixArgs& a, hipStream_t st);

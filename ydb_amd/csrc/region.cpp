@@ -30,33 +30,57 @@ int Log2Of(uint64_t x) {
 // The records a scan left, sorted by region.  `sink`: the sink the scan ran with (record arrays; its table_mask and
 // `regionShift` say which bits of a key's table position are its region number); `regions`: how many there are.
 Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nvals, bool needMask, int regionShift, uint64_t regions,
-                                     SortedRecords& out) {
+                                     SortedRecords& out, bool byCursors) {
     const bool twoWords = sink.two_words != 0, hashed = sink.hashed != 0;
     const size_t n = size_t(rows);
     const int regionBits = Log2Of(regions);
     // one round of the sort for up to 256 regions, else two of about as many bits each (the second of 6 bits at least)
     const int bitsB = regionBits <= 8 ? 0 : std::max(6, regionBits / 2);  // (fewer digits a round: longer runs per tile in the scatter)
     const int bitsA = regionBits - bitsB;
+    const int digitsA = std::max(64, 1 << bitsA);
+    // The first round without its counting pass: every digit's place in the sorted arrays gets room for half as many
+    // records again as the mean.  The digit is a slice of a hash, but the records are not spread like balls over bins: a key
+    // of many rows puts them all into one place (ClickBench UserID: the fullest of 128 digits holds 1.28 times the mean --
+    // and the fullest of the 16384 regions 30 times, which is why the second round counts).  SSA_RADIX_ROOM_PERMILLE
+    // (tests) gives a part of the room only.
+    uint64_t permille = 1000;
+    if (const char* env = std::getenv("SSA_RADIX_ROOM_PERMILLE")) permille = uint64_t(std::max(1, std::atoi(env)));
+    const uint64_t meanA = uint64_t(n >> bitsA);  // (2^bitsA digits have records: digitsA may be more)
+    const uint64_t capA = ((meanA + meanA / 2 + 4096) * permille / 1000 + 63) & ~uint64_t(63);
+    const uint64_t roomA = capA << bitsA;
+    if (bitsB == 0 || roomA >= (uint64_t(1) << 32)) byCursors = false;  // (places are 32-bit numbers)
     if (std::getenv("SSA_DEBUG_PLAN")) {
-        std::fprintf(stderr, "regions: %llu regions (table mask %llx, shift %d), sort rounds of %d and %d bits\n", (unsigned long long)regions,
-                     (unsigned long long)sink.table_mask, regionShift, bitsA, bitsB);
+        std::fprintf(stderr, "regions: %llu regions (table mask %llx, shift %d), sort rounds of %d and %d bits%s\n", (unsigned long long)regions,
+                     (unsigned long long)sink.table_mask, regionShift, bitsA, bitsB, byCursors ? ", the first without counts" : "");
     }
 
     const bool raw64 = sink.rec_raw64 != 0;  // (64-bit keys in one word: no hi arrays)
-    BufferPtr partLo = Buffer::Alloc(n * 8), partHi = Buffer::Alloc(twoWords && !raw64 ? n * 8 : 64);
-    BufferPtr partVal = Buffer::Alloc(size_t(nvals) * n * 8 + 64), partMask = Buffer::Alloc(needMask ? n * 4 : 64);
-    BufferPtr partRow = Buffer::Alloc(hashed ? n * 4 : 64), recRow = Buffer::Alloc(hashed && bitsB > 0 ? n * 4 : 64);
+    const size_t partN = byCursors ? size_t(roomA) : n;
+    const size_t backN = n;
+    BufferPtr partLo = Buffer::Alloc(partN * 8), partHi = Buffer::Alloc(twoWords && !raw64 ? partN * 8 : 64);
+    BufferPtr partVal = Buffer::Alloc(size_t(nvals) * partN * 8 + 64), partMask = Buffer::Alloc(needMask ? partN * 4 : 64);
+    BufferPtr partRow = Buffer::Alloc(hashed ? partN * 4 : 64), recRow = Buffer::Alloc(hashed && bitsB > 0 ? backN * 4 : 64);
     if (!partLo || !partHi || !partVal || !partMask || !partRow || !recRow) return Status::Hip("out of device memory");
     RecordSet scanned{sink.rec_lo, sink.rec_hi, sink.rec_val, needMask ? sink.rec_mask : nullptr, nullptr};
     RecordSet part{static_cast<uint64_t*>(partLo->Ptr), static_cast<uint64_t*>(partHi->Ptr), static_cast<uint64_t*>(partVal->Ptr),
                    needMask ? static_cast<uint32_t*>(partMask->Ptr) : nullptr, hashed ? static_cast<uint32_t*>(partRow->Ptr) : nullptr};
     RecordSet back = scanned;  // the second round sorts into the scan's arrays again
     back.row = hashed ? static_cast<uint32_t*>(recRow->Ptr) : nullptr;
+    out.keep = {partLo, partHi, partVal, partMask, partRow, recRow};
+    if (byCursors) {  // (... unless the first went without counts: arrays of their own, and the scan's records stay as they are)
+        BufferPtr backLo = Buffer::Alloc(backN * 8), backHi = Buffer::Alloc(twoWords && !raw64 ? backN * 8 : 64);
+        BufferPtr backVal = Buffer::Alloc(size_t(nvals) * backN * 8 + 64), backMask = Buffer::Alloc(needMask ? backN * 4 : 64);
+        if (!backLo || !backHi || !backVal || !backMask) return Status::Hip("out of device memory");
+        back = RecordSet{static_cast<uint64_t*>(backLo->Ptr), static_cast<uint64_t*>(backHi->Ptr), static_cast<uint64_t*>(backVal->Ptr),
+                         needMask ? static_cast<uint32_t*>(backMask->Ptr) : nullptr, hashed ? static_cast<uint32_t*>(recRow->Ptr) : nullptr};
+        out.keep.insert(out.keep.end(), {backLo, backHi, backVal, backMask});
+    }
 
     RadixArgs ra{};
     ra.src = scanned;
     ra.dst = part;
     ra.stride = rows;
+    ra.dst_stride = int64_t(partN);
     ra.nvals = nvals;
     ra.two_words = twoWords;
     ra.raw64 = raw64;
@@ -65,7 +89,7 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
     ra.table_mask = sink.table_mask;
     ra.region_shift = regionShift;
     ra.digit_shift = bitsB;
-    ra.ndigits = std::max(64, 1 << bitsA);
+    ra.ndigits = digitsA;
     ra.nseg = 1;
     // (three workgroups a CU; more of them -- raw keys leave room for six -- measured slower: shorter chunks, shorter runs)
     int64_t workgroups = 768;
@@ -73,22 +97,48 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
     ra.chunks = int(std::min<int64_t>(workgroups, std::max<int64_t>(1, (rows + 16383) / 16384)));
     BufferPtr segA = Buffer::Alloc(64), countsA = Buffer::Alloc(size_t(ra.chunks) * ra.ndigits * 4), startA = Buffer::Alloc(size_t(ra.ndigits + 1) * 4 + 64);
     if (!segA || !countsA || !startA) return Status::Hip("out of device memory");
+    out.keep.insert(out.keep.end(), {segA, countsA, startA});
     const uint32_t whole[2] = {0u, uint32_t(rows)};
     SSA_HIP(hipMemcpyAsync(segA->Ptr, whole, sizeof(whole), hipMemcpyHostToDevice, StreamHandle));
     ra.seg_start = static_cast<const uint32_t*>(segA->Ptr);
     ra.counts = static_cast<uint32_t*>(countsA->Ptr);
     ra.out_start = static_cast<uint32_t*>(startA->Ptr);
-    SSA_HIP(LaunchRadixCount(ra, StreamHandle));
-    SSA_HIP(LaunchRadixOffsets(ra, StreamHandle));
+    // the cursors and the overflow word: one buffer, zeroed once (digit d's place starts at d * cap: no table of starts)
+    BufferPtr cursors;
+    uint32_t* cursorA = nullptr;
+    uint32_t* overflow = nullptr;
+    if (byCursors) {
+        const size_t words = size_t(digitsA) + 16;
+        cursors = Buffer::Alloc(words * 4);
+        if (!cursors) return Status::Hip("out of device memory");
+        out.keep.push_back(cursors);
+        SSA_HIP(hipMemsetAsync(cursors->Ptr, 0, words * 4, StreamHandle));
+        cursorA = static_cast<uint32_t*>(cursors->Ptr);
+        overflow = cursorA + digitsA;
+        ra.cursor = cursorA;
+        ra.bucket_cap = uint32_t(capA);
+        ra.overflow = overflow;
+    } else {
+        SSA_HIP(LaunchRadixCount(ra, StreamHandle));
+        SSA_HIP(LaunchRadixOffsets(ra, StreamHandle));
+    }
     SSA_HIP(LaunchRadixScatter(ra, StreamHandle));
 
     out.set = part;
+    out.stride = int64_t(partN);
     out.region_start = ra.out_start;
-    out.keep = {partLo, partHi, partVal, partMask, partRow, recRow, segA, countsA, startA};
+    if (byCursors) {
+        out.overflow = overflow;
+        out.cursors = cursorA;
+        out.ncursors = size_t(digitsA);
+        out.cursor_cap = uint32_t(capA);
+    }
     if (bitsB > 0) {
         RadixArgs rb = ra;
         rb.src = part;
         rb.dst = back;
+        rb.stride = int64_t(partN);
+        rb.dst_stride = rows;
         rb.skip_free = 0;
         rb.present = nullptr;  // (the first round kept the records only)
         rb.digit_shift = 0;
@@ -101,10 +151,17 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
         if (!countsB || !startB) return Status::Hip("out of device memory");
         rb.counts = static_cast<uint32_t*>(countsB->Ptr);
         rb.out_start = static_cast<uint32_t*>(startB->Ptr);
+        rb.cursor = nullptr;
+        rb.overflow = nullptr;
+        if (byCursors) {  // (segment seg: the seg_count[seg] records from seg * capA on)
+            rb.seg_count = cursorA;
+            rb.seg_cap = uint32_t(capA);
+        }
         SSA_HIP(LaunchRadixCount(rb, StreamHandle));
         SSA_HIP(LaunchRadixOffsets(rb, StreamHandle));
         SSA_HIP(LaunchRadixScatter(rb, StreamHandle));
         out.set = back;
+        out.stride = rb.dst_stride;
         out.region_start = rb.out_start;
         out.keep.push_back(countsB);
         out.keep.push_back(startB);
@@ -175,7 +232,7 @@ Status Executor::AggregateDeferredRecords(const KeyedSink& sink, const ScanArgs&
     out.keep.insert(out.keep.end(), {tmpLo, tmpHi, tmpRep, tmpAcc, tmpSeen, counts, offsets, total});
     SSA_HIP(hipMemsetAsync(counts->Ptr, 0, size_t(regions) * 4, StreamHandle));  // (a region without records leaves no count)
     ea.rec = sorted.set;
-    ea.stride = rows;
+    ea.stride = sorted.stride != 0 ? sorted.stride : rows;
     ea.nvals = nvals;
     ea.region_slots = ldsSlots;
     ea.small_slots = smallSlots;
