@@ -2542,6 +2542,7 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             uint32_t overflowed = 0;
             uint32_t* overflowAt = HostWords ? reinterpret_cast<uint32_t*>(HostWords + 12) : &overflowed;
             Status st = Status::OK();
+            int64_t emittedAhead = 0;  // room of the output columns the groups were emitted into before their number was known
             for (int attempt = 0; attempt < 2; ++attempt) {
                 const bool byCursors = attempt == 0 && !hint.NoRadixCursors && std::getenv("SSA_NO_RADIX_CURSORS") == nullptr;
                 if (attempt == 0 && !byCursors) continue;
@@ -2550,17 +2551,27 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
                 *overflowAt = 0;
                 st = SortDeferredRecords(ssink, in.Rows, nvals, needMask, 63 - __builtin_clzll(uint64_t(smallSlots)), regionCount, sorted, byCursors);
                 if (st.ok()) st = AggregateDeferredRecords(ssink, sargs, sorted, in.Rows, nvals, ldsSlots, smallSlots, regionCount, regionGroups, foundAt);
-                if (st.ok() && sorted.overflow != nullptr) {
-                    const hipError_t e = hipMemcpyAsync(overflowAt, sorted.overflow, 4, hipMemcpyDeviceToHost, StreamHandle);
-                    if (e != hipSuccess) st = Status::Hip(hipGetErrorString(e));
+                // The groups go to the output columns right behind the region pass, into columns with room for somewhat
+                // more groups than the step's last scan found: their number arrives with the synchronisation below, and
+                // only a scan that found more than the room is emitted again, into longer columns.
+                emittedAhead = 0;
+                if (st.ok() && hint.Groups > 0 && !std::getenv("SSA_NO_EMIT_AHEAD")) {
+                    emittedAhead = hint.Groups + hint.Groups / 32 + 4096;
+                    st = prepareOutputs(emittedAhead);
+                    fa.capacity = uint64_t(emittedAhead);
+                    if (st.ok()) st = EmitRegionGroups(regionGroups, fa);
                 }
-                if (st.ok() && sorted.overflow != nullptr) {
-                    hipError_t e = hipStreamSynchronize(StreamHandle);
+                if (st.ok()) {
+                    uint32_t word = 0;
+                    uint32_t* wordAt = HostWords ? reinterpret_cast<uint32_t*>(HostWords) : &word;
+                    hipError_t e = sorted.overflow != nullptr ? hipMemcpyAsync(overflowAt, sorted.overflow, 4, hipMemcpyDeviceToHost, StreamHandle) : hipSuccess;
+                    if (e == hipSuccess) e = hipMemcpyAsync(wordAt, StatusWord->Ptr, 4, hipMemcpyDeviceToHost, StreamHandle);
+                    if (e == hipSuccess) e = hipStreamSynchronize(StreamHandle);  // (the count has arrived)
                     // (what the region pass said about a part of the records says nothing)
                     if (e == hipSuccess && *overflowAt != 0) e = hipMemsetAsync(StatusWord->Ptr, 0, 4, StreamHandle);
                     if (e != hipSuccess) st = Status::Hip(hipGetErrorString(e));
+                    else if (*overflowAt == 0) st = DecodeScanStatus(*wordAt, &tableFull, nullptr);
                 }
-                if (st.ok() && *overflowAt == 0) st = CheckScanStatus(&tableFull, nullptr);  // (synchronises the stream: the count has arrived)
                 if (!st.ok() || *overflowAt == 0) break;
                 hint.NoRadixCursors = true;
                 gRadixCursorOverflows.fetch_add(1, std::memory_order_relaxed);
@@ -2576,9 +2587,11 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             }
             if (st.ok() && !tableFull) {
                 found = *foundAt;
-                st = prepareOutputs(found);
-                fa.capacity = uint64_t(found);
-                if (st.ok() && found > 0) st = EmitRegionGroups(regionGroups, fa);
+                if (emittedAhead == 0 || found > emittedAhead) {
+                    st = prepareOutputs(found);
+                    fa.capacity = uint64_t(found);
+                    if (st.ok() && found > 0) st = EmitRegionGroups(regionGroups, fa);
+                }
             }
             // (the buffers of the sort and of the region pass are freed on the way out of this block: the stream has to be
             // past their last use)
