@@ -48,8 +48,11 @@ constexpr int kRadixTile = kBlock * kRadixPerThread;
 __device__ __forceinline__ void RadixChunk(const RadixArgs& a, uint32_t& begin, uint32_t& end) {
     const int seg = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
     // (a segment left by a round with cursors: at seg * seg_cap, seg_count[seg] records of it)
-    const uint32_t s0 = a.seg_count != nullptr ? uint32_t(seg) * a.seg_cap : a.seg_start[seg];
-    const uint32_t s1 = a.seg_count != nullptr ? s0 + (a.seg_count[seg] < a.seg_cap ? a.seg_count[seg] : a.seg_cap) : a.seg_start[seg + 1];
+    // (no seg_start at all: one segment, the `stride` records of src)
+    const bool whole = a.seg_count == nullptr && a.seg_start == nullptr;
+    const uint32_t s0 = whole ? 0u : (a.seg_count != nullptr ? uint32_t(seg) * a.seg_cap : a.seg_start[seg]);
+    const uint32_t s1 = whole ? uint32_t(a.stride)
+                              : (a.seg_count != nullptr ? s0 + (a.seg_count[seg] < a.seg_cap ? a.seg_count[seg] : a.seg_cap) : a.seg_start[seg + 1]);
     uint32_t per = (s1 - s0 + uint32_t(a.chunks) - 1) / uint32_t(a.chunks);
     per = (per + kRadixTile - 1) / kRadixTile * kRadixTile;
     const uint64_t b = uint64_t(s0) + uint64_t(chunk) * per;
@@ -1041,9 +1044,19 @@ __global__ __launch_bounds__(kThreads) void RegionEmitExactKernel(const RegionEm
                 }
             }
             if (kCountOnly) {
+                // (the records of a key of many rows fill whole waves: 64 additions to one address would go one after the
+                // other, so the lanes that share the first lane's slot add their number once)
 #pragma unroll
                 for (int c = 0; c < kEmitC; ++c) {
-                    if ((live >> c) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(lAcc + slot[c]), 1ull);
+                    const bool on = ((live >> c) & 1u) != 0;
+                    const uint64_t lanesOn = __ballot(on);
+                    if (lanesOn == 0) continue;
+                    const int leader = __ffsll(static_cast<unsigned long long>(lanesOn)) - 1;
+                    const uint32_t leaderSlot = uint32_t(__builtin_amdgcn_readlane(int(slot[c]), leader));
+                    const bool shares = on && slot[c] == leaderSlot;
+                    const uint64_t sharing = __ballot(shares);
+                    const uint64_t add = shares ? (lane == leader ? uint64_t(__popcll(sharing)) : 0ull) : 1ull;
+                    if (on && add != 0) atomicAdd(reinterpret_cast<unsigned long long*>(lAcc + slot[c]), static_cast<unsigned long long>(add));
                 }
                 continue;
             }

@@ -248,7 +248,7 @@ struct RadixArgs {
     int32_t ndigits;              // 64 .. 256, a power of two
     int32_t nseg;
     int32_t chunks;               // workgroups per segment
-    const uint32_t* seg_start;    // [nseg + 1]
+    const uint32_t* seg_start;    // [nseg + 1]; nullptr: one segment, the `stride` records of src
     uint32_t* counts;             // [nseg][chunks][ndigits] records per chunk and digit; then those of the earlier chunks
     uint32_t* out_start;          // [nseg * ndigits + 1] first record of each (segment, digit) in dst
     // Without a counting pass: (segment, digit) number b of dst has room for bucket_cap records from b * bucket_cap on

@@ -95,12 +95,10 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
     int64_t workgroups = 768;
     if (const char* env = std::getenv("SSA_RADIX_WORKGROUPS")) workgroups = std::max(64, std::atoi(env));  // experiments
     ra.chunks = int(std::min<int64_t>(workgroups, std::max<int64_t>(1, (rows + 16383) / 16384)));
-    BufferPtr segA = Buffer::Alloc(64), countsA = Buffer::Alloc(size_t(ra.chunks) * ra.ndigits * 4), startA = Buffer::Alloc(size_t(ra.ndigits + 1) * 4 + 64);
-    if (!segA || !countsA || !startA) return Status::Hip("out of device memory");
-    out.keep.insert(out.keep.end(), {segA, countsA, startA});
-    const uint32_t whole[2] = {0u, uint32_t(rows)};
-    SSA_HIP(hipMemcpyAsync(segA->Ptr, whole, sizeof(whole), hipMemcpyHostToDevice, StreamHandle));
-    ra.seg_start = static_cast<const uint32_t*>(segA->Ptr);
+    BufferPtr countsA = Buffer::Alloc(size_t(ra.chunks) * ra.ndigits * 4), startA = Buffer::Alloc(size_t(ra.ndigits + 1) * 4 + 64);
+    if (!countsA || !startA) return Status::Hip("out of device memory");
+    out.keep.insert(out.keep.end(), {countsA, startA});
+    ra.seg_start = nullptr;  // (one segment: the scan's `rows` records)
     ra.counts = static_cast<uint32_t*>(countsA->Ptr);
     ra.out_start = static_cast<uint32_t*>(startA->Ptr);
     // the cursors and the overflow word: one buffer, zeroed once (digit d's place starts at d * cap: no table of starts)
@@ -166,7 +164,6 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
         out.keep.push_back(countsB);
         out.keep.push_back(startB);
     }
-    // (the whole stack of whole[] is read by the copy above: the caller synchronises the stream before it returns)
     return Status::OK();
 }
 
