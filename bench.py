@@ -376,11 +376,11 @@ def main():
                      "unit": "rows/s", "ms_per_step": 1e3 * e / args.steps, "algorithmic_bytes_per_row": bpr,
                      "groups": res[0].rows if k == "cb_userid" else len(next(iter(res[0].values())).valid)}
             if k == "cb_userid":
-                # scan, two rounds of the sort, the region pass, the move to the output: several kernels, priced as a step
+                # scan, two rounds of the sort (the second with a counting pass), the region pass, the move to the output: several kernels, priced as a step
                 # against the bytes of the key column
                 entry["roofline"] = {"bound": "hbm", "achieved": cb_rows * bpr / (e / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                      "frac": cb_rows * bpr / (e / args.steps) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                                     "kernel": "the whole step: ssa_spec_keyed_plain, RadixCount/Scatter x2, RegionEmitExactKernel, RegionCompactEmitKernel",
+                                     "kernel": "the whole step: ssa_spec_keyed_plain, RadixScatter, RadixCount + RadixScatter, RegionEmitExactKernel, RegionCompactEmitKernel",
                                      "algorithmic_bytes_per_launch": int(cb_rows * bpr)}
             else:
                 entry["roofline"] = roofline_of(k, prog, kernel_ms, launches, algo_bytes, s.local.SpecializationStats()[2],
