@@ -1146,11 +1146,11 @@ __global__ __launch_bounds__(kThreads) void RegionEmitExactKernel(const RegionEm
         const uint64_t row0 = uint64_t(region) * uint64_t(R);
         for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kThreads) {
             const int i = lList[idx];
-            uint64_t elo = lLo[i < R ? i : 0], ehi = two ? lHi[i < R ? i : 0] : 0ull;
-            if (raw) RawKeyWords(i == R ? kEmpty : elo, elo, ehi);
-            a.tmp_lo[row0 + idx] = elo;
-            if (kRaw || kTwo) a.tmp_hi[row0 + idx] = ehi;
-            a.tmp_seen[row0 + idx] = anyCheck ? lSeen[i] : 0u;
+            // (a raw 64-bit key leaves as the one word it is; seen flags only where an aggregate looks at them)
+            const uint64_t elo = lLo[i < R ? i : 0];
+            a.tmp_lo[row0 + idx] = raw && i == R ? kEmpty : elo;
+            if (kTwo) a.tmp_hi[row0 + idx] = lHi[i < R ? i : 0];
+            if (anyCheck) a.tmp_seen[row0 + idx] = lSeen[i];
         }
         for (int k = 0; k < naggs; ++k) {
             for (uint32_t idx = threadIdx.x; idx < ngroups; idx += kThreads) a.tmp_acc[size_t(k) * a.tmp_stride + row0 + idx] = lAcc[size_t(k) * R1 + lList[idx]];
@@ -1174,6 +1174,11 @@ __global__ __launch_bounds__(kBlock) void RegionCompactEmitKernel(const RegionEm
     const RegionEmitArgs& a = KernArgsAs<RegionEmitArgs>();
     const KeyedFinalizeArgs& f = a.f;
     const int R = a.region_slots;
+    // what the pass over exact keys leaves out: the second word of a raw 64-bit key (tmp_lo holds the key as one word), the
+    // seen flags when no aggregate looks at them
+    const bool raw = !f.hashed && a.s.rec_raw64 != 0;
+    bool seenKept = f.hashed != 0;
+    for (int k = 0; k < a.s.naggs; ++k) seenKept = seenKept || a.s.aggs[k].check_valid != 0;
     for (int region = blockIdx.x; region < a.nregions; region += gridDim.x) {
         const uint32_t n = a.region_groups[region];
         const int64_t base = a.region_offsets[region];
@@ -1181,9 +1186,11 @@ __global__ __launch_bounds__(kBlock) void RegionCompactEmitKernel(const RegionEm
         const uint64_t row0 = uint64_t(region) * uint64_t(R);
         for (uint32_t idx = threadIdx.x; idx < n; idx += kBlock) {
             const uint64_t at = row0 + idx;
-            const uint64_t khi = (!f.hashed && f.two_words) ? a.tmp_hi[at] : 0ull;
+            uint64_t klo = a.tmp_lo[at];
+            uint64_t khi = (!f.hashed && f.two_words && !raw) ? a.tmp_hi[at] : 0ull;
+            if (raw) RawKeyWords(klo, klo, khi);
             const uint64_t rep = f.group_rep_row != nullptr ? a.tmp_rep[at] : 0ull;
-            EmitGroup(f, base + idx, a.tmp_lo[at], khi, a.tmp_seen[at], rep, [&](int j) { return a.tmp_acc[size_t(j) * a.tmp_stride + at]; });
+            EmitGroup(f, base + idx, klo, khi, seenKept ? a.tmp_seen[at] : 0u, rep, [&](int j) { return a.tmp_acc[size_t(j) * a.tmp_stride + at]; });
         }
     }
 }
