@@ -2127,7 +2127,8 @@ Status Executor::RunKeyedScan(const TProgramStep& step, const StepPlan& plan, co
             if (a.kind != AGG_COUNT) ++nvals;
             if (a.check_valid || a.kind == AGG_MIN_F || a.kind == AGG_MAX_F) needMask = true;
         }
-        // (the records and their sorted copy: at most 32 GB of HBM)
+        // (the records and their sorted copy: at most 32 GB of HBM -- half as much again while the sort's first round gives
+        // its digits room to spare and its second writes to arrays of its own)
         const double recordBytes = 2.0 * double(in.Rows) * (8 + (twoWords ? 8 : 0) + 8 * nvals + (needMask ? 4 : 0) + (hashed ? 4 : 0));
         can = can && recordBytes <= 32e9;
         deferWanted = can && mode != 0 && (mode == 1 || (hint.Groups >= (int64_t(1) << 20) && in.Rows >= (int64_t(1) << 22)));
