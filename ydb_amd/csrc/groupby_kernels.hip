@@ -178,17 +178,19 @@ __global__ __launch_bounds__(1024) void RadixStartScanKernel(const RadixArgs) {
     if (threadIdx.x == 0) a.out_start[0] = 0;
 }
 
-// The records to their places.  A tile of the chunk is first ordered by digit inside LDS (indices only), then written
-// out in that order: neighbouring lanes then write neighbouring records of one (segment, digit), whole lines at a time.
-// kRaw: 64-bit keys in one word (RadixArgs.raw64) -- the ordered tile keeps no key words in LDS (they are read once more,
-// from the cache, where they are written out), which lets twice the workgroups share a CU.
+// The records to their places.  A tile of the chunk is first ordered by digit inside LDS (the first key words and the
+// records' indices in the tile), then written out in that order: neighbouring lanes then write neighbouring records of
+// one (segment, digit), whole lines at a time.  kRaw: 64-bit keys in one word (RadixArgs.raw64).
+// (Raw keys were once kept out of LDS and read a second time where they were written out -- from the cache, mostly, but
+// the counters saw 1.35 GB read per round for 0.8 GB of records, and the second round trip to memory in every tile cost
+// more than the 32 KB of LDS: 615 -> 553 us a round for a hundred million keys.)
 template <bool kRaw, int kPer>
 __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
     constexpr int kTile = kBlock * kPer;  // (a chunk is whole tiles of kTile records: its last tile here may be half of one)
     const RadixArgs& a = KernArgsAs<RadixArgs>();
     __shared__ uint32_t lCursor[256], lCount[256], lBase[256 + 1];
     __shared__ uint32_t lWave[kBlock / 64];
-    __shared__ uint64_t lSortedLo[kRaw ? 1 : kTile];
+    __shared__ uint64_t lSortedLo[kTile];
     __shared__ uint16_t lOrder[kTile];
     __shared__ uint8_t lDigit[kTile];
     const int seg = blockIdx.x / a.chunks;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         for (int u = 0; u < kPer; ++u) {
             if (digit[u] == 0xFFFFFFFFu) continue;
             const uint32_t at = lBase[digit[u]] + rank[u];
-            if (!raw) lSortedLo[at] = lo[u];
+            lSortedLo[at] = raw ? (lo[u] | (hi[u] << 63)) : lo[u];  // (a raw key: the word as it came)
             lOrder[at] = uint16_t(u * kBlock + threadIdx.x);
             lDigit[at] = uint8_t(digit[u]);
         }
@@ -295,8 +297,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
         const uint32_t room0 = (uint32_t(seg) * uint32_t(a.ndigits) + 1u) * a.bucket_cap;
         auto fits = [&](uint32_t d, uint32_t at) { return !byCursor || at < room0 + d * a.bucket_cap; };
         if (raw && !more) {
-            // One word a record, read once more from the cache: the reads of a thread's kPer records first, all of them in
-            // flight together, then the writes (a read and a write per trip of the loop below is a round trip per record).
+            // One word a record: the places and words of a thread's kPer records first, then the writes
             uint64_t word[kPer];
             uint32_t to[kPer];
 #pragma unroll
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
                 const uint32_t d = there ? lDigit[p] : 0u;
                 to[j] = there ? lCursor[d] + (p - lBase[d]) : 0xFFFFFFFFu;
                 if (!fits(d, to[j])) to[j] = 0xFFFFFFFFu;
-                word[j] = a.src.lo[r0 + (there ? uint32_t(lOrder[p]) : 0u)];
+                word[j] = lSortedLo[there ? p : 0u];
             }
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
@@ -318,8 +319,7 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
             const uint32_t at = lCursor[d] + (p - lBase[d]);
             if (!fits(d, at)) continue;
             const uint32_t r = r0 + lOrder[p];
-            // (64-bit keys in one word: the word as it came, read once more -- from the cache)
-            a.dst.lo[at] = raw ? a.src.lo[r] : lSortedLo[raw ? 0 : p];
+            a.dst.lo[at] = lSortedLo[p];
             if (!more) continue;
             if (two && !raw) a.dst.hi[at] = a.src.hi[r];
             if (a.dst.mask != nullptr) a.dst.mask[at] = a.src.mask[r];
