@@ -91,8 +91,9 @@ Status Executor::SortDeferredRecords(const KeyedSink& sink, int64_t rows, int nv
     ra.digit_shift = bitsB;
     ra.ndigits = digitsA;
     ra.nseg = 1;
-    // (three workgroups a CU; more of them -- raw keys leave room for six -- measured slower: shorter chunks, shorter runs)
-    int64_t workgroups = 768;
+    // (two workgroups a CU, of the three that a tile's 47 KB of LDS allow: 256 / 384 / 512 / 640 / 768 / 1024 workgroups
+    // measured 3.20 / 2.72 / 2.48 / 2.57 / 2.53 / 2.55 ms per step of a hundred million 64-bit keys)
+    int64_t workgroups = 512;
     if (const char* env = std::getenv("SSA_RADIX_WORKGROUPS")) workgroups = std::max(64, std::atoi(env));  // experiments
     ra.chunks = int(std::min<int64_t>(workgroups, std::max<int64_t>(1, (rows + 16383) / 16384)));
     BufferPtr countsA = Buffer::Alloc(size_t(ra.chunks) * ra.ndigits * 4), startA = Buffer::Alloc(size_t(ra.ndigits + 1) * 4 + 64);
