@@ -60,27 +60,32 @@ __device__ __forceinline__ void RadixChunk(const RadixArgs& a, uint32_t& begin, 
     end = b + per < s1 ? uint32_t(b + per) : s1;
 }
 
-__global__ __launch_bounds__(kBlock) void RadixCountKernel(const RadixArgs) {
+// (four times the scatter's threads on the same chunk, every 256 of them a tile at a time: the pass only reads, and a chunk's
+// one workgroup -- two a CU -- had too few loads in flight to keep the memory busy: 232 us for 0.8 GB)
+constexpr int kCountThreads = 4 * kBlock;
+__global__ __launch_bounds__(kCountThreads) void RadixCountKernel(const RadixArgs) {
     const RadixArgs& a = KernArgsAs<RadixArgs>();
     __shared__ uint32_t lHist[256];
-    lHist[threadIdx.x] = 0;
+    const uint32_t tid = threadIdx.x & uint32_t(kBlock - 1), sub = threadIdx.x / uint32_t(kBlock);
+    if (threadIdx.x < 256) lHist[threadIdx.x] = 0;
     __syncthreads();
     uint32_t begin, end;
     RadixChunk(a, begin, end);
     const bool two = a.two_words != 0, raw = a.raw64 != 0;
-    for (uint32_t r0 = begin; r0 < end; r0 += kRadixTile) {
+    for (uint64_t t0 = uint64_t(begin) + uint64_t(sub) * kRadixTile; t0 < end; t0 += uint64_t(kCountThreads / kBlock) * kRadixTile) {
+        const uint32_t r0 = uint32_t(t0);
         // (loads without conditions, so that all of them are in flight together: a row past the end reads the last one)
         uint64_t lo[kRadixPerThread], hi[kRadixPerThread];
 #pragma unroll
         for (int u = 0; u < kRadixPerThread; ++u) {
-            const uint32_t r = r0 + u * kBlock + threadIdx.x;
+            const uint32_t r = r0 + u * kBlock + tid;
             lo[u] = a.src.lo[r < end ? r : end - 1];
             hi[u] = 0;
         }
         if (two && !raw) {
 #pragma unroll
             for (int u = 0; u < kRadixPerThread; ++u) {
-                const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                const uint32_t r = r0 + u * kBlock + tid;
                 hi[u] = a.src.hi[r < end ? r : end - 1];
             }
         }
@@ -95,13 +100,13 @@ __global__ __launch_bounds__(kBlock) void RadixCountKernel(const RadixArgs) {
             if (a.present != nullptr) {
 #pragma unroll
                 for (int u = 0; u < kRadixPerThread; ++u) {
-                    const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                    const uint32_t r = r0 + u * kBlock + tid;
                     pres[u] = a.present[(r < end ? r : end - 1) >> 6];
                 }
             }
 #pragma unroll
             for (int u = 0; u < kRadixPerThread; ++u) {
-                const uint32_t r = r0 + u * kBlock + threadIdx.x;
+                const uint32_t r = r0 + u * kBlock + tid;
                 const bool there = r < end && ((pres[u] >> (r & 63u)) & 1ull) != 0;
                 uint64_t l, h;
                 RawKeyWords(lo[u], l, h);
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void RadixCountKernel(const RadixArgs) {
         }
 #pragma unroll
         for (int u = 0; u < kRadixPerThread; ++u) {
-            if (r0 + u * kBlock + threadIdx.x >= end) lo[u] = kEmpty;
+            if (r0 + u * kBlock + tid >= end) lo[u] = kEmpty;
         }
 #pragma unroll
         for (int u = 0; u < kRadixPerThread; ++u) {
@@ -1326,7 +1331,7 @@ hipError_t LaunchKeyedTableInit(const KeyedSink& sink, bool twoWords, bool hashe
 }
 
 hipError_t LaunchRadixCount(const RadixArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(RadixCountKernel, dim3(uint32_t(a.nseg * a.chunks)), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(RadixCountKernel, dim3(uint32_t(a.nseg * a.chunks)), dim3(kCountThreads), 0, st, a);
     return hipGetLastError();
 }
 
