@@ -152,6 +152,30 @@ def test_string_keys_with_few_hash_values(monkeypatch):
     compare_batches(region, oracle, key_names=["s"])
 
 
+def test_string_keys_that_differ_in_their_last_bytes(monkeypatch):
+    """Long keys that share a hash (a debug switch of the library) are told apart by their bytes: keys of 9 .. 80 bytes
+    that differ in the last byte only, keys that are the start of other keys, and the column's last string, whose bytes
+    end where the buffer ends."""
+    rng = np.random.default_rng(513)
+    stem = "the quick brown fox jumps over the lazy dog and runs on through the fields of barley and rye"
+    words = []
+    for n in list(range(9, 81)):
+        words += [stem[:n - 1] + c for c in "abc"]
+    words += [stem[:n] for n in (10, 20, 31, 32, 33, 40, 64)]
+    words = sorted(set(words))
+    n = 30_000
+    pick = rng.integers(0, len(words), n)
+    pick[-1] = len(words) - 1
+    batch = {"s": Col([words[i] for i in pick], type="string"), "v": rng.integers(0, 9, n).astype(np.int32)}
+    res = [(1, "s"), (2, "v")]
+    p = Program().group_by([Aggregate(100, AGG.COUNT, []), Aggregate(101, AGG.SUM, [2])], keys=[1])
+    monkeypatch.setenv("SSA_DEBUG_FLAGS", "64")
+    region, direct, oracle = run_three_ways(monkeypatch, res, p, batch, lds="16,1")
+    assert len(oracle["s"].values) == len(words) if hasattr(oracle["s"], "values") else True
+    compare_batches(region, direct, key_names=["s"])
+    compare_batches(region, oracle, key_names=["s"])
+
+
 def test_float_min_max_skip_nans(monkeypatch):
     rng = np.random.default_rng(506)
     n = 150_000

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void RegionApplyKernel(const RegionApplyArg
             if (hashed && (hi >> 63) != 0) {
                 const uint64_t row = a.rec.row[i];
                 g = TableUpsertVerified(lLo, lHi, lRep, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, row, uint32_t(R),
-                                        [&](uint64_t rep) { return SameKeyRows(a.cols, s, row, rep); });
+                                        [&](uint64_t rep) { return SameKeyRows<4>(a.cols, s, row, rep); });
             } else {
                 g = TableUpsert(lLo, lHi, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, two, uint32_t(R));
                 if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(lRep + g), static_cast<unsigned long long>(a.rec.row[i]));
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(kBlock) void RegionEmitKernel(const RegionEmitArgs)
             if (hashed && (hi >> 63) != 0) {
                 const uint64_t row = s.t_rep_row[small0 + i];
                 g = TableUpsertVerified(lLo, lHi, lRep, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, row, uint32_t(R),
-                                        [&](uint64_t rep) { return SameKeyRows(a.cols, s, row, rep); });
+                                        [&](uint64_t rep) { return SameKeyRows<4>(a.cols, s, row, rep); });
             } else {
                 g = TableUpsert(lLo, lHi, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, two, uint32_t(R));
                 if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(lRep + g), static_cast<unsigned long long>(s.t_rep_row[small0 + i]));
@@ -771,6 +771,11 @@ __global__ __launch_bounds__(kBlock) void RegionEmitKernel(const RegionEmitArgs)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) masks[j] = a.rec.mask[i0 + j * kBlock < last ? i0 + j * kBlock : i0];
             }
+            uint32_t rows[4] = {0, 0, 0, 0};  // (with the other words of the records: not a load and a wait per record)
+            if (hashed) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rows[j] = a.rec.row[i0 + j * kBlock < last ? i0 + j * kBlock : i0];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t i = i0 + j * kBlock;
@@ -780,12 +785,12 @@ __global__ __launch_bounds__(kBlock) void RegionEmitKernel(const RegionEmitArgs)
                 const uint32_t start = RegionLdsStart(Fold32(lo, hi), ldsShift);
                 int64_t g;
                 if (hashed && (hi >> 63) != 0) {
-                    const uint64_t row = a.rec.row[i];
+                    const uint64_t row = rows[j];
                     g = TableUpsertVerified(lLo, lHi, lRep, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, row, uint32_t(R),
-                                            [&](uint64_t rep) { return SameKeyRows(a.cols, s, row, rep); });
+                                            [&](uint64_t rep) { return SameKeyRows<4>(a.cols, s, row, rep); });
                 } else {
                     g = TableUpsert(lLo, lHi, uint64_t(R - 1), uint64_t(R - 1), start, lo, hi, two, uint32_t(R));
-                    if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(lRep + g), static_cast<unsigned long long>(a.rec.row[i]));
+                    if (hashed && g >= 0) atomicMin(reinterpret_cast<unsigned long long*>(lRep + g), static_cast<unsigned long long>(rows[j]));
                 }
                 if (g < 0) {
                     err |= SCAN_TABLE_FULL;

@@ -197,6 +197,11 @@ __device__ __forceinline__ int64_t TableUpsert(uint64_t* tLo, uint64_t* tHi, uin
 // table key is a hash (a string of more than 8 bytes, more than 119 key bits): the hash finds a slot, this decides
 // whether the slot's group is the row's -- equal hashes of different keys end up in different slots.  Such steps take
 // all their keys from input columns.  A string whose offsets do not describe the chars buffer counts as empty.
+// kWords: 8-byte words of both strings that are loaded together (a load, a compare and a branch per word is a round trip
+// to memory per 8 bytes): 4 in the region passes, which wait for these loads and little else; 1 in the scan, whose
+// registers are better spent on rows in flight.  The last bytes of a string are compared as masked words where both
+// buffers have the bytes to read, not byte by byte.
+template <int kWords = 1>
 __device__ __noinline__ bool SameKeyRows(const DevColumn* cols, const KeyedSink& s, uint64_t r1, uint64_t r2) {
     if (r1 == r2) return true;
     for (int k = 0; k < s.nkeys; ++k) {
@@ -210,7 +215,42 @@ __device__ __noinline__ bool SameKeyRows(const DevColumn* cols, const KeyedSink&
             if (n1 != n2) return false;
             const uint8_t* p = col.chars + b1;
             const uint8_t* q = col.chars + b2;
+            constexpr int32_t kStep = 8 * kWords;
             int32_t i = 0;
+            for (; i + kStep <= n1; i += kStep) {
+                uint64_t x[kWords], y[kWords], diff = 0;
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) {
+                    __builtin_memcpy(&x[w], p + i + 8 * w, 8);
+                    __builtin_memcpy(&y[w], q + i + 8 * w, 8);
+                }
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) diff |= x[w] ^ y[w];
+                if (diff != 0) return false;
+            }
+            if (i == n1) continue;
+            // the last 1 .. kStep - 1 bytes: the same loads where both buffers have kStep readable bytes from here on (no
+            // sectors fetched for words behind the strings' ends), the bytes past the ends masked away
+            if (int64_t(b1) + i + kStep <= int64_t(col.chars_bytes) && int64_t(b2) + i + kStep <= int64_t(col.chars_bytes)) {
+                const int32_t rest = n1 - i;
+                uint64_t x[kWords], y[kWords], diff = 0;
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) {
+                    x[w] = y[w] = 0;
+                    if (8 * w < rest) {
+                        __builtin_memcpy(&x[w], p + i + 8 * w, 8);
+                        __builtin_memcpy(&y[w], q + i + 8 * w, 8);
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) {
+                    const int32_t m = rest - 8 * w;  // bytes of this word that belong to the strings
+                    const uint64_t keep = m >= 8 ? ~0ull : (m <= 0 ? 0ull : (1ull << (8 * m)) - 1ull);
+                    diff |= (x[w] ^ y[w]) & keep;
+                }
+                if (diff != 0) return false;
+                continue;
+            }
             for (; i + 8 <= n1; i += 8) {
                 uint64_t x, y;
                 __builtin_memcpy(&x, p + i, 8);
