@@ -318,18 +318,62 @@ __global__ __launch_bounds__(kBlock) void RadixScatterKernel(const RadixArgs) {
             for (int j = 0; j < kPer; ++j) {
                 if (to[j] != 0xFFFFFFFFu) a.dst.lo[to[j]] = word[j];
             }
-        } else
-        for (uint32_t p = threadIdx.x; p < n; p += kBlock) {
-            const uint32_t d = lDigit[p];
-            const uint32_t at = lCursor[d] + (p - lBase[d]);
-            if (!fits(d, at)) continue;
-            const uint32_t r = r0 + lOrder[p];
-            a.dst.lo[at] = lSortedLo[p];
-            if (!more) continue;
-            if (two && !raw) a.dst.hi[at] = a.src.hi[r];
-            if (a.dst.mask != nullptr) a.dst.mask[at] = a.src.mask[r];
-            if (a.dst.row != nullptr) a.dst.row[at] = a.src.row != nullptr ? a.src.row[r] : r;
-            for (int v = 0; v < a.nvals; ++v) a.dst.val[size_t(v) * size_t(dstStride) + at] = a.src.val[size_t(v) * size_t(a.stride) + r];
+        } else {
+            // Records of several words: four of a thread's records at a time, and of each array the four reads first, in
+            // flight together, then the four writes (a read and a write per record and array is a round trip to memory
+            // each: the compiler keeps a read behind the write before it, the arrays might overlap).
+            constexpr int kGroup = 4;
+            for (int j0 = 0; j0 < kPer && uint32_t(j0) * kBlock < n; j0 += kGroup) {
+                uint32_t to[kGroup], r[kGroup];
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) {
+                    const uint32_t p = uint32_t(j0 + j) * kBlock + threadIdx.x;
+                    const bool there = p < n;
+                    const uint32_t d = there ? lDigit[p] : 0u;
+                    to[j] = there ? lCursor[d] + (p - lBase[d]) : 0xFFFFFFFFu;
+                    if (!fits(d, to[j])) to[j] = 0xFFFFFFFFu;
+                    r[j] = r0 + (there ? uint32_t(lOrder[p]) : 0u);  // (a record of the tile in any case: reads need no condition)
+                    if (to[j] != 0xFFFFFFFFu) a.dst.lo[to[j]] = lSortedLo[p];
+                }
+                if (two && !raw) {
+                    uint64_t w[kGroup];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) w[j] = a.src.hi[r[j]];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) {
+                        if (to[j] != 0xFFFFFFFFu) a.dst.hi[to[j]] = w[j];
+                    }
+                }
+                if (a.dst.mask != nullptr) {
+                    uint32_t w[kGroup];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) w[j] = a.src.mask[r[j]];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) {
+                        if (to[j] != 0xFFFFFFFFu) a.dst.mask[to[j]] = w[j];
+                    }
+                }
+                if (a.dst.row != nullptr) {
+                    uint32_t w[kGroup];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) w[j] = a.src.row != nullptr ? a.src.row[r[j]] : r[j];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) {
+                        if (to[j] != 0xFFFFFFFFu) a.dst.row[to[j]] = w[j];
+                    }
+                }
+                for (int v = 0; v < a.nvals; ++v) {
+                    const uint64_t* from = a.src.val + size_t(v) * size_t(a.stride);
+                    uint64_t* into = a.dst.val + size_t(v) * size_t(dstStride);
+                    uint64_t w[kGroup];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) w[j] = from[r[j]];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) {
+                        if (to[j] != 0xFFFFFFFFu) into[to[j]] = w[j];
+                    }
+                }
+            }
         }
         __syncthreads();
         if (!byCursor) lCursor[threadIdx.x] += lCount[threadIdx.x];
